@@ -1,0 +1,72 @@
+/*
+ * jpeggpu_ext.h -- additive entry points next to the drop-in API of jpeggpu.h. Nothing here exists in
+ * the reference; callers that only use jpeggpu.h never need this header.
+ *
+ *   jpeggpu_ext_set_subsequence_bytes  tuning knob the reference leaves as a compile-time constant
+ *                                      (src/decoder_defs.hpp:28-34 `chunk_size`)
+ *   jpeggpu_ext_get_layout             where the intermediate buffers of the last parsed image sit
+ *                                      inside d_tmp, for stage-level parity tests and profiling
+ *   jpeggpu_ext_upsample_planes        nearest-neighbour chroma replication on the device, the integer
+ *                                      part of the reference's host helper util/util.h:62-91
+ */
+#ifndef JPEGGPU_JPEGGPU_EXT_H_
+#define JPEGGPU_JPEGGPU_EXT_H_
+
+#include <jpeggpu/jpeggpu.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+/* 32, 64 or 128. Takes effect at the next jpeggpu_decoder_parse_header. Default 128 (the reference's
+ * value) unless the environment variable JPEGGPU_SUBSEQ_BYTES overrides it at startup. */
+enum jpeggpu_status jpeggpu_ext_set_subsequence_bytes(jpeggpu_decoder_t decoder, int subseq_bytes);
+
+struct jpeggpu_ext_scan_layout {
+    int num_components;        /* components in this scan */
+    int component_idx[JPEGGPU_MAX_COMP];
+    int num_subsequences;
+    int num_segments;
+    int num_sequences;         /* workgroups of the Huffman kernels */
+    int num_data_units;
+    int data_units_per_mcu;
+    int num_chunks;            /* destuff work items */
+    /* byte offsets inside d_tmp */
+    size_t off_segments;       /* {int subseq_offset, subseq_count}[num_segments] */
+    size_t off_chunks;
+    size_t off_destuffed;      /* uint8[num_subsequences * subsequence_bytes] */
+    size_t off_segment_index;  /* int[num_subsequences] */
+    size_t off_state_p;        /* int[num_subsequences] */
+    size_t off_state_n;
+    size_t off_state_cz;       /* c | z << 8 */
+    size_t off_state_dc[JPEGGPU_MAX_COMP];
+    size_t off_coefficients;   /* int16[num_data_units * 64], stream order, natural order inside */
+};
+
+struct jpeggpu_ext_layout {
+    int subsequence_bytes;
+    int num_scans;
+    size_t transferred_bytes;  /* entropy-coded byte range copied by jpeggpu_decoder_transfer */
+    size_t blob_bytes;         /* table blob copied by jpeggpu_decoder_transfer */
+    size_t off_bytes;          /* stuffed bytes inside d_tmp */
+    size_t off_qtables;        /* uint8[4][64], natural order */
+    struct jpeggpu_ext_scan_layout scans[JPEGGPU_MAX_COMP];
+};
+
+enum jpeggpu_status jpeggpu_ext_get_layout(jpeggpu_decoder_t decoder, struct jpeggpu_ext_layout* layout);
+
+/* Replicate every plane of `src` (as produced by jpeggpu_decoder_decode for `info`) to the full
+ * image resolution: dst[c][y][x] = src[c][y * sy_c / sy_max][x * sx_c / sx_max]. */
+enum jpeggpu_status jpeggpu_ext_upsample_planes(
+    const struct jpeggpu_img_info* info,
+    const struct jpeggpu_img* src,
+    struct jpeggpu_img* dst,
+    int width,
+    int height,
+    jpeggpu_stream_t stream);
+
+#ifdef __cplusplus
+}
+#endif
+
+#endif /* JPEGGPU_JPEGGPU_EXT_H_ */

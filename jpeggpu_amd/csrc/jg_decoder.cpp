@@ -1,0 +1,496 @@
+// jg_decoder.cpp -- per-image orchestration and the exported C ABI (include/jpeggpu/jpeggpu.h).
+//
+// Counterpart of the reference's src/jpeggpu.cpp:39-160 (argument checks, status strings) and
+// src/decoder.cpp:67-354 (parse -> size -> transfer -> decode). Differences by design:
+//   * one `plan` carves d_tmp for get_buffer_size / transfer / decode alike (the reference replays
+//     decode_impl<false>, decoder.cpp:327-334);
+//   * transfer ships the entropy-coded byte range plus ONE pinned table blob (2 copies instead of
+//     ~10, and no post-EOI trailer; decoder.cpp:175-208);
+//   * coefficients stay in stream order; there are no per-component coefficient planes, no transpose
+//     pass and no DC pass (decoder.cpp:240-314).
+#include "jg_kernels.hpp"
+#include "jg_reader.hpp"
+
+#include <jpeggpu/jpeggpu.h>
+#include <jpeggpu/jpeggpu_ext.h>
+
+#include <hip/hip_runtime.h>
+
+#include <cstdlib>
+#include <cstring>
+#include <new>
+
+namespace jg {
+
+namespace {
+
+inline size_t align_up(size_t v, size_t a) { return (v + a - 1) / a * a; }
+
+/// Host staging memory for the table blob: page-locked when a HIP device is present (so the copy
+/// enqueued by transfer is asynchronous), pageable otherwise (header parsing needs no GPU).
+struct StagingBuffer {
+    uint8_t* ptr  = nullptr;
+    size_t cap    = 0;
+    bool pinned   = false;
+
+    bool reserve(size_t n)
+    {
+        if (n <= cap) return true;
+        release();
+        const size_t want = align_up(n + n / 2, 4096);
+        void* p           = nullptr;
+        if (hipHostMalloc(&p, want, hipHostMallocDefault) == hipSuccess && p) {
+            pinned = true;
+        } else {
+            (void)hipGetLastError();
+            p      = std::malloc(want);
+            pinned = false;
+        }
+        if (!p) return false;
+        ptr = static_cast<uint8_t*>(p);
+        cap = want;
+        return true;
+    }
+    void release()
+    {
+        if (ptr) {
+            if (pinned) (void)hipHostFree(ptr);
+            else std::free(ptr);
+        }
+        ptr = nullptr;
+        cap = 0;
+    }
+};
+
+struct ScanPlan {
+    // offsets inside the blob (and, shifted by off_blob, inside d_tmp)
+    size_t blob_tables = 0, blob_segments = 0, blob_chunks = 0;
+    // offsets inside d_tmp
+    size_t destuffed = 0, seg_idx = 0, st_p = 0, st_n = 0, st_cz = 0, st_dc[kMaxComp] = {};
+    size_t tails_n = 0, tails_dc[kMaxComp] = {};
+    size_t coef = 0;
+    int num_seq = 0;
+};
+
+struct Plan {
+    size_t off_bytes = 0, bytes_len = 0;
+    size_t off_blob = 0, blob_size = 0;
+    size_t blob_qtables = 0;
+    size_t off_coef_all = 0, coef_all_bytes = 0;
+    size_t total = 0;
+    ScanPlan scan[kMaxScans];
+};
+
+} // namespace
+
+struct Decoder {
+    Reader reader;
+    Logger logger;
+    StagingBuffer blob;
+    Plan plan;
+    const uint8_t* data = nullptr;
+    size_t data_size    = 0;
+    int subseq_bytes    = 128;
+    bool parsed         = false;
+
+    void make_plan();
+    bool fill_blob();
+};
+
+void Decoder::make_plan()
+{
+    const Stream& s = reader.s;
+    Plan p;
+    // table blob
+    size_t b       = 0;
+    p.blob_qtables = b;
+    b += align_up(sizeof(s.qtable), 256);
+    for (int i = 0; i < s.num_scans; ++i) {
+        const Scan& sc    = s.scans[i];
+        ScanPlan& sp      = p.scan[i];
+        sp.blob_tables    = b;
+        b += align_up(sizeof(sc.tables), 256);
+        sp.blob_segments  = b;
+        b += align_up(sc.segments.size() * sizeof(Segment), 256);
+        sp.blob_chunks    = b;
+        b += align_up(sc.chunks.size() * sizeof(DestuffChunk), 256);
+    }
+    p.blob_size = b;
+
+    // device carve: transferred region first, at fixed places (reference decoder.cpp:116-155)
+    size_t o    = 0;
+    p.off_bytes = o;
+    p.bytes_len = s.xfer_end - s.xfer_begin;
+    o += align_up(p.bytes_len, kDestuffWin) + kDestuffWin; // whole windows are loaded
+    p.off_blob = o;
+    o += align_up(p.blob_size, 256);
+    for (int i = 0; i < s.num_scans; ++i) {
+        const Scan& sc = s.scans[i];
+        ScanPlan& sp   = p.scan[i];
+        const size_t S = static_cast<size_t>(sc.num_subseq);
+        sp.num_seq     = static_cast<int>((S + kSeqSubseq - 1) / kSeqSubseq);
+        sp.destuffed   = o;
+        o += align_up(S * subseq_bytes + 256, 256);
+        sp.seg_idx = o;
+        o += align_up(S * 4, 256);
+        sp.st_p = o;
+        o += align_up(S * 4, 256);
+        sp.st_n = o;
+        o += align_up(S * 4, 256);
+        sp.st_cz = o;
+        o += align_up(S * 4, 256);
+        for (int k = 0; k < sc.num_comp; ++k) {
+            sp.st_dc[k] = o;
+            o += align_up(S * 4, 256);
+        }
+        sp.tails_n = o;
+        o += align_up(static_cast<size_t>(sp.num_seq) * 4, 256);
+        for (int k = 0; k < sc.num_comp; ++k) {
+            sp.tails_dc[k] = o;
+            o += align_up(static_cast<size_t>(sp.num_seq) * 4, 256);
+        }
+    }
+    // all coefficient buffers are contiguous: one memset covers them
+    p.off_coef_all = o;
+    for (int i = 0; i < s.num_scans; ++i) {
+        p.scan[i].coef = o;
+        o += align_up(static_cast<size_t>(s.scans[i].num_du) * 128, 256);
+    }
+    p.coef_all_bytes = o - p.off_coef_all;
+    p.total          = o;
+    plan             = p;
+}
+
+bool Decoder::fill_blob()
+{
+    const Stream& s = reader.s;
+    if (!blob.reserve(plan.blob_size)) return false;
+    std::memset(blob.ptr, 0, plan.blob_size);
+    std::memcpy(blob.ptr + plan.blob_qtables, s.qtable, sizeof(s.qtable));
+    for (int i = 0; i < s.num_scans; ++i) {
+        const Scan& sc     = s.scans[i];
+        const ScanPlan& sp = plan.scan[i];
+        std::memcpy(blob.ptr + sp.blob_tables, sc.tables, sizeof(sc.tables));
+        if (!sc.segments.empty())
+            std::memcpy(blob.ptr + sp.blob_segments, sc.segments.data(), sc.segments.size() * sizeof(Segment));
+        if (!sc.chunks.empty())
+            std::memcpy(blob.ptr + sp.blob_chunks, sc.chunks.data(), sc.chunks.size() * sizeof(DestuffChunk));
+    }
+    return true;
+}
+
+} // namespace jg
+
+struct jpeggpu_decoder {
+    jg::Decoder d;
+};
+
+using jg::Decoder;
+
+namespace {
+
+#define JG_CHECK_HIP(call)                                                                          \
+    do {                                                                                            \
+        const hipError_t err_ = (call);                                                             \
+        if (err_ != hipSuccess) {                                                                   \
+            d.logger.log("HIP error \"%s\" at: " __FILE__ ":%d\n", hipGetErrorString(err_), __LINE__); \
+            return JPEGGPU_INTERNAL_ERROR;                                                          \
+        }                                                                                           \
+    } while (0)
+
+jpeggpu_status do_transfer(Decoder& d, void* d_tmp, size_t tmp_size, hipStream_t stream)
+{
+    if (!d.parsed) return JPEGGPU_INVALID_ARGUMENT;
+    if (!d_tmp || (reinterpret_cast<uintptr_t>(d_tmp) & 255)) return JPEGGPU_INVALID_ARGUMENT;
+    if (tmp_size < d.plan.total) return JPEGGPU_INTERNAL_ERROR; // reference util.hpp:66-68
+    uint8_t* base = static_cast<uint8_t*>(d_tmp);
+    JG_CHECK_HIP(hipMemcpyAsync(
+        base + d.plan.off_bytes, d.data + d.reader.s.xfer_begin, d.plan.bytes_len, hipMemcpyHostToDevice, stream));
+    JG_CHECK_HIP(hipMemcpyAsync(
+        base + d.plan.off_blob, d.blob.ptr, d.plan.blob_size, hipMemcpyHostToDevice, stream));
+    return JPEGGPU_SUCCESS;
+}
+
+jpeggpu_status do_decode(Decoder& d, jpeggpu_img* img, void* d_tmp, size_t tmp_size, hipStream_t stream)
+{
+    using namespace jg;
+    if (!d.parsed) return JPEGGPU_INVALID_ARGUMENT;
+    const Stream& s = d.reader.s;
+    for (int c = 0; c < s.num_comp; ++c) {
+        if (!img->image[c] || img->pitch[c] < s.comp[c].size_x) return JPEGGPU_INVALID_ARGUMENT;
+    }
+    if (!d_tmp || (reinterpret_cast<uintptr_t>(d_tmp) & 255)) return JPEGGPU_INVALID_ARGUMENT;
+    if (tmp_size < d.plan.total) return JPEGGPU_INTERNAL_ERROR;
+    uint8_t* base     = static_cast<uint8_t*>(d_tmp);
+    const Plan& plan  = d.plan;
+    uint8_t* blob     = base + plan.off_blob;
+
+    // only non-zero coefficients are stored by the write pass
+    if (plan.coef_all_bytes)
+        JG_CHECK_HIP(hipMemsetAsync(base + plan.off_coef_all, 0, plan.coef_all_bytes, stream));
+
+    for (int i = 0; i < s.num_scans; ++i) {
+        const Scan& sc     = s.scans[i];
+        const ScanPlan& pl = plan.scan[i];
+
+        ScanParams sp{};
+        sp.num_subseq       = sc.num_subseq;
+        sp.num_segments     = static_cast<int>(sc.segments.size());
+        sp.du_per_mcu       = sc.du_per_mcu;
+        sp.num_comp         = sc.num_comp;
+        sp.mcus_per_segment = sc.mcus_per_segment;
+        sp.total_mcus       = sc.mcus_x * sc.mcus_y;
+        sp.subseq_words     = d.subseq_bytes / 4;
+        IdctParams ip{};
+        ip.num_du     = sc.num_du;
+        ip.du_per_mcu = sc.du_per_mcu;
+        ip.mcus_x     = sc.mcus_x;
+        int du        = 0;
+        for (int a = 0; a < sc.num_comp; ++a) {
+            const ScanComponent& c = sc.comp[a];
+            sp.dc_slot |= static_cast<uint32_t>(c.dc_id * 2) << (4 * a);
+            sp.ac_slot |= static_cast<uint32_t>(c.ac_id * 2 + 1) << (4 * a);
+            for (int y = 0; y < c.v; ++y) {
+                for (int x = 0; x < c.h; ++x) { // row-major inside the MCU (T.81 A.2.3)
+                    sp.du_comp |= static_cast<uint32_t>(a) << (2 * du);
+                    ip.du_comp[du] = static_cast<uint8_t>(a);
+                    ip.du_dx[du]   = static_cast<uint8_t>(x);
+                    ip.du_dy[du]   = static_cast<uint8_t>(y);
+                    ++du;
+                }
+            }
+            const Component& fc = s.comp[c.comp_idx];
+            ip.comp_h[a]        = c.h;
+            ip.comp_v[a]        = c.v;
+            ip.size_x[a]        = fc.size_x;
+            ip.size_y[a]        = fc.size_y;
+            ip.pitch[a]         = img->pitch[c.comp_idx];
+            ip.qidx[a]          = fc.qidx;
+            ip.plane[a]         = img->image[c.comp_idx];
+        }
+
+        SubseqState st{};
+        st.p  = reinterpret_cast<int*>(base + pl.st_p);
+        st.n  = reinterpret_cast<int*>(base + pl.st_n);
+        st.cz = reinterpret_cast<int*>(base + pl.st_cz);
+        SeqTails tails{};
+        tails.n = reinterpret_cast<int*>(base + pl.tails_n);
+        for (int k = 0; k < sc.num_comp; ++k) {
+            st.dc[k]    = reinterpret_cast<int*>(base + pl.st_dc[k]);
+            tails.dc[k] = reinterpret_cast<int*>(base + pl.tails_dc[k]);
+        }
+        const Segment* d_segments = reinterpret_cast<const Segment*>(blob + pl.blob_segments);
+        int* d_seg_idx            = reinterpret_cast<int*>(base + pl.seg_idx);
+        int16_t* d_coef           = reinterpret_cast<int16_t*>(base + pl.coef);
+
+        d.logger.log(
+            "scan %d: %d chunks, %d subsequences of %d bytes, %d sequences, %d segments\n",
+            i, static_cast<int>(sc.chunks.size()), sc.num_subseq, d.subseq_bytes, pl.num_seq, sp.num_segments);
+
+        JG_CHECK_HIP(launch_destuff(
+            base + plan.off_bytes,
+            base + pl.destuffed,
+            d_seg_idx,
+            reinterpret_cast<const DestuffChunk*>(blob + pl.blob_chunks),
+            static_cast<int>(sc.chunks.size()),
+            d.subseq_bytes,
+            stream));
+        JG_CHECK_HIP(launch_huffman(
+            base + pl.destuffed,
+            d_segments,
+            d_seg_idx,
+            reinterpret_cast<const HuffTableDev*>(blob + pl.blob_tables),
+            sp,
+            st,
+            tails,
+            d_coef,
+            stream));
+        JG_CHECK_HIP(launch_idct(d_coef, blob + plan.blob_qtables, ip, stream));
+    }
+    return JPEGGPU_SUCCESS;
+}
+
+} // namespace
+
+extern "C" {
+
+const char* jpeggpu_get_status_string(enum jpeggpu_status stat)
+{
+    switch (stat) { // same strings as the reference, src/jpeggpu.cpp:41-60
+    case JPEGGPU_SUCCESS: return "success";
+    case JPEGGPU_INVALID_ARGUMENT: return "invalid argument";
+    case JPEGGPU_INVALID_JPEG: return "invalid jpeg";
+    case JPEGGPU_INTERNAL_ERROR: return "internal jpeggpu error";
+    case JPEGGPU_NOT_SUPPORTED: return "jpeg is not supported";
+    case JPEGGPU_OUT_OF_HOST_MEMORY: return "out of host memory";
+    case JPEGGPU_INCOMPLETE_BITSTREAM: return "incomplete bitstream";
+    }
+    return "unknown status";
+}
+
+enum jpeggpu_status jpeggpu_decoder_startup(jpeggpu_decoder_t* decoder)
+{
+    if (!decoder) return JPEGGPU_INVALID_ARGUMENT;
+    *decoder = new (std::nothrow) jpeggpu_decoder();
+    if (*decoder == nullptr) return JPEGGPU_OUT_OF_HOST_MEMORY;
+    if (const char* e = std::getenv("JPEGGPU_SUBSEQ_BYTES")) {
+        const int v = std::atoi(e);
+        if (jg::subseq_bytes_supported(v)) (*decoder)->d.subseq_bytes = v;
+    }
+    return JPEGGPU_SUCCESS;
+}
+
+enum jpeggpu_status jpeggpu_set_logging(jpeggpu_decoder_t decoder, int do_logging)
+{
+    if (!decoder) return JPEGGPU_INVALID_ARGUMENT;
+    decoder->d.logger.enabled = do_logging != 0;
+    return JPEGGPU_SUCCESS;
+}
+
+int is_css_444(struct jpeggpu_subsampling css, int num_components)
+{
+    if (num_components < 1 || num_components > JPEGGPU_MAX_COMP) return 0;
+    for (int c = 0; c < num_components; ++c) {
+        if (css.x[c] != 1 || css.y[c] != 1) return 0;
+    }
+    return 1;
+}
+
+enum jpeggpu_status jpeggpu_decoder_parse_header(
+    jpeggpu_decoder_t decoder, struct jpeggpu_img_info* img_info, const uint8_t* data, size_t size)
+{
+    if (!decoder || !img_info || !data) return JPEGGPU_INVALID_ARGUMENT;
+    Decoder& d = decoder->d;
+    d.parsed   = false;
+    jpeggpu_status st;
+    try {
+        st = d.reader.parse(data, size, d.subseq_bytes, d.logger);
+    } catch (const std::bad_alloc&) {
+        return JPEGGPU_OUT_OF_HOST_MEMORY;
+    }
+    if (st != JPEGGPU_SUCCESS) return st;
+    const jg::Stream& s = d.reader.s;
+    std::memset(img_info, 0, sizeof(*img_info));
+    img_info->num_components = s.num_comp;
+    for (int c = 0; c < s.num_comp; ++c) {
+        img_info->sizes_x[c]       = s.comp[c].size_x;
+        img_info->sizes_y[c]       = s.comp[c].size_y;
+        img_info->subsampling.x[c] = s.comp[c].hs;
+        img_info->subsampling.y[c] = s.comp[c].vs;
+    }
+    d.data      = data;
+    d.data_size = size;
+    d.make_plan();
+    if (!d.fill_blob()) return JPEGGPU_OUT_OF_HOST_MEMORY;
+    d.parsed = true;
+    return JPEGGPU_SUCCESS;
+}
+
+enum jpeggpu_status jpeggpu_decoder_get_buffer_size(jpeggpu_decoder_t decoder, size_t* tmp_size)
+{
+    if (!decoder || !tmp_size) return JPEGGPU_INVALID_ARGUMENT;
+    if (!decoder->d.parsed) return JPEGGPU_INVALID_ARGUMENT;
+    *tmp_size = decoder->d.plan.total;
+    return JPEGGPU_SUCCESS;
+}
+
+enum jpeggpu_status jpeggpu_decoder_transfer(
+    jpeggpu_decoder_t decoder, void* d_tmp, size_t tmp_size, jpeggpu_stream_t stream)
+{
+    if (!decoder) return JPEGGPU_INVALID_ARGUMENT;
+    return do_transfer(decoder->d, d_tmp, tmp_size, stream);
+}
+
+enum jpeggpu_status jpeggpu_decoder_decode(
+    jpeggpu_decoder_t decoder, struct jpeggpu_img* img, void* d_tmp, size_t tmp_size, jpeggpu_stream_t stream)
+{
+    if (!decoder || !img) return JPEGGPU_INVALID_ARGUMENT;
+    return do_decode(decoder->d, img, d_tmp, tmp_size, stream);
+}
+
+enum jpeggpu_status jpeggpu_decoder_cleanup(jpeggpu_decoder_t decoder)
+{
+    if (!decoder) return JPEGGPU_INVALID_ARGUMENT;
+    decoder->d.blob.release();
+    delete decoder;
+    return JPEGGPU_SUCCESS;
+}
+
+enum jpeggpu_status jpeggpu_ext_set_subsequence_bytes(jpeggpu_decoder_t decoder, int subseq_bytes)
+{
+    if (!decoder || !jg::subseq_bytes_supported(subseq_bytes)) return JPEGGPU_INVALID_ARGUMENT;
+    decoder->d.subseq_bytes = subseq_bytes;
+    decoder->d.parsed       = false;
+    return JPEGGPU_SUCCESS;
+}
+
+enum jpeggpu_status jpeggpu_ext_get_layout(jpeggpu_decoder_t decoder, struct jpeggpu_ext_layout* out)
+{
+    if (!decoder || !out) return JPEGGPU_INVALID_ARGUMENT;
+    const Decoder& d = decoder->d;
+    if (!d.parsed) return JPEGGPU_INVALID_ARGUMENT;
+    const jg::Stream& s = d.reader.s;
+    std::memset(out, 0, sizeof(*out));
+    out->subsequence_bytes = d.subseq_bytes;
+    out->num_scans         = s.num_scans;
+    out->transferred_bytes = d.plan.bytes_len;
+    out->blob_bytes        = d.plan.blob_size;
+    out->off_bytes         = d.plan.off_bytes;
+    out->off_qtables       = d.plan.off_blob + d.plan.blob_qtables;
+    for (int i = 0; i < s.num_scans; ++i) {
+        const jg::Scan& sc         = s.scans[i];
+        const jg::ScanPlan& pl     = d.plan.scan[i];
+        jpeggpu_ext_scan_layout& o = out->scans[i];
+        o.num_components           = sc.num_comp;
+        for (int k = 0; k < sc.num_comp; ++k) {
+            o.component_idx[k] = sc.comp[k].comp_idx;
+            o.off_state_dc[k]  = pl.st_dc[k];
+        }
+        o.num_subsequences   = sc.num_subseq;
+        o.num_segments       = static_cast<int>(sc.segments.size());
+        o.num_sequences      = pl.num_seq;
+        o.num_data_units     = sc.num_du;
+        o.data_units_per_mcu = sc.du_per_mcu;
+        o.num_chunks         = static_cast<int>(sc.chunks.size());
+        o.off_segments       = d.plan.off_blob + pl.blob_segments;
+        o.off_chunks         = d.plan.off_blob + pl.blob_chunks;
+        o.off_destuffed      = pl.destuffed;
+        o.off_segment_index  = pl.seg_idx;
+        o.off_state_p        = pl.st_p;
+        o.off_state_n        = pl.st_n;
+        o.off_state_cz       = pl.st_cz;
+        o.off_coefficients   = pl.coef;
+    }
+    return JPEGGPU_SUCCESS;
+}
+
+enum jpeggpu_status jpeggpu_ext_upsample_planes(
+    const struct jpeggpu_img_info* info,
+    const struct jpeggpu_img* src,
+    struct jpeggpu_img* dst,
+    int width,
+    int height,
+    jpeggpu_stream_t stream)
+{
+    if (!info || !src || !dst || width <= 0 || height <= 0) return JPEGGPU_INVALID_ARGUMENT;
+    const int nc = info->num_components;
+    if (nc < 1 || nc > JPEGGPU_MAX_COMP) return JPEGGPU_INVALID_ARGUMENT;
+    int sx_max = 0, sy_max = 0;
+    for (int c = 0; c < nc; ++c) {
+        if (info->subsampling.x[c] < 1 || info->subsampling.y[c] < 1) return JPEGGPU_INVALID_ARGUMENT;
+        sx_max = info->subsampling.x[c] > sx_max ? info->subsampling.x[c] : sx_max;
+        sy_max = info->subsampling.y[c] > sy_max ? info->subsampling.y[c] : sy_max;
+    }
+    for (int c = 0; c < nc; ++c) {
+        if (!src->image[c] || !dst->image[c] || dst->pitch[c] < width || src->pitch[c] < info->sizes_x[c])
+            return JPEGGPU_INVALID_ARGUMENT;
+        const hipError_t err = jg::launch_upsample(
+            src->image[c], src->pitch[c], info->sizes_x[c], info->sizes_y[c],
+            dst->image[c], dst->pitch[c], width, height,
+            info->subsampling.x[c], sx_max, info->subsampling.y[c], sy_max, stream);
+        if (err != hipSuccess) return JPEGGPU_INTERNAL_ERROR;
+    }
+    return JPEGGPU_SUCCESS;
+}
+
+} // extern "C"

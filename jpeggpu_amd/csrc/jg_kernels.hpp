@@ -1,0 +1,60 @@
+// jg_kernels.hpp -- launch interface of the gfx950 kernels (all launches are asynchronous on `stream`).
+#ifndef JG_KERNELS_HPP_
+#define JG_KERNELS_HPP_
+
+#include "jg_defs.h"
+
+#include <hip/hip_runtime_api.h>
+
+namespace jg {
+
+/// Per-subsequence synchronisation state in device memory, structure-of-arrays
+/// (reference `subsequence_info`, src/decode_huffman.cu:71-89, plus the DC sums).
+struct SubseqState {
+    int* p;             // bit position after the last committed symbol, relative to the segment
+    int* n;             // coefficient slots committed
+    int* cz;            // c | z << 8
+    int* dc[kMaxComp];  // sum of committed DC differences per scan component
+};
+
+/// Per-sequence (workgroup) aggregate used to place the write pass without a device-wide scan.
+struct SeqTails {
+    int* n;
+    int* dc[kMaxComp];
+};
+
+bool subseq_bytes_supported(int subseq_bytes);
+
+hipError_t launch_destuff(
+    const uint8_t* d_bytes,
+    uint8_t* d_destuffed,
+    int* d_seg_idx,
+    const DestuffChunk* d_chunks,
+    int num_chunks,
+    int subseq_bytes,
+    hipStream_t stream);
+
+hipError_t launch_huffman(
+    const uint8_t* d_destuffed,
+    const Segment* d_segments,
+    const int* d_seg_idx,
+    const HuffTableDev* d_tables,
+    const ScanParams& sp,
+    SubseqState st,
+    SeqTails tails,
+    int16_t* d_coef, // stream-order coefficients, must be zero-filled
+    hipStream_t stream);
+
+hipError_t launch_idct(
+    const int16_t* d_coef, const uint8_t* d_qtables, const IdctParams& ip, hipStream_t stream);
+
+/// Nearest-neighbour replication of one plane: dst[y][x] = src[y * num_y / den_y][x * num_x / den_x]
+/// (integer part of the reference's host helper util/util.h:62-91).
+hipError_t launch_upsample(
+    const uint8_t* src, int src_pitch, int src_w, int src_h,
+    uint8_t* dst, int dst_pitch, int dst_w, int dst_h,
+    int num_x, int den_x, int num_y, int den_y, hipStream_t stream);
+
+} // namespace jg
+
+#endif // JG_KERNELS_HPP_

@@ -1,0 +1,491 @@
+// jg_reader.cpp -- see jg_reader.hpp. Status codes per defect follow src/reader.cpp of the reference.
+#include "jg_reader.hpp"
+
+#include <algorithm>
+#include <cstring>
+
+namespace jg {
+
+namespace {
+constexpr uint8_t M_SOF0 = 0xC0, M_SOF1 = 0xC1, M_DHT = 0xC4, M_RST0 = 0xD0, M_RST7 = 0xD7,
+                  M_SOI = 0xD8, M_EOI = 0xD9, M_SOS = 0xDA, M_DQT = 0xDB, M_DRI = 0xDD;
+constexpr int kNatural[64] = JG_ORDER_NATURAL;
+
+inline int ceil_div(int a, int b) { return (a + b - 1) / b; }
+} // namespace
+
+void build_huff_table(
+    HuffTableDev& t, const uint8_t (&num_codes)[16], const uint8_t* huffval, int count, bool is_dc)
+{
+    std::memset(&t, 0, sizeof(t));
+    for (int i = 0; i < count && i < 256; ++i) t.huffval[i] = huffval[i];
+    // canonical code assignment, T.81 Annex C; lut entry 0 = "longer than 8 bits or undefined"
+    uint16_t huffcode[256];
+    int idx       = 0;
+    uint32_t code = 0;
+    for (int l = 0; l < 16; ++l) {
+        for (int i = 0; i < num_codes[l] && idx < 256; ++i) {
+            huffcode[idx] = static_cast<uint16_t>(code);
+            if (l < 8) {
+                const int shift   = 7 - l;
+                const uint32_t e  = huff_entry(l + 1, l + 1, t.huffval[idx], is_dc);
+                const uint32_t lo = (code << shift) & 0xFF;
+                for (uint32_t j = 0; j < (1u << shift); ++j) t.lut[(lo + j) & 0xFF] = e;
+            }
+            ++idx;
+            ++code;
+        }
+        code <<= 1;
+    }
+    idx = 0;
+    for (int l = 0; l < 16; ++l) {
+        if (num_codes[l] && idx < 256) {
+            t.valoff[l] = idx - huffcode[idx];
+            idx         = std::min(idx + num_codes[l], 256);
+            t.maxcode[l] = huffcode[idx - 1];
+        } else {
+            t.maxcode[l] = -1;
+            t.valoff[l]  = 0;
+        }
+    }
+}
+
+jpeggpu_status Reader::read_sof(const Logger& log)
+{
+    if (remaining() < 2) return JPEGGPU_INVALID_JPEG;
+    const uint16_t length = u16();
+    if (length < 2) return JPEGGPU_INVALID_JPEG;
+    if (remaining() < static_cast<size_t>(length - 2)) return JPEGGPU_INCOMPLETE_BITSTREAM;
+    if (length < 8) return JPEGGPU_INVALID_JPEG;
+    const uint8_t precision = u8();
+    if (precision != 8) {
+        log.log("\tunsupported sample precision %d, only 8 is supported\n", precision);
+        return JPEGGPU_NOT_SUPPORTED;
+    }
+    const uint16_t lines   = u16();
+    const uint16_t samples = u16();
+    if (lines == 0 || samples == 0) {
+        log.log("\tinvalid size x=%d, y=%d\n", samples, lines);
+        return JPEGGPU_INVALID_JPEG;
+    }
+    s.size_x         = samples;
+    s.size_y         = lines;
+    const uint8_t nc = u8();
+    if (nc == 0) return JPEGGPU_INVALID_JPEG;
+    if (nc > kMaxComp) {
+        log.log("\ttoo many components %d\n", nc);
+        return JPEGGPU_NOT_SUPPORTED;
+    }
+    if (length != 8 + 3 * nc) return JPEGGPU_INVALID_JPEG;
+    s.num_comp = nc;
+    log.log("\tsize_x: %d, size_y: %d, num_components: %d\n", s.size_x, s.size_y, s.num_comp);
+    s.hs_max = s.vs_max = 0;
+    for (int c = 0; c < nc; ++c) {
+        Component& comp  = s.comp[c];
+        comp.id          = u8();
+        const uint8_t sf = u8();
+        const int hs = sf >> 4, vs = sf & 15;
+        if (hs < 1 || hs > 4 || vs < 1 || vs > 4) {
+            log.log("\tinvalid sampling factor (%d, %d)\n", hs, vs);
+            return JPEGGPU_INVALID_JPEG;
+        }
+        // a single-component frame is decoded as 1x1 whatever the header says (reference :147-153)
+        comp.hs         = nc == 1 ? 1 : hs;
+        comp.vs         = nc == 1 ? 1 : vs;
+        const uint8_t q = u8();
+        if (q > 3) {
+            log.log("\tinvalid quantization table index (%d)\n", q);
+            return JPEGGPU_INVALID_JPEG;
+        }
+        comp.qidx = q;
+        for (int d = 0; d < c; ++d) {
+            if (s.comp[d].id == comp.id) return JPEGGPU_INVALID_JPEG;
+        }
+        log.log("\tc_id: %d, ssx: %d, ssy: %d, qi: %d\n", comp.id, comp.hs, comp.vs, comp.qidx);
+        s.hs_max = std::max(s.hs_max, comp.hs);
+        s.vs_max = std::max(s.vs_max, comp.vs);
+    }
+    for (int c = 0; c < nc; ++c) {
+        Component& comp = s.comp[c];
+        comp.size_x     = ceil_div(s.size_x * comp.hs, s.hs_max); // T.81 A.1.1
+        comp.size_y     = ceil_div(s.size_y * comp.vs, s.vs_max);
+    }
+    return JPEGGPU_SUCCESS;
+}
+
+jpeggpu_status Reader::read_dht(const Logger& log)
+{
+    if (remaining() < 2) return JPEGGPU_INVALID_JPEG;
+    const uint16_t length = u16();
+    if (length < 2 || remaining() < static_cast<size_t>(length - 2)) {
+        log.log("\ttoo few bytes in DHT segment\n");
+        return JPEGGPU_INVALID_JPEG;
+    }
+    int rem = length - 2;
+    while (rem > 0) {
+        const uint8_t index = u8();
+        --rem;
+        const int tc = index >> 4, th = index & 15;
+        if (tc != 0 && tc != 1) {
+            log.log("\tinvalid Huffman table class\n");
+            return JPEGGPU_INVALID_JPEG;
+        }
+        if (th > 3) {
+            log.log("\tHuffman table index must be 0, 1, 2, or 3\n");
+            return JPEGGPU_NOT_SUPPORTED;
+        }
+        if (rem < 16) return JPEGGPU_INVALID_JPEG;
+        uint8_t num_codes[16];
+        int count = 0;
+        for (int i = 0; i < 16; ++i) {
+            num_codes[i] = u8();
+            count += num_codes[i];
+        }
+        rem -= 16;
+        if (count > 256 || rem < count) {
+            log.log("\tinvalid value count in DHT segment\n");
+            return JPEGGPU_INVALID_JPEG;
+        }
+        // reject over-subscribed code lengths: the canonical code would not fit its length
+        uint32_t code = 0;
+        for (int l = 0; l < 16; ++l) {
+            code += num_codes[l];
+            if (code > (1u << (l + 1))) return JPEGGPU_INVALID_JPEG;
+            code <<= 1;
+        }
+        log.log("\t%s Huffman table index %d\n", tc == 0 ? "DC" : "AC", th);
+        const int slot = th * 2 + tc;
+        build_huff_table(cur_tables_[slot], num_codes, cur_, count, tc == 0);
+        ht_defined_[slot] = true;
+        cur_ += count;
+        rem -= count;
+    }
+    return JPEGGPU_SUCCESS;
+}
+
+jpeggpu_status Reader::read_dqt(const Logger& log)
+{
+    if (remaining() < 2) return JPEGGPU_INVALID_JPEG;
+    const uint16_t length = u16();
+    if (length < 2 || remaining() < static_cast<size_t>(length - 2)) {
+        log.log("\ttoo few bytes in DQT segment\n");
+        return JPEGGPU_INVALID_JPEG;
+    }
+    int rem = length - 2;
+    while (rem > 0) {
+        const uint8_t info = u8();
+        --rem;
+        const int precision = info >> 4, id = info & 15;
+        if ((precision != 0 && precision != 1) || id > 3) {
+            log.log("\tinvalid precision or id value\n");
+            return JPEGGPU_INVALID_JPEG;
+        }
+        if (precision != 0) {
+            log.log("\t16-bit quantization table is not supported\n");
+            return JPEGGPU_NOT_SUPPORTED;
+        }
+        if (rem < 64) return JPEGGPU_INVALID_JPEG;
+        // A table that a component of an earlier scan dequantises with must not be replaced: all
+        // scans are dequantised together at the end (reference src/reader.cpp:524-541 intends this).
+        bool in_use = false;
+        for (int c = 0; c < s.num_comp; ++c) in_use |= comp_in_scan_[c] && s.comp[c].qidx == id;
+        for (int j = 0; j < 64; ++j) {
+            const uint8_t q = u8();
+            if (!in_use) s.qtable[id][kNatural[j]] = q;
+        }
+        qt_defined_[id] = true;
+        rem -= 64;
+    }
+    return JPEGGPU_SUCCESS;
+}
+
+jpeggpu_status Reader::read_dri(const Logger& log)
+{
+    if (remaining() < 2) return JPEGGPU_INVALID_JPEG;
+    const uint16_t length = u16();
+    if (length != 4 || remaining() < 2) return JPEGGPU_INVALID_JPEG;
+    const uint16_t rsti = u16();
+    if (s.num_scans > 0 && s.restart_interval != rsti) {
+        log.log("\tredefined restart interval\n");
+        return JPEGGPU_NOT_SUPPORTED;
+    }
+    s.restart_interval = rsti;
+    log.log("\trestart_interval: %d\n", s.restart_interval);
+    return JPEGGPU_SUCCESS;
+}
+
+jpeggpu_status Reader::skip_segment(const Logger& log)
+{
+    if (remaining() < 2) return JPEGGPU_INVALID_JPEG;
+    const uint16_t length = u16();
+    if (length < 2) return JPEGGPU_INVALID_JPEG;
+    if (remaining() < static_cast<size_t>(length - 2)) return JPEGGPU_INCOMPLETE_BITSTREAM;
+    log.log("\twarning: skipping this segment\n");
+    cur_ += length - 2;
+    return JPEGGPU_SUCCESS;
+}
+
+jpeggpu_status Reader::read_sos(const Logger& log)
+{
+    if (!found_sof_) return JPEGGPU_INVALID_JPEG;
+    if (remaining() < 3) {
+        log.log("\ttoo few bytes in SOS segment\n");
+        return JPEGGPU_INVALID_JPEG;
+    }
+    const uint16_t length = u16();
+    if (length < 3) return JPEGGPU_INVALID_JPEG;
+    const uint8_t ns = u8();
+    if (ns < 1 || ns > 4) {
+        log.log("\tinvalid number of components in scan %d\n", ns);
+        return JPEGGPU_INVALID_JPEG;
+    }
+    if (s.num_scans >= kMaxScans) return JPEGGPU_INVALID_JPEG;
+    if (length != 6 + 2 * ns) return JPEGGPU_INVALID_JPEG;
+    if (remaining() < static_cast<size_t>(2 * ns + 3)) return JPEGGPU_INCOMPLETE_BITSTREAM;
+
+    Scan& scan            = s.scans[s.num_scans];
+    scan                  = Scan{};
+    scan.num_comp         = ns;
+    const bool interleave = ns > 1;
+    scan.du_per_mcu       = 0;
+    for (int a = 0; a < ns; ++a) {
+        ScanComponent& sc = scan.comp[a];
+        const uint8_t sel = u8();
+        const uint8_t tab = u8();
+        const int id_dc = tab >> 4, id_ac = tab & 15;
+        log.log("\tc_id: %d, dc: %d, ac: %d\n", sel, id_dc, id_ac);
+        int ci = -1;
+        for (int i = 0; i < s.num_comp; ++i) {
+            if (s.comp[i].id == sel) {
+                ci = i;
+                break;
+            }
+        }
+        if (ci < 0) {
+            log.log("\tinvalid component selector\n");
+            return JPEGGPU_INVALID_JPEG;
+        }
+        // T.81 A.2: scan components follow frame order; a component is coded in exactly one scan
+        if (a > 0 && ci <= scan.comp[a - 1].comp_idx) return JPEGGPU_INVALID_JPEG;
+        if (comp_in_scan_[ci]) return JPEGGPU_INVALID_JPEG;
+        if (id_dc > 3 || id_ac > 3) return JPEGGPU_INVALID_JPEG;
+        if (!ht_defined_[id_dc * 2] || !ht_defined_[id_ac * 2 + 1]) return JPEGGPU_INVALID_JPEG;
+        const Component& comp = s.comp[ci];
+        if (!qt_defined_[comp.qidx]) {
+            log.log("\tquantization table at index %d not defined\n", comp.qidx);
+            return JPEGGPU_INVALID_JPEG;
+        }
+        sc.comp_idx = ci;
+        sc.dc_id    = id_dc;
+        sc.ac_id    = id_ac;
+        sc.h        = interleave ? comp.hs : 1;
+        sc.v        = interleave ? comp.vs : 1;
+        sc.data_x   = ceil_div(comp.size_x, 8 * sc.h) * 8 * sc.h; // T.81 A.2.4
+        sc.data_y   = ceil_div(comp.size_y, 8 * sc.v) * 8 * sc.v;
+        const int mx = sc.data_x / (8 * sc.h), my = sc.data_y / (8 * sc.v);
+        if (a > 0 && (mx != scan.mcus_x || my != scan.mcus_y)) {
+            // sampling factors that do not divide the maximum can disagree on the MCU count
+            log.log("\tcomponents disagree on the number of MCUs\n");
+            return JPEGGPU_NOT_SUPPORTED;
+        }
+        scan.mcus_x = mx;
+        scan.mcus_y = my;
+        scan.du_per_mcu += sc.h * sc.v;
+    }
+    if (scan.du_per_mcu > kMaxDuPerMcu) {
+        log.log("\ttoo many data units in mcu\n");
+        return JPEGGPU_INVALID_JPEG;
+    }
+    for (int a = 0; a < ns; ++a) comp_in_scan_[scan.comp[a].comp_idx] = true;
+    u8(); // spectral selection start (0 for baseline)
+    u8(); // spectral selection end (63)
+    u8(); // successive approximation (0)
+
+    std::memcpy(scan.tables, cur_tables_, sizeof(cur_tables_)); // tables in force for this scan
+    const int total_mcus  = scan.mcus_x * scan.mcus_y;
+    scan.mcus_per_segment = s.restart_interval ? s.restart_interval : total_mcus;
+    scan.num_du           = total_mcus * scan.du_per_mcu;
+    scan.begin            = static_cast<size_t>(cur_ - base_);
+    if (s.num_scans == 0) s.xfer_begin = (scan.begin - 1) & ~static_cast<size_t>(15);
+    ++s.num_scans;
+    return walk_scan(scan, log);
+}
+
+/// Walk the entropy-coded bytes of one scan (reference src/reader.cpp:447-489): find restart
+/// markers and the terminating marker, count destuffed bytes per segment, and emit the destuff
+/// work list with precomputed destination offsets.
+jpeggpu_status Reader::walk_scan(Scan& scan, const Logger& log)
+{
+    const size_t xb = s.xfer_begin;
+    const auto boff = [&](const uint8_t* p) { return static_cast<size_t>(p - base_) - xb; };
+
+    const uint8_t* seg_begin = cur_;
+    size_t chunk_begin       = boff(cur_);
+    size_t next_win          = (chunk_begin / kDestuffWin + 1) * kDestuffWin;
+    uint32_t ff_in_chunk     = 0;
+    size_t seg_first_chunk   = scan.chunks.size();
+    int seg_dst_base         = 0; // in bytes of the destuffed buffer
+    size_t chunk_dst         = 0;
+    const uint8_t* pos       = cur_;
+    (void)seg_begin;
+
+    const auto emit = [&](size_t b, size_t e) {
+        DestuffChunk c;
+        c.win_off = static_cast<uint32_t>(b / kDestuffWin * kDestuffWin);
+        c.begin   = static_cast<uint32_t>(b);
+        c.end     = static_cast<uint32_t>(e);
+        c.dst_off = static_cast<uint32_t>(chunk_dst);
+        c.pad_end = 0;
+        c.seg     = static_cast<int32_t>(scan.segments.size());
+        c.first   = scan.chunks.size() == seg_first_chunk ? 1u : 0u;
+        c.reserved = 0;
+        scan.chunks.push_back(c);
+        chunk_dst += (e - b) - ff_in_chunk;
+        ff_in_chunk = 0;
+    };
+
+    while (true) {
+        const uint8_t* q =
+            static_cast<const uint8_t*>(std::memchr(pos, 0xFF, static_cast<size_t>(end_ - pos)));
+        if (q == nullptr || q + 1 >= end_) return JPEGGPU_INVALID_JPEG; // no end-of-image marker
+        const size_t qo = boff(q);
+        while (next_win <= qo) {
+            emit(chunk_begin, next_win);
+            chunk_begin = next_win;
+            next_win += kDestuffWin;
+        }
+        uint8_t m = q[1];
+        if (m == 0) { // stuffed byte: FF 00 stands for a data byte FF
+            ++ff_in_chunk;
+            pos = q + 2;
+            continue;
+        }
+        const uint8_t* mk = q; // skip fill bytes (any number of FF before the marker code)
+        while (m == 0xFF) {
+            ++mk;
+            if (mk + 1 >= end_) return JPEGGPU_INVALID_JPEG;
+            m = mk[1];
+        }
+        if (m == 0) return JPEGGPU_INVALID_JPEG; // FF FF 00 is not a legal sequence
+        // the segment's data ends at q
+        if (qo > chunk_begin || scan.chunks.size() == seg_first_chunk) emit(chunk_begin, qo);
+        const size_t seg_bytes = chunk_dst - static_cast<size_t>(seg_dst_base);
+        if (seg_bytes > (1u << 27)) return JPEGGPU_NOT_SUPPORTED; // bit positions are 32-bit
+        Segment seg;
+        seg.subseq_offset = scan.num_subseq;
+        seg.subseq_count  = static_cast<int>((seg_bytes + subseq_bytes_ - 1) / subseq_bytes_);
+        scan.num_subseq += seg.subseq_count;
+        const size_t padded_end = static_cast<size_t>(scan.num_subseq) * subseq_bytes_;
+        scan.chunks.back().pad_end = static_cast<uint32_t>(padded_end);
+        scan.segments.push_back(seg);
+        if (padded_end > (1u << 31)) return JPEGGPU_NOT_SUPPORTED;
+
+        const bool is_rst = M_RST0 <= m && m <= M_RST7;
+        if (!is_rst) {
+            cur_     = mk; // the marker loop continues at the FF of the terminating marker
+            scan.end = static_cast<size_t>(mk - base_);
+            break;
+        }
+        pos = mk + 2;
+        if (pos >= end_) return JPEGGPU_INVALID_JPEG;
+        // next segment
+        seg_dst_base    = static_cast<int>(padded_end);
+        chunk_dst       = padded_end;
+        chunk_begin     = boff(pos);
+        next_win        = (chunk_begin / kDestuffWin + 1) * kDestuffWin;
+        ff_in_chunk     = 0;
+        seg_first_chunk = scan.chunks.size();
+    }
+
+    const int total_mcus = scan.mcus_x * scan.mcus_y;
+    const int expect     = ceil_div(total_mcus, scan.mcus_per_segment);
+    if (static_cast<int>(scan.segments.size()) != expect) {
+        log.log(
+            "\tscan has %d restart segments, geometry requires %d\n",
+            static_cast<int>(scan.segments.size()),
+            expect);
+        return JPEGGPU_INVALID_JPEG;
+    }
+    s.xfer_end = scan.end;
+    return JPEGGPU_SUCCESS;
+}
+
+jpeggpu_status Reader::parse(const uint8_t* data, size_t size, int subseq_bytes, const Logger& log)
+{
+    s             = Stream{};
+    std::memset(s.qtable, 0, sizeof(s.qtable));
+    base_         = data;
+    cur_          = data;
+    end_          = data + size;
+    subseq_bytes_ = subseq_bytes;
+    found_sof_    = false;
+    std::memset(qt_defined_, 0, sizeof(qt_defined_));
+    std::memset(ht_defined_, 0, sizeof(ht_defined_));
+    std::memset(cur_tables_, 0, sizeof(cur_tables_));
+    std::memset(comp_in_scan_, 0, sizeof(comp_in_scan_));
+    if (size >= (1ull << 31)) return JPEGGPU_NOT_SUPPORTED;
+
+    const auto read_marker = [&](uint8_t& marker) -> jpeggpu_status {
+        if (remaining() < 2) {
+            log.log("\ttoo few bytes for marker\n");
+            return JPEGGPU_INVALID_JPEG;
+        }
+        const uint8_t ff = u8();
+        if (ff != 0xFF) {
+            log.log("\tinvalid marker byte 0x%02x\n", ff);
+            return JPEGGPU_INVALID_JPEG;
+        }
+        marker = u8();
+        while (marker == 0xFF) { // fill bytes
+            if (remaining() < 1) return JPEGGPU_INVALID_JPEG;
+            marker = u8();
+        }
+        return JPEGGPU_SUCCESS;
+    };
+
+    uint8_t marker = 0;
+    jpeggpu_status st;
+    if ((st = read_marker(marker)) != JPEGGPU_SUCCESS) return st;
+    if (marker != M_SOI) return JPEGGPU_INVALID_JPEG;
+    do {
+        if ((st = read_marker(marker)) != JPEGGPU_SUCCESS) return st;
+        log.log("marker 0x%02x\n", marker);
+        st = JPEGGPU_SUCCESS;
+        if (marker == M_SOF0 || marker == M_SOF1) {
+            if (found_sof_) return JPEGGPU_INVALID_JPEG;
+            found_sof_ = true;
+            st         = read_sof(log);
+        } else if (
+            (marker >= 0xC2 && marker <= 0xCF && marker != M_DHT && marker != 0xC8 &&
+             marker != 0xCC)) {
+            log.log("\tunsupported JPEG type: SOF%d\n", marker - 0xC0);
+            return JPEGGPU_NOT_SUPPORTED;
+        } else if (marker == M_DHT) {
+            st = read_dht(log);
+        } else if (marker == M_SOS) {
+            st = read_sos(log);
+        } else if (marker == M_DQT) {
+            st = read_dqt(log);
+        } else if (marker == M_DRI) {
+            st = read_dri(log);
+        } else if (marker == M_EOI) {
+            break;
+        } else if (marker == M_SOI || (marker >= M_RST0 && marker <= M_RST7) || marker == 0x01) {
+            return JPEGGPU_INVALID_JPEG; // stand-alone markers have no place here
+        } else {
+            st = skip_segment(log);
+        }
+        if (st != JPEGGPU_SUCCESS) return st;
+    } while (true);
+
+    if (!found_sof_ || s.num_scans == 0) return JPEGGPU_INVALID_JPEG;
+    for (int c = 0; c < s.num_comp; ++c) {
+        if (!comp_in_scan_[c]) {
+            log.log("\tcomponent with index %d not defined in scan\n", c);
+            return JPEGGPU_INVALID_JPEG;
+        }
+    }
+    return JPEGGPU_SUCCESS;
+}
+
+} // namespace jg

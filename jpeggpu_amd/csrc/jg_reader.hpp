@@ -1,0 +1,119 @@
+// jg_reader.hpp -- host-side marker/segment parser (C++, runs on the calling thread, no GPU work).
+//
+// Behavioural counterpart of the reference's reader (src/reader.hpp:38-196, src/reader.cpp:81-729):
+// SOI / SOF0 / SOF1 / DHT / DQT / DRI / SOS / EOI, the same status codes for the same defects, the
+// same geometry rules (plane size ceil(size*ss/ss_max), MCU-rounded data size, single-component
+// frames forced to 1x1 sampling). Differences, each deliberate:
+//   B-1 Huffman tables persist across scans as T.81 requires (the reference loses them);
+//   B-2 a non-interleaved scan has one data unit per MCU and ceil(size/8) blocks per row;
+//   B-6 length fields and table ids are range-checked;
+//   fill bytes (FF FF .. before a marker) are skipped; a scan whose restart-marker count does not
+//   match the frame geometry is rejected (the kernels index output by segment number);
+//   the walk over the entropy-coded bytes also emits the destuff work list (see jg_defs.h).
+#ifndef JG_READER_HPP_
+#define JG_READER_HPP_
+
+#include "jg_defs.h"
+
+#include <jpeggpu/jpeggpu.h>
+
+#include <cstdarg>
+#include <cstdio>
+#include <vector>
+
+namespace jg {
+
+struct Logger {
+    bool enabled = false;
+    void log(const char* fmt, ...) const __attribute__((format(printf, 2, 3)))
+    {
+        if (!enabled) return;
+        va_list ap;
+        va_start(ap, fmt);
+        vprintf(fmt, ap);
+        va_end(ap);
+    }
+};
+
+struct Component {
+    uint8_t id;
+    uint8_t qidx;
+    int hs, vs;         // sampling factors (1x1 forced for single-component frames)
+    int size_x, size_y; // plane size
+};
+
+struct ScanComponent {
+    int comp_idx;
+    int dc_id, ac_id;     // Huffman table ids 0..3
+    int h, v;             // data units per MCU in this scan (1,1 when not interleaved)
+    int data_x, data_y;   // plane size rounded up to this scan's MCU
+};
+
+struct Scan {
+    int num_comp = 0;
+    ScanComponent comp[kMaxComp];
+    size_t begin = 0; // file offset of first entropy-coded byte
+    size_t end   = 0; // file offset of the marker that terminates the scan
+    int du_per_mcu = 0;
+    int mcus_x = 0, mcus_y = 0;
+    int mcus_per_segment = 0;
+    int num_subseq = 0;
+    int num_du = 0;
+    HuffTableDev tables[kHuffSlots]; // snapshot of the tables in force at SOS
+    std::vector<Segment> segments;
+    std::vector<DestuffChunk> chunks;
+};
+
+struct Stream {
+    int size_x = 0, size_y = 0;
+    int hs_max = 0, vs_max = 0;
+    int num_comp = 0;
+    Component comp[kMaxComp];
+    int restart_interval = 0;
+    int num_scans = 0;
+    Scan scans[kMaxScans];
+    uint8_t qtable[4][64]; // natural order, 8-bit (reference src/defs.hpp:87-89)
+    // Transferred byte range of the file: [xfer_begin, xfer_end). Buffer offset = file offset - xfer_begin.
+    size_t xfer_begin = 0;
+    size_t xfer_end   = 0;
+};
+
+struct Reader {
+    jpeggpu_status parse(const uint8_t* data, size_t size, int subseq_bytes, const Logger& log);
+
+    Stream s;
+
+  private:
+    const uint8_t* base_ = nullptr;
+    const uint8_t* cur_  = nullptr;
+    const uint8_t* end_  = nullptr;
+    int subseq_bytes_    = 128;
+    bool found_sof_      = false;
+    bool qt_defined_[4]{};
+    bool ht_defined_[kHuffSlots]{};
+    HuffTableDev cur_tables_[kHuffSlots];
+    bool comp_in_scan_[kMaxComp]{};
+
+    size_t remaining() const { return static_cast<size_t>(end_ - cur_); }
+    uint8_t u8() { return *cur_++; }
+    uint16_t u16()
+    {
+        const uint16_t hi = u8();
+        return static_cast<uint16_t>(hi << 8 | u8());
+    }
+    jpeggpu_status read_sof(const Logger& log);
+    jpeggpu_status read_dht(const Logger& log);
+    jpeggpu_status read_dqt(const Logger& log);
+    jpeggpu_status read_dri(const Logger& log);
+    jpeggpu_status read_sos(const Logger& log);
+    jpeggpu_status walk_scan(Scan& scan, const Logger& log);
+    jpeggpu_status skip_segment(const Logger& log);
+};
+
+/// Build the device form of one Huffman table from a DHT payload
+/// (reference compute_huffman_table, src/reader.cpp:186-224).
+void build_huff_table(HuffTableDev& t, const uint8_t (&num_codes)[16], const uint8_t* huffval, int count, bool is_dc);
+
+} // namespace jg
+
+#endif // JG_READER_HPP_

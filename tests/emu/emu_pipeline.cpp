@@ -1,0 +1,321 @@
+// emu_pipeline.cpp -- host emulation of the device pipeline's LOGIC, for CPU-only tests.
+//
+// Compiles the product's own parser (jg_reader.cpp) and per-lane symbol loop (jg_huff_core.h) with
+// g++ and replays, lane by lane, what the gfx950 kernels of jg_kernels.hip do: destuff by work
+// list, speculative decode, lock-step intra-sequence flows, inter-sequence flows, sequence tails,
+// write pass with look-back. It has no LDS, no waves and no barriers -- each "iteration" loops over
+// the lanes in order, reading the previous iteration's table -- so it checks the algorithm and the
+// host-built tables, not the kernels' memory layout. The GPU tests check the kernels themselves.
+#include "jg_huff_core.h"
+#include "jg_reader.hpp"
+
+#include <cstring>
+#include <vector>
+
+using namespace jg;
+
+namespace {
+
+struct HostFetch {
+    const uint8_t* seg; // first byte of the segment in the destuffed buffer
+    int seg_words;
+    uint32_t operator()(int w) const
+    {
+        if (w >= seg_words) return 0;
+        const uint8_t* p = seg + static_cast<size_t>(w) * 4;
+        return static_cast<uint32_t>(p[0]) << 24 | p[1] << 16 | p[2] << 8 | p[3];
+    }
+};
+
+struct HostSink {
+    static constexpr bool kWrite = true;
+    int16_t* out;
+    int pos, quota;
+    int pred[kMaxComp];
+    bool full() const { return pos >= quota; }
+    void store(int v)
+    {
+        static const uint8_t nat[64] = JG_ORDER_NATURAL;
+        if (pos < quota) out[(pos & ~63) + nat[pos & 63]] = static_cast<int16_t>(v);
+    }
+    void dc(int comp, int diff)
+    {
+        pred[comp] += diff;
+        store(pred[comp]);
+        ++pos;
+    }
+    void ac(int run, int v)
+    {
+        pos += run;
+        store(v);
+        ++pos;
+    }
+    void advance(int k) { pos += k; }
+};
+
+struct St {
+    int p, n, cz, dc[kMaxComp];
+};
+
+void emu_destuff(const uint8_t* bytes, const Scan& sc, int subseq_bytes, std::vector<uint8_t>& dst, std::vector<int>& seg_idx)
+{
+    dst.assign(static_cast<size_t>(sc.num_subseq) * subseq_bytes + 256, 0xAA); // poison: padding must be written
+    seg_idx.assign(sc.num_subseq, -1);
+    for (const DestuffChunk& ck : sc.chunks) {
+        uint32_t o = ck.dst_off;
+        for (uint32_t pos = ck.begin; pos < ck.end; ++pos) {
+            uint32_t p = pos > 0 ? bytes[pos - 1] : 0;
+            if (ck.first && pos == ck.begin) p = 0;
+            const uint32_t b = bytes[pos];
+            if (p == 0xFF && b == 0) dst[o++] = 0xFF;
+            else if (p != 0xFF && b != 0xFF) dst[o++] = static_cast<uint8_t>(b);
+        }
+        const uint32_t total = o - ck.dst_off;
+        for (uint32_t z = o; ck.pad_end && z < ck.pad_end; ++z) dst[z] = 0;
+        if (total) {
+            for (uint32_t s = (ck.dst_off + subseq_bytes - 1) / subseq_bytes; s * subseq_bytes < ck.dst_off + total; ++s)
+                seg_idx[s] = ck.seg;
+        }
+    }
+}
+
+} // namespace
+
+extern "C" {
+
+/// Returns a jpeggpu_status. Outputs are for scan `scan_idx`; pointers may be null.
+int emu_decode_scan(
+    const uint8_t* data,
+    size_t size,
+    int subseq_bytes,
+    int scan_idx,
+    int* out_num_subseq,
+    int* out_num_du,
+    uint8_t* destuffed, // [num_subseq * subseq_bytes]
+    int* seg_index,     // [num_subseq]
+    int* st_p,
+    int* st_n,
+    int* st_cz,
+    int* st_dc, // [4][num_subseq]
+    int16_t* coef,
+    int* out_max_flow_iters)
+{
+    Reader rd;
+    Logger log;
+    const jpeggpu_status stat = rd.parse(data, size, subseq_bytes, log);
+    if (stat != JPEGGPU_SUCCESS) return stat;
+    const Stream& s = rd.s;
+    if (scan_idx < 0 || scan_idx >= s.num_scans) return JPEGGPU_INVALID_ARGUMENT;
+    const Scan& sc = s.scans[scan_idx];
+    if (out_num_subseq) *out_num_subseq = sc.num_subseq;
+    if (out_num_du) *out_num_du = sc.num_du;
+    if (!coef) return JPEGGPU_SUCCESS;
+
+    // the transferred byte buffer, as the device sees it
+    std::vector<uint8_t> bytes(s.xfer_end - s.xfer_begin + 2 * kDestuffWin, 0);
+    std::memcpy(bytes.data(), data + s.xfer_begin, s.xfer_end - s.xfer_begin);
+
+    std::vector<uint8_t> dst;
+    std::vector<int> segi;
+    emu_destuff(bytes.data(), sc, subseq_bytes, dst, segi);
+
+    ScanParams sp{};
+    sp.num_subseq       = sc.num_subseq;
+    sp.num_segments     = static_cast<int>(sc.segments.size());
+    sp.du_per_mcu       = sc.du_per_mcu;
+    sp.num_comp         = sc.num_comp;
+    sp.mcus_per_segment = sc.mcus_per_segment;
+    sp.total_mcus       = sc.mcus_x * sc.mcus_y;
+    sp.subseq_words     = subseq_bytes / 4;
+    int du              = 0;
+    for (int a = 0; a < sc.num_comp; ++a) {
+        sp.dc_slot |= static_cast<uint32_t>(sc.comp[a].dc_id * 2) << (4 * a);
+        sp.ac_slot |= static_cast<uint32_t>(sc.comp[a].ac_id * 2 + 1) << (4 * a);
+        for (int k = 0; k < sc.comp[a].h * sc.comp[a].v; ++k) sp.du_comp |= static_cast<uint32_t>(a) << (2 * du++);
+    }
+
+    const int S    = sc.num_subseq;
+    const int T    = kSeqSubseq;
+    const int bits = subseq_bytes * 8;
+    const int W    = subseq_bytes / 4;
+    std::vector<St> st(S);
+    NoSink nosink;
+    int max_iters = 0;
+
+    struct Lane {
+        LaneState s;
+        BitWindow<HostFetch> bw;
+        HostFetch f;
+        int end_bit, lim;
+        bool flowing;
+    };
+
+    // ---- intra-sequence (huff_sync_intra) ----
+    const int num_seq = (S + T - 1) / T;
+    for (int b = 0; b < num_seq; ++b) {
+        const int first = b * T, nsub = std::min(T, S - first);
+        std::vector<Lane> ln(nsub);
+        for (int t = 0; t < nsub; ++t) {
+            const int sub      = first + t;
+            const Segment seg  = sc.segments[segi[sub]];
+            const int rel      = sub - seg.subseq_offset;
+            Lane& L            = ln[t];
+            L.f                = HostFetch{dst.data() + static_cast<size_t>(seg.subseq_offset) * subseq_bytes, seg.subseq_count * W};
+            L.lim              = std::min(nsub, seg.subseq_offset + seg.subseq_count - first);
+            L.s                = LaneState{};
+            L.s.p              = rel * bits;
+            L.end_bit          = (rel + 1) * bits;
+            L.bw.seek(L.s.p, L.f);
+            decode_subsequence(L.s, L.bw, L.f, L.end_bit, sc.tables, sp, nosink);
+            St& o = st[sub];
+            o.p = L.s.p; o.n = L.s.n; o.cz = L.s.c | (L.s.z << 8);
+            for (int k = 0; k < kMaxComp; ++k) o.dc[k] = L.s.dc[k];
+            L.flowing = true;
+        }
+        for (int iter = 0; iter < T; ++iter) {
+            bool any = false;
+            for (int t = 0; t < nsub; ++t) { // entry j of iteration `iter` is touched by lane t only
+                Lane& L     = ln[t];
+                const int j = t + 1 + iter;
+                if (L.flowing && j < L.lim) {
+                    L.s.n = 0;
+                    for (int k = 0; k < kMaxComp; ++k) L.s.dc[k] = 0;
+                    L.end_bit += bits;
+                    decode_subsequence(L.s, L.bw, L.f, L.end_bit, sc.tables, sp, nosink);
+                    St& o        = st[first + j];
+                    const int cz = L.s.c | (L.s.z << 8);
+                    if (L.s.p == o.p && cz == o.cz) L.flowing = false;
+                    o.p = L.s.p; o.n = L.s.n; o.cz = cz;
+                    for (int k = 0; k < kMaxComp; ++k) o.dc[k] = L.s.dc[k];
+                } else {
+                    L.flowing = false;
+                }
+                any |= L.flowing && j + 1 < L.lim;
+            }
+            if (iter + 1 > max_iters) max_iters = iter + 1;
+            if (!any) break;
+        }
+    }
+
+    // ---- inter-sequence (huff_sync_inter), groups of 1024 boundaries in stream order ----
+    for (int base = 1; base < num_seq; base += 1024) {
+        const int nb = std::min(1024, num_seq - base);
+        std::vector<Lane> ln(nb);
+        std::vector<int> jj(nb);
+        for (int t = 0; t < nb; ++t) {
+            const int from    = (base + t) * T - 1;
+            const Segment seg = sc.segments[segi[from]];
+            Lane& L           = ln[t];
+            L.lim             = seg.subseq_offset + seg.subseq_count;
+            jj[t]             = from + 1;
+            L.flowing         = jj[t] < L.lim;
+            if (L.flowing) {
+                L.f       = HostFetch{dst.data() + static_cast<size_t>(seg.subseq_offset) * subseq_bytes, seg.subseq_count * W};
+                L.s       = LaneState{};
+                L.s.p     = st[from].p;
+                L.s.c     = st[from].cz & 0xFF;
+                L.s.z     = st[from].cz >> 8;
+                L.end_bit = (from - seg.subseq_offset + 1) * bits;
+                L.bw.seek(L.s.p, L.f);
+            }
+        }
+        while (true) {
+            bool any = false;
+            for (int t = 0; t < nb; ++t) {
+                Lane& L = ln[t];
+                int& j  = jj[t];
+                if (L.flowing && j < L.lim) {
+                    L.s.n = 0;
+                    for (int k = 0; k < kMaxComp; ++k) L.s.dc[k] = 0;
+                    L.end_bit += bits;
+                    decode_subsequence(L.s, L.bw, L.f, L.end_bit, sc.tables, sp, nosink);
+                    St& o        = st[j];
+                    const int cz = L.s.c | (L.s.z << 8);
+                    if (L.s.p == o.p && cz == o.cz) L.flowing = false;
+                    o.p = L.s.p; o.n = L.s.n; o.cz = cz;
+                    for (int k = 0; k < kMaxComp; ++k) o.dc[k] = L.s.dc[k];
+                    ++j;
+                } else {
+                    L.flowing = false;
+                }
+                any |= L.flowing && j < L.lim;
+            }
+            if (!any) break;
+        }
+    }
+
+    // ---- sequence tails (huff_seq_tails) ----
+    std::vector<St> tails(num_seq);
+    for (int b = 0; b < num_seq; ++b) {
+        const int first = b * T, nsub = std::min(T, S - first);
+        const int open_from = sc.segments[segi[first + nsub - 1]].subseq_offset;
+        St acc{};
+        for (int t = 0; t < nsub; ++t) {
+            if (first + t >= open_from) {
+                acc.n += st[first + t].n;
+                for (int k = 0; k < kMaxComp; ++k) acc.dc[k] += st[first + t].dc[k];
+            }
+        }
+        tails[b] = acc;
+    }
+
+    // ---- write pass (huff_write) ----
+    std::memset(coef, 0, static_cast<size_t>(sc.num_du) * 128);
+    for (int b = 0; b < num_seq; ++b) {
+        const int first = b * T, nsub = std::min(T, S - first);
+        const Segment seg0 = sc.segments[segi[first]];
+        St carry{};
+        if (seg0.subseq_offset < first) {
+            for (int a = seg0.subseq_offset / T; a < b; ++a) {
+                carry.n += tails[a].n;
+                for (int k = 0; k < kMaxComp; ++k) carry.dc[k] += tails[a].dc[k];
+            }
+        }
+        std::vector<St> ex(nsub + 1);
+        St run{};
+        for (int t = 0; t < nsub; ++t) {
+            ex[t] = run;
+            run.n += st[first + t].n;
+            for (int k = 0; k < kMaxComp; ++k) run.dc[k] += st[first + t].dc[k];
+        }
+        for (int t = 0; t < nsub; ++t) {
+            const int sub      = first + t;
+            const int seg_i    = segi[sub];
+            const Segment seg  = sc.segments[seg_i];
+            const int rel      = sub - seg.subseq_offset;
+            const bool carried = seg.subseq_offset < first;
+            const int ts       = carried ? 0 : seg.subseq_offset - first;
+            HostSink sink;
+            sink.out = coef;
+            const int nprefix = ex[t].n - ex[ts].n + (carried ? carry.n : 0);
+            for (int k = 0; k < kMaxComp; ++k) sink.pred[k] = ex[t].dc[k] - ex[ts].dc[k] + (carried ? carry.dc[k] : 0);
+            const int du_words = sp.du_per_mcu * 64;
+            const int m0 = seg_i * sp.mcus_per_segment, m1 = std::min(m0 + sp.mcus_per_segment, sp.total_mcus);
+            sink.pos   = m0 * du_words + nprefix;
+            sink.quota = m1 * du_words;
+            LaneState ls{};
+            if (rel > 0) {
+                ls.p = st[sub - 1].p;
+                ls.c = st[sub - 1].cz & 0xFF;
+                ls.z = st[sub - 1].cz >> 8;
+            }
+            HostFetch f{dst.data() + static_cast<size_t>(seg.subseq_offset) * subseq_bytes, seg.subseq_count * W};
+            BitWindow<HostFetch> bw;
+            bw.seek(ls.p, f);
+            decode_subsequence(ls, bw, f, (rel + 1) * bits, sc.tables, sp, sink);
+        }
+    }
+
+    if (destuffed) std::memcpy(destuffed, dst.data(), static_cast<size_t>(S) * subseq_bytes);
+    if (seg_index) std::memcpy(seg_index, segi.data(), sizeof(int) * S);
+    for (int i = 0; i < S; ++i) {
+        if (st_p) st_p[i] = st[i].p;
+        if (st_n) st_n[i] = st[i].n;
+        if (st_cz) st_cz[i] = st[i].cz;
+        if (st_dc)
+            for (int k = 0; k < kMaxComp; ++k) st_dc[static_cast<size_t>(k) * S + i] = st[i].dc[k];
+    }
+    if (out_max_flow_iters) *out_max_flow_iters = max_iters;
+    return JPEGGPU_SUCCESS;
+}
+}
