@@ -6,6 +6,9 @@
  *                                      (src/decoder_defs.hpp:28-34 `chunk_size`)
  *   jpeggpu_ext_get_layout             where the intermediate buffers of the last parsed image sit
  *                                      inside d_tmp, for stage-level parity tests and profiling
+ *   jpeggpu_ext_set_profiling /        per-stage device time of a decode from HIP events recorded on the
+ *   jpeggpu_ext_get_stage_ms           caller's stream (the reference has wall-clock timing only,
+ *                                      benchmark/benchmark_jpeggpu.hpp:96-102)
  *   jpeggpu_ext_upsample_planes        nearest-neighbour chroma replication on the device, the integer
  *                                      part of the reference's host helper util/util.h:62-91
  */
@@ -54,6 +57,22 @@ struct jpeggpu_ext_layout {
 };
 
 enum jpeggpu_status jpeggpu_ext_get_layout(jpeggpu_decoder_t decoder, struct jpeggpu_ext_layout* layout);
+
+/* Stage timing: when enabled, jpeggpu_decoder_decode records HIP events on the caller's stream
+ * between its launches; after the stream has been synchronised jpeggpu_ext_get_stage_ms returns the
+ * milliseconds of the LAST decode per stage (summed over scans). */
+enum jpeggpu_ext_stage {
+    JPEGGPU_EXT_STAGE_MEMSET     = 0, /* zero-fill of the coefficient buffer */
+    JPEGGPU_EXT_STAGE_DESTUFF    = 1,
+    JPEGGPU_EXT_STAGE_SYNC_INTRA = 2,
+    JPEGGPU_EXT_STAGE_SYNC_INTER = 3,
+    JPEGGPU_EXT_STAGE_TAILS      = 4,
+    JPEGGPU_EXT_STAGE_WRITE      = 5,
+    JPEGGPU_EXT_STAGE_IDCT       = 6,
+    JPEGGPU_EXT_NUM_STAGES       = 7
+};
+enum jpeggpu_status jpeggpu_ext_set_profiling(jpeggpu_decoder_t decoder, int enable);
+enum jpeggpu_status jpeggpu_ext_get_stage_ms(jpeggpu_decoder_t decoder, float* ms /* [JPEGGPU_EXT_NUM_STAGES] */);
 
 /* Replicate every plane of `src` (as produced by jpeggpu_decoder_decode for `info`) to the full
  * image resolution: dst[c][y][x] = src[c][y * sy_c / sy_max][x * sx_c / sx_max]. */

@@ -1,0 +1,214 @@
+"""ctypes mirror of include/jpeggpu/jpeggpu.h (+ jpeggpu_ext.h).
+
+Call order is the reference's (example/example_tool.c:101-128):
+    startup -> parse_header -> get_buffer_size -> transfer(d_tmp) -> decode(d_tmp) -> cleanup.
+Device memory and streams are the caller's: pass raw device pointers (e.g. torch tensors'
+data_ptr()) and a hipStream_t handle (torch.cuda.Stream.cuda_stream). There is no CPU fallback: if
+the HIP library is missing, importing the binding fails.
+"""
+import ctypes as C
+import enum
+import os
+
+from . import build as _build
+
+MAX_COMP = 4
+STAGES = ("memset", "destuff", "sync_intra", "sync_inter", "tails", "write", "idct")
+
+
+class Status(enum.IntEnum):
+    SUCCESS = 0
+    INVALID_ARGUMENT = 1
+    INVALID_JPEG = 2
+    INTERNAL_ERROR = 3
+    NOT_SUPPORTED = 4
+    OUT_OF_HOST_MEMORY = 5
+    INCOMPLETE_BITSTREAM = 6
+
+
+class Subsampling(C.Structure):
+    _fields_ = [("x", C.c_int * MAX_COMP), ("y", C.c_int * MAX_COMP)]
+
+
+class ImgInfo(C.Structure):
+    _fields_ = [("sizes_x", C.c_int * MAX_COMP), ("sizes_y", C.c_int * MAX_COMP),
+                ("num_components", C.c_int), ("subsampling", Subsampling)]
+
+
+class Img(C.Structure):
+    _fields_ = [("image", C.c_void_p * MAX_COMP), ("pitch", C.c_int * MAX_COMP)]
+
+
+class ExtScanLayout(C.Structure):
+    _fields_ = [
+        ("num_components", C.c_int), ("component_idx", C.c_int * MAX_COMP),
+        ("num_subsequences", C.c_int), ("num_segments", C.c_int), ("num_sequences", C.c_int),
+        ("num_data_units", C.c_int), ("data_units_per_mcu", C.c_int), ("num_chunks", C.c_int),
+        ("off_segments", C.c_size_t), ("off_chunks", C.c_size_t), ("off_destuffed", C.c_size_t),
+        ("off_segment_index", C.c_size_t), ("off_state_p", C.c_size_t), ("off_state_n", C.c_size_t),
+        ("off_state_cz", C.c_size_t), ("off_state_dc", C.c_size_t * MAX_COMP),
+        ("off_coefficients", C.c_size_t),
+    ]
+
+
+class ExtLayout(C.Structure):
+    _fields_ = [
+        ("subsequence_bytes", C.c_int), ("num_scans", C.c_int),
+        ("transferred_bytes", C.c_size_t), ("blob_bytes", C.c_size_t),
+        ("off_bytes", C.c_size_t), ("off_qtables", C.c_size_t),
+        ("scans", ExtScanLayout * MAX_COMP),
+    ]
+
+
+class JpegGpuError(RuntimeError):
+    def __init__(self, status, where=""):
+        self.status = Status(status)
+        super().__init__("%s: %s" % (where, status_string(status)))
+
+
+_lib = None
+
+
+def lib():
+    """Load the C-ABI library (fails loudly when it has not been built)."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    # torch ships its own libamdhip64 (SONAME libamdhip64.so.7, loaded via RPATH under the file name
+    # libamdhip64.so). Import it first so our NEEDED libamdhip64.so.7 resolves to that same runtime:
+    # two HIP runtimes in one process do not know each other's allocations and streams.
+    try:
+        import torch  # noqa: F401
+    except ImportError:
+        pass
+    path = _build.LIB_PATH
+    if not os.path.exists(path):
+        raise ImportError(
+            "jpeggpu_amd: %s is missing -- run `python -c 'import __graft_entry__ as g; g.build()'`" % path)
+    L = C.CDLL(path)
+    dec = C.c_void_p
+    L.jpeggpu_get_status_string.restype = C.c_char_p
+    L.jpeggpu_get_status_string.argtypes = [C.c_int]
+    L.jpeggpu_decoder_startup.argtypes = [C.POINTER(dec)]
+    L.jpeggpu_set_logging.argtypes = [dec, C.c_int]
+    L.is_css_444.argtypes = [Subsampling, C.c_int]
+    L.jpeggpu_decoder_parse_header.argtypes = [dec, C.POINTER(ImgInfo), C.c_void_p, C.c_size_t]
+    L.jpeggpu_decoder_get_buffer_size.argtypes = [dec, C.POINTER(C.c_size_t)]
+    L.jpeggpu_decoder_transfer.argtypes = [dec, C.c_void_p, C.c_size_t, C.c_void_p]
+    L.jpeggpu_decoder_decode.argtypes = [dec, C.POINTER(Img), C.c_void_p, C.c_size_t, C.c_void_p]
+    L.jpeggpu_decoder_cleanup.argtypes = [dec]
+    L.jpeggpu_ext_set_subsequence_bytes.argtypes = [dec, C.c_int]
+    L.jpeggpu_ext_get_layout.argtypes = [dec, C.POINTER(ExtLayout)]
+    L.jpeggpu_ext_set_profiling.argtypes = [dec, C.c_int]
+    L.jpeggpu_ext_get_stage_ms.argtypes = [dec, C.POINTER(C.c_float)]
+    L.jpeggpu_ext_upsample_planes.argtypes = [
+        C.POINTER(ImgInfo), C.POINTER(Img), C.POINTER(Img), C.c_int, C.c_int, C.c_void_p]
+    _lib = L
+    return L
+
+
+def status_string(status) -> str:
+    return lib().jpeggpu_get_status_string(int(status)).decode()
+
+
+def _check(status, where):
+    if status != 0:
+        raise JpegGpuError(status, where)
+
+
+class Decoder:
+    """One jpeggpu_decoder_t. Not thread-safe; one decoder per host thread / stream."""
+
+    def __init__(self, subseq_bytes=None):
+        self._h = C.c_void_p()
+        _check(lib().jpeggpu_decoder_startup(C.byref(self._h)), "jpeggpu_decoder_startup")
+        self._keep = None
+        if subseq_bytes is not None:
+            self.set_subsequence_bytes(subseq_bytes)
+
+    def set_logging(self, on: bool):
+        _check(lib().jpeggpu_set_logging(self._h, int(on)), "jpeggpu_set_logging")
+
+    def set_subsequence_bytes(self, n: int):
+        _check(lib().jpeggpu_ext_set_subsequence_bytes(self._h, n), "jpeggpu_ext_set_subsequence_bytes")
+
+    def parse_header(self, data, size=None) -> ImgInfo:
+        """`data`: bytes, a numpy uint8 array, or an integer host address (then `size` is required).
+        The buffer is borrowed until the copy enqueued by transfer() has executed."""
+        info = ImgInfo()
+        if isinstance(data, int):
+            ptr, n = data, size
+        elif isinstance(data, (bytes, bytearray)):
+            self._keep = data
+            ptr = C.cast(C.c_char_p(bytes(data)) if isinstance(data, bytearray) else C.c_char_p(data), C.c_void_p).value
+            n = len(data)
+        else:  # numpy / torch-like with ctypes or data_ptr
+            self._keep = data
+            ptr = data.ctypes.data if hasattr(data, "ctypes") else data.data_ptr()
+            n = data.nbytes if hasattr(data, "nbytes") else data.numel()
+        _check(lib().jpeggpu_decoder_parse_header(self._h, C.byref(info), ptr, n), "jpeggpu_decoder_parse_header")
+        return info
+
+    def get_buffer_size(self) -> int:
+        n = C.c_size_t()
+        _check(lib().jpeggpu_decoder_get_buffer_size(self._h, C.byref(n)), "jpeggpu_decoder_get_buffer_size")
+        return n.value
+
+    def transfer(self, d_tmp: int, tmp_size: int, stream: int = 0):
+        _check(lib().jpeggpu_decoder_transfer(self._h, d_tmp, tmp_size, stream), "jpeggpu_decoder_transfer")
+
+    def decode(self, planes, pitches, d_tmp: int, tmp_size: int, stream: int = 0):
+        img = Img()
+        for c, (p, pitch) in enumerate(zip(planes, pitches)):
+            img.image[c] = p
+            img.pitch[c] = pitch
+        _check(lib().jpeggpu_decoder_decode(self._h, C.byref(img), d_tmp, tmp_size, stream), "jpeggpu_decoder_decode")
+
+    def set_profiling(self, on: bool):
+        _check(lib().jpeggpu_ext_set_profiling(self._h, int(on)), "jpeggpu_ext_set_profiling")
+
+    def stage_ms(self):
+        """Per-stage milliseconds of the last decode (after the stream was synchronised)."""
+        ms = (C.c_float * len(STAGES))()
+        _check(lib().jpeggpu_ext_get_stage_ms(self._h, ms), "jpeggpu_ext_get_stage_ms")
+        return dict(zip(STAGES, ms))
+
+    def layout(self) -> ExtLayout:
+        lay = ExtLayout()
+        _check(lib().jpeggpu_ext_get_layout(self._h, C.byref(lay)), "jpeggpu_ext_get_layout")
+        return lay
+
+    def cleanup(self):
+        if self._h:
+            lib().jpeggpu_decoder_cleanup(self._h)
+            self._h = C.c_void_p()
+
+    def __del__(self):
+        try:
+            self.cleanup()
+        except Exception:
+            pass
+
+
+def decode_to_planes(data: bytes, device="cuda:0", subseq_bytes=None, return_tmp=False):
+    """Convenience wrapper used by tests: full call sequence on torch's current stream, returns the
+    planes as torch uint8 tensors on `device` (torch is only the allocator / stream provider)."""
+    import torch
+
+    dec = Decoder(subseq_bytes)
+    try:
+        info = dec.parse_header(data)
+        n = dec.get_buffer_size()
+        tmp = torch.empty(n + 256, dtype=torch.uint8, device=device)
+        base = (tmp.data_ptr() + 255) // 256 * 256
+        stream = torch.cuda.current_stream(torch.device(device)).cuda_stream
+        planes = [torch.empty((info.sizes_y[c], info.sizes_x[c]), dtype=torch.uint8, device=device)
+                  for c in range(info.num_components)]
+        dec.transfer(base, n, stream)
+        dec.decode([p.data_ptr() for p in planes], [p.stride(0) for p in planes], base, n, stream)
+        torch.cuda.synchronize(torch.device(device))
+        if return_tmp:
+            return planes, info, tmp, base, dec.layout()
+        return planes, info
+    finally:
+        dec.cleanup()

@@ -19,6 +19,7 @@
 #include <cstdlib>
 #include <cstring>
 #include <new>
+#include <vector>
 
 namespace jg {
 
@@ -93,6 +94,13 @@ struct Decoder {
     int subseq_bytes    = 128;
     bool parsed         = false;
 
+    // optional stage timing (jpeggpu_ext_set_profiling): events recorded between the launches
+    bool profiling = false;
+    std::vector<hipEvent_t> events;
+    std::vector<int> event_stage; // stage that ENDS at event i (event 0 has none)
+    size_t events_used = 0;
+    bool mark(int stage, hipStream_t stream);
+
     void make_plan();
     bool fill_blob();
 };
@@ -161,6 +169,19 @@ void Decoder::make_plan()
     plan             = p;
 }
 
+bool Decoder::mark(int stage, hipStream_t stream)
+{
+    if (!profiling) return true;
+    if (events_used == events.size()) {
+        hipEvent_t e;
+        if (hipEventCreate(&e) != hipSuccess) return false;
+        events.push_back(e);
+        event_stage.push_back(0);
+    }
+    event_stage[events_used] = stage;
+    return hipEventRecord(events[events_used++], stream) == hipSuccess;
+}
+
 bool Decoder::fill_blob()
 {
     const Stream& s = reader.s;
@@ -225,9 +246,12 @@ jpeggpu_status do_decode(Decoder& d, jpeggpu_img* img, void* d_tmp, size_t tmp_s
     const Plan& plan  = d.plan;
     uint8_t* blob     = base + plan.off_blob;
 
+    d.events_used = 0;
+    d.mark(-1, stream);
     // only non-zero coefficients are stored by the write pass
     if (plan.coef_all_bytes)
         JG_CHECK_HIP(hipMemsetAsync(base + plan.off_coef_all, 0, plan.coef_all_bytes, stream));
+    d.mark(JPEGGPU_EXT_STAGE_MEMSET, stream);
 
     for (int i = 0; i < s.num_scans; ++i) {
         const Scan& sc     = s.scans[i];
@@ -295,17 +319,23 @@ jpeggpu_status do_decode(Decoder& d, jpeggpu_img* img, void* d_tmp, size_t tmp_s
             static_cast<int>(sc.chunks.size()),
             d.subseq_bytes,
             stream));
-        JG_CHECK_HIP(launch_huffman(
-            base + pl.destuffed,
-            d_segments,
-            d_seg_idx,
-            reinterpret_cast<const HuffTableDev*>(blob + pl.blob_tables),
-            sp,
-            st,
-            tails,
-            d_coef,
-            stream));
+        d.mark(JPEGGPU_EXT_STAGE_DESTUFF, stream);
+        for (int hs = kHuffSyncIntra; hs <= kHuffWrite; ++hs) {
+            JG_CHECK_HIP(launch_huffman_stage(
+                static_cast<HuffStage>(hs),
+                base + pl.destuffed,
+                d_segments,
+                d_seg_idx,
+                reinterpret_cast<const HuffTableDev*>(blob + pl.blob_tables),
+                sp,
+                st,
+                tails,
+                d_coef,
+                stream));
+            d.mark(JPEGGPU_EXT_STAGE_SYNC_INTRA + hs, stream);
+        }
         JG_CHECK_HIP(launch_idct(d_coef, blob + plan.blob_qtables, ip, stream));
+        d.mark(JPEGGPU_EXT_STAGE_IDCT, stream);
     }
     return JPEGGPU_SUCCESS;
 }
@@ -412,6 +442,7 @@ enum jpeggpu_status jpeggpu_decoder_cleanup(jpeggpu_decoder_t decoder)
 {
     if (!decoder) return JPEGGPU_INVALID_ARGUMENT;
     decoder->d.blob.release();
+    for (hipEvent_t e : decoder->d.events) (void)hipEventDestroy(e);
     delete decoder;
     return JPEGGPU_SUCCESS;
 }
@@ -421,6 +452,29 @@ enum jpeggpu_status jpeggpu_ext_set_subsequence_bytes(jpeggpu_decoder_t decoder,
     if (!decoder || !jg::subseq_bytes_supported(subseq_bytes)) return JPEGGPU_INVALID_ARGUMENT;
     decoder->d.subseq_bytes = subseq_bytes;
     decoder->d.parsed       = false;
+    return JPEGGPU_SUCCESS;
+}
+
+enum jpeggpu_status jpeggpu_ext_set_profiling(jpeggpu_decoder_t decoder, int enable)
+{
+    if (!decoder) return JPEGGPU_INVALID_ARGUMENT;
+    decoder->d.profiling   = enable != 0;
+    decoder->d.events_used = 0;
+    return JPEGGPU_SUCCESS;
+}
+
+enum jpeggpu_status jpeggpu_ext_get_stage_ms(jpeggpu_decoder_t decoder, float* ms)
+{
+    if (!decoder || !ms) return JPEGGPU_INVALID_ARGUMENT;
+    Decoder& d = decoder->d;
+    for (int i = 0; i < JPEGGPU_EXT_NUM_STAGES; ++i) ms[i] = 0.f;
+    if (!d.profiling || d.events_used < 2) return JPEGGPU_INVALID_ARGUMENT;
+    for (size_t i = 1; i < d.events_used; ++i) {
+        float t = 0.f;
+        if (hipEventElapsedTime(&t, d.events[i - 1], d.events[i]) != hipSuccess) return JPEGGPU_INTERNAL_ERROR;
+        const int st = d.event_stage[i];
+        if (st >= 0 && st < JPEGGPU_EXT_NUM_STAGES) ms[st] += t;
+    }
     return JPEGGPU_SUCCESS;
 }
 

@@ -145,20 +145,25 @@ struct SeqImage {
     static constexpr int kWords  = W * kStride;
 };
 
+/// `edge` holds the three words around the sequence: [0] the word before it (the write pass of the
+/// sequence's first subsequence starts up to 31 bits before its own first bit, reference
+/// decode_huffman_reader.hpp:279-292 carries those bits in `cache`), [1] and [2] the two words after
+/// it (a symbol may be peeked across the sequence's end).
 template <int W>
 struct LdsFetch {
     const uint32_t* img;
-    const uint32_t* tail;
+    const uint32_t* edge;
     int base;      // word offset of the segment's first word relative to the sequence's first word
     int seg_words; // words in the segment (zero beyond, reference decode_huffman_reader.hpp:110-152)
     __device__ __forceinline__ uint32_t operator()(int w) const
     {
         if (w >= seg_words) return 0u;
         const int local = base + w;
-        const int t     = local / W; // W is a power of two
-        const int k     = local % W;
+        if (local < 0) return edge[0];
+        const int t = local / W; // W is a power of two
+        const int k = local % W;
         if (t < T) return img[k * SeqImage<W>::kStride + t];
-        return tail[(local - T * W) & 1];
+        return edge[1 + ((local - T * W) & 1)];
     }
 };
 
@@ -173,7 +178,7 @@ struct GlobalFetch {
 
 template <int W>
 __device__ __forceinline__ void load_sequence(
-    uint32_t* img, uint32_t* tail, const uint32_t* __restrict__ scan32, int first_sub, int nsub, int num_subseq)
+    uint32_t* img, uint32_t* edge, const uint32_t* __restrict__ scan32, int first_sub, int nsub, int num_subseq)
 {
     const uint32_t* src = scan32 + static_cast<size_t>(first_sub) * W;
     const int nwords    = nsub * W;
@@ -181,10 +186,10 @@ __device__ __forceinline__ void load_sequence(
         img[(i % W) * SeqImage<W>::kStride + i / W] = __builtin_bswap32(src[i]);
     }
     if (threadIdx.x < 2) {
-        // the two words after the sequence: a symbol may be peeked across the sequence's end
-        const bool more   = first_sub + nsub < num_subseq;
-        tail[threadIdx.x] = more ? __builtin_bswap32(src[nwords + threadIdx.x]) : 0u;
+        const bool more       = first_sub + nsub < num_subseq;
+        edge[1 + threadIdx.x] = more ? __builtin_bswap32(src[nwords + threadIdx.x]) : 0u;
     }
+    if (threadIdx.x == 2) edge[0] = first_sub > 0 ? __builtin_bswap32(src[-1]) : 0u;
 }
 
 __device__ __forceinline__ void load_tables(HuffTableDev* s_tab, const HuffTableDev* __restrict__ g_tab)
@@ -213,7 +218,7 @@ __global__ __launch_bounds__(T) void huff_sync_intra(
     SubseqState out)
 {
     __shared__ uint32_t s_img[SeqImage<W>::kWords];
-    __shared__ uint32_t s_tail[2];
+    __shared__ uint32_t s_tail[3];
     __shared__ HuffTableDev s_tab[kHuffSlots];
     __shared__ int s_p[T], s_n[T], s_cz[T], s_dc[kMaxComp][T];
 
@@ -465,7 +470,7 @@ __global__ __launch_bounds__(T) void huff_write(
     int16_t* __restrict__ coef)
 {
     __shared__ uint32_t s_img[SeqImage<W>::kWords];
-    __shared__ uint32_t s_tail[2];
+    __shared__ uint32_t s_tail[3];
     __shared__ HuffTableDev s_tab[kHuffSlots];
     __shared__ int s_scan[T + 1];
     __shared__ int s_wave[4];
@@ -689,6 +694,7 @@ __global__ __launch_bounds__(256) void upsample_kernel(
 
 template <int W>
 hipError_t launch_huffman_w(
+    HuffStage which,
     const uint32_t* scan32,
     const Segment* d_segments,
     const int* d_seg_idx,
@@ -700,14 +706,24 @@ hipError_t launch_huffman_w(
     hipStream_t stream)
 {
     const int num_seq = (sp.num_subseq + T - 1) / T;
-    huff_sync_intra<W><<<num_seq, T, 0, stream>>>(scan32, d_segments, d_seg_idx, d_tables, sp, st);
-    if (num_seq > 1) {
-        const int want  = ((num_seq - 1 + 63) / 64) * 64;
-        const int lanes = want < 1024 ? want : 1024;
-        huff_sync_inter<W><<<1, lanes, 0, stream>>>(scan32, d_segments, d_seg_idx, d_tables, sp, st);
+    switch (which) {
+    case kHuffSyncIntra:
+        huff_sync_intra<W><<<num_seq, T, 0, stream>>>(scan32, d_segments, d_seg_idx, d_tables, sp, st);
+        break;
+    case kHuffSyncInter:
+        if (num_seq > 1) {
+            const int want  = ((num_seq - 1 + 63) / 64) * 64;
+            const int lanes = want < 1024 ? want : 1024;
+            huff_sync_inter<W><<<1, lanes, 0, stream>>>(scan32, d_segments, d_seg_idx, d_tables, sp, st);
+        }
+        break;
+    case kHuffTails:
+        huff_seq_tails<<<num_seq, T, 0, stream>>>(d_segments, d_seg_idx, sp, st, tails);
+        break;
+    case kHuffWrite:
+        huff_write<W><<<num_seq, T, 0, stream>>>(scan32, d_segments, d_seg_idx, d_tables, sp, st, tails, d_coef);
+        break;
     }
-    huff_seq_tails<<<num_seq, T, 0, stream>>>(d_segments, d_seg_idx, sp, st, tails);
-    huff_write<W><<<num_seq, T, 0, stream>>>(scan32, d_segments, d_seg_idx, d_tables, sp, st, tails, d_coef);
     return hipGetLastError();
 }
 
@@ -731,7 +747,8 @@ hipError_t launch_destuff(
     return hipGetLastError();
 }
 
-hipError_t launch_huffman(
+hipError_t launch_huffman_stage(
+    HuffStage which,
     const uint8_t* d_destuffed,
     const Segment* d_segments,
     const int* d_seg_idx,
@@ -745,9 +762,9 @@ hipError_t launch_huffman(
     if (sp.num_subseq == 0) return hipSuccess;
     const uint32_t* scan32 = reinterpret_cast<const uint32_t*>(d_destuffed);
     switch (sp.subseq_words) {
-    case 8: return launch_huffman_w<8>(scan32, d_segments, d_seg_idx, d_tables, sp, st, tails, d_coef, stream);
-    case 16: return launch_huffman_w<16>(scan32, d_segments, d_seg_idx, d_tables, sp, st, tails, d_coef, stream);
-    case 32: return launch_huffman_w<32>(scan32, d_segments, d_seg_idx, d_tables, sp, st, tails, d_coef, stream);
+    case 8: return launch_huffman_w<8>(which, scan32, d_segments, d_seg_idx, d_tables, sp, st, tails, d_coef, stream);
+    case 16: return launch_huffman_w<16>(which, scan32, d_segments, d_seg_idx, d_tables, sp, st, tails, d_coef, stream);
+    case 32: return launch_huffman_w<32>(which, scan32, d_segments, d_seg_idx, d_tables, sp, st, tails, d_coef, stream);
     }
     return hipErrorInvalidValue;
 }

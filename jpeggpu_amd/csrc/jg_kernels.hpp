@@ -34,7 +34,12 @@ hipError_t launch_destuff(
     int subseq_bytes,
     hipStream_t stream);
 
-hipError_t launch_huffman(
+/// The four Huffman launches of one scan, in order. `which` selects one of them so the caller can
+/// place timing events between the kernels.
+enum HuffStage { kHuffSyncIntra = 0, kHuffSyncInter = 1, kHuffTails = 2, kHuffWrite = 3 };
+
+hipError_t launch_huffman_stage(
+    HuffStage which,
     const uint8_t* d_destuffed,
     const Segment* d_segments,
     const int* d_seg_idx,

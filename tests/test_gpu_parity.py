@@ -1,0 +1,91 @@
+"""GPU parity: the HIP path, called through the C ABI, against the CPU oracle. Bit-exact."""
+import numpy as np
+import pytest
+
+from tests import cases
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def torch_cuda():
+    import torch
+
+    assert torch.cuda.is_available(), "GPU tests need a HIP device"
+    return torch
+
+
+@pytest.fixture(scope="module")
+def inputs():
+    return cases.matrix()
+
+
+def _decode_gpu(data, subseq_bytes=None):
+    import jpeggpu_amd
+
+    planes, info = jpeggpu_amd.decode_to_planes(data, subseq_bytes=subseq_bytes)
+    return [p.cpu().numpy() for p in planes], info
+
+
+@pytest.mark.parametrize("subseq_bytes", [128, 64, 32])
+def test_matrix_planes_bit_exact(gpu_lib, torch_cuda, inputs, subseq_bytes):
+    from oracle import oracle
+
+    bad = []
+    for name, data in inputs.items():
+        ref = oracle.decode(data)
+        got, info = _decode_gpu(data, subseq_bytes)
+        assert info.num_components == ref.ncomp
+        for c in range(ref.ncomp):
+            assert got[c].shape == ref.planes[c].shape, name
+            if not np.array_equal(got[c], ref.planes[c]):
+                bad.append((name, c, int((got[c] != ref.planes[c]).sum())))
+    assert not bad, bad
+
+
+def _tmp_view(torch, tmp, base, off, count, dtype):
+    start = base - tmp.data_ptr() + off
+    nbytes = count * torch.tensor([], dtype=dtype).element_size()
+    return tmp[start:start + nbytes].view(dtype).cpu().numpy()
+
+
+@pytest.mark.parametrize("name", ["dri_row", "multi_seq_nodri", "ni_420_dri", "cfg5_small", "dri_fill"])
+@pytest.mark.parametrize("subseq_bytes", [128, 32])
+def test_stage_parity(gpu_lib, torch_cuda, inputs, name, subseq_bytes):
+    """Every intermediate buffer against its CPU twin: destuffed bytes, subsequence->segment map,
+    synchronised states, stream-order coefficients."""
+    import jpeggpu_amd
+    from oracle import oracle
+
+    torch = torch_cuda
+    data = inputs[name]
+    planes, info, tmp, base, lay = jpeggpu_amd.decode_to_planes(data, subseq_bytes=subseq_bytes, return_tmp=True)
+    for s in range(lay.num_scans):
+        sl = lay.scans[s]
+        tw = oracle.scan_stages(data, s, subseq_bytes)
+        S = sl.num_subsequences
+        assert S == tw.num_subseq and sl.num_segments == tw.num_segments and sl.num_data_units == tw.num_du
+        dst = _tmp_view(torch, tmp, base, sl.off_destuffed, S * subseq_bytes, torch.uint8)
+        assert np.array_equal(dst, tw.destuffed), "destuffed bytes"
+        seg = _tmp_view(torch, tmp, base, sl.off_segment_index, S, torch.int32)
+        assert np.array_equal(seg, tw.seg_index), "segment index"
+        ok = tw.p >= 0
+        for nm, off, ref in (("p", sl.off_state_p, tw.p), ("n", sl.off_state_n, tw.n), ("cz", sl.off_state_cz, tw.cz)):
+            got = _tmp_view(torch, tmp, base, off, S, torch.int32)
+            assert np.array_equal(got[ok], ref[ok]), "state " + nm
+        for k in range(sl.num_components):
+            got = _tmp_view(torch, tmp, base, sl.off_state_dc[k], S, torch.int32)
+            assert np.array_equal(got[ok], tw.dc[k][ok]), "state dc%d" % k
+        coef = _tmp_view(torch, tmp, base, sl.off_coefficients, sl.num_data_units * 64, torch.int16)
+        assert np.array_equal(coef.reshape(-1, 64), tw.stream_coef), "coefficients"
+
+
+def test_reference_photo_full_size(gpu_lib, torch_cuda, photo_bytes):
+    """BASELINE config 1/2 input: the reference's own 12 MP photo, bit-exact vs the oracle."""
+    from oracle import oracle
+
+    ref = oracle.decode(photo_bytes)
+    got, info = _decode_gpu(photo_bytes)
+    assert list(info.sizes_x)[:3] == [4032, 2016, 2016] and list(info.sizes_y)[:3] == [3024, 1512, 1512]
+    for c in range(3):
+        assert np.array_equal(got[c], ref.planes[c]), "component %d" % c

@@ -1,0 +1,61 @@
+"""ctypes binding of tools/jpegsynth.c: seeded synthetic baseline JPEGs for tests and bench."""
+import ctypes as C
+import os
+import subprocess
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+_LIB = os.path.join(_HERE, "libjpegsynth.so")
+
+
+class _Params(C.Structure):
+    _fields_ = [("width", C.c_int), ("height", C.c_int), ("ncomp", C.c_int),
+                ("hs", C.c_int * 4), ("vs", C.c_int * 4),
+                ("interleaved", C.c_int), ("restart_interval", C.c_int), ("quality", C.c_int),
+                ("optimize", C.c_int), ("noise", C.c_int), ("fill_bytes", C.c_int), ("seed", C.c_uint64)]
+
+
+def build(force=False):
+    src = os.path.join(_HERE, "jpegsynth.c")
+    if force or not os.path.exists(_LIB) or os.path.getmtime(_LIB) < os.path.getmtime(src):
+        subprocess.check_call(["gcc", "-O2", "-shared", "-fPIC", "-o", _LIB, src, "-lm"])
+    return _LIB
+
+
+_lib = None
+
+
+def encode(width, height, sampling=((2, 2), (1, 1), (1, 1)), interleaved=True, restart_interval=0,
+           quality=75, optimize=False, noise=6, fill_bytes=0, seed=0) -> bytes:
+    """sampling: one (h, v) pair per component (1..4 components)."""
+    global _lib
+    if _lib is None:
+        build()
+        _lib = C.CDLL(_LIB)
+        _lib.js_encode.restype = C.c_size_t
+        _lib.js_encode.argtypes = [C.POINTER(_Params), C.c_void_p, C.c_size_t]
+    p = _Params()
+    p.width, p.height, p.ncomp = width, height, len(sampling)
+    for c, (h, v) in enumerate(sampling):
+        p.hs[c], p.vs[c] = h, v
+    p.interleaved, p.restart_interval, p.quality = int(interleaved), restart_interval, quality
+    p.optimize, p.noise, p.fill_bytes, p.seed = int(optimize), noise, fill_bytes, seed
+    cap = 1024 + width * height * len(sampling) * 3
+    buf = C.create_string_buffer(cap)
+    n = _lib.js_encode(C.byref(p), buf, cap)
+    if n == 0:
+        raise RuntimeError("jpegsynth: encode failed (bad parameters or buffer too small)")
+    return buf.raw[:n]
+
+
+# The five BASELINE.json configurations, at full size and at a reduced size for oracle-speed tests.
+def config(idx: int, seed: int = 0, small: bool = False) -> bytes:
+    if idx in (1, 2, 3):  # 12 MP 4:2:0 interleaved, one restart interval per MCU row
+        w, h = (4032, 3024) if not small else (496, 360)
+        return encode(w, h, ((2, 2), (1, 1), (1, 1)), True, (w + 15) // 16, quality=88, noise=9, seed=seed)
+    if idx == 4:  # 39 MP 4:4:4, three single-component scans, no restart markers
+        w, h = (7216, 5408) if not small else (456, 344)
+        return encode(w, h, ((1, 1), (1, 1), (1, 1)), False, 0, quality=80, noise=6, seed=seed)
+    if idx == 5:  # 4 components (2x1,1x1,1x1,2x1), 4 DC + 4 AC tables, no restart markers
+        w, h = (4032, 3024) if not small else (504, 376)
+        return encode(w, h, ((2, 1), (1, 1), (1, 1), (2, 1)), True, 0, quality=85, optimize=True, noise=6, seed=seed)
+    raise ValueError(idx)
