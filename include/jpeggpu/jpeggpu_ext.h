@@ -42,7 +42,9 @@ struct jpeggpu_ext_scan_layout {
     size_t off_state_p;        /* int[num_subsequences] */
     size_t off_state_n;
     size_t off_state_cz;       /* c | z << 8 */
-    size_t off_state_dc[JPEGGPU_MAX_COMP];
+    size_t off_state_dc01;     /* uint32[num_subsequences]: wrapping 16-bit DC-difference sums of scan
+                                  components 0 (low half) and 1 (high half) */
+    size_t off_state_dc23;     /* same for scan components 2 and 3 */
     size_t off_coefficients;   /* int16[num_data_units * 64], stream order, natural order inside */
 };
 

@@ -46,7 +46,7 @@ class ExtScanLayout(C.Structure):
         ("num_data_units", C.c_int), ("data_units_per_mcu", C.c_int), ("num_chunks", C.c_int),
         ("off_segments", C.c_size_t), ("off_chunks", C.c_size_t), ("off_destuffed", C.c_size_t),
         ("off_segment_index", C.c_size_t), ("off_state_p", C.c_size_t), ("off_state_n", C.c_size_t),
-        ("off_state_cz", C.c_size_t), ("off_state_dc", C.c_size_t * MAX_COMP),
+        ("off_state_cz", C.c_size_t), ("off_state_dc01", C.c_size_t), ("off_state_dc23", C.c_size_t),
         ("off_coefficients", C.c_size_t),
     ]
 

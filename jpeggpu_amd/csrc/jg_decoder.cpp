@@ -67,8 +67,8 @@ struct ScanPlan {
     // offsets inside the blob (and, shifted by off_blob, inside d_tmp)
     size_t blob_tables = 0, blob_segments = 0, blob_chunks = 0;
     // offsets inside d_tmp
-    size_t destuffed = 0, seg_idx = 0, st_p = 0, st_n = 0, st_cz = 0, st_dc[kMaxComp] = {};
-    size_t tails_n = 0, tails_dc[kMaxComp] = {};
+    size_t destuffed = 0, seg_idx = 0, st_p = 0, st_n = 0, st_cz = 0, st_dc01 = 0, st_dc23 = 0;
+    size_t tails_n = 0, tails_dc01 = 0, tails_dc23 = 0;
     size_t coef = 0;
     int num_seq = 0;
 };
@@ -117,7 +117,7 @@ void Decoder::make_plan()
         const Scan& sc    = s.scans[i];
         ScanPlan& sp      = p.scan[i];
         sp.blob_tables    = b;
-        b += align_up(sizeof(sc.tables), 256);
+        b += align_up(sc.table_pack.size(), 256);
         sp.blob_segments  = b;
         b += align_up(sc.segments.size() * sizeof(Segment), 256);
         sp.blob_chunks    = b;
@@ -147,16 +147,16 @@ void Decoder::make_plan()
         o += align_up(S * 4, 256);
         sp.st_cz = o;
         o += align_up(S * 4, 256);
-        for (int k = 0; k < sc.num_comp; ++k) {
-            sp.st_dc[k] = o;
-            o += align_up(S * 4, 256);
-        }
+        sp.st_dc01 = o;
+        o += align_up(S * 4, 256);
+        sp.st_dc23 = o;
+        o += align_up(S * 4, 256);
         sp.tails_n = o;
         o += align_up(static_cast<size_t>(sp.num_seq) * 4, 256);
-        for (int k = 0; k < sc.num_comp; ++k) {
-            sp.tails_dc[k] = o;
-            o += align_up(static_cast<size_t>(sp.num_seq) * 4, 256);
-        }
+        sp.tails_dc01 = o;
+        o += align_up(static_cast<size_t>(sp.num_seq) * 4, 256);
+        sp.tails_dc23 = o;
+        o += align_up(static_cast<size_t>(sp.num_seq) * 4, 256);
     }
     // all coefficient buffers are contiguous: one memset covers them
     p.off_coef_all = o;
@@ -191,7 +191,7 @@ bool Decoder::fill_blob()
     for (int i = 0; i < s.num_scans; ++i) {
         const Scan& sc     = s.scans[i];
         const ScanPlan& sp = plan.scan[i];
-        std::memcpy(blob.ptr + sp.blob_tables, sc.tables, sizeof(sc.tables));
+        std::memcpy(blob.ptr + sp.blob_tables, sc.table_pack.data(), sc.table_pack.size());
         if (!sc.segments.empty())
             std::memcpy(blob.ptr + sp.blob_segments, sc.segments.data(), sc.segments.size() * sizeof(Segment));
         if (!sc.chunks.empty())
@@ -265,6 +265,7 @@ jpeggpu_status do_decode(Decoder& d, jpeggpu_img* img, void* d_tmp, size_t tmp_s
         sp.mcus_per_segment = sc.mcus_per_segment;
         sp.total_mcus       = sc.mcus_x * sc.mcus_y;
         sp.subseq_words     = d.subseq_bytes / 4;
+        sp.tab_bytes        = static_cast<uint32_t>(sc.table_pack.size());
         IdctParams ip{};
         ip.num_du     = sc.num_du;
         ip.du_per_mcu = sc.du_per_mcu;
@@ -272,8 +273,8 @@ jpeggpu_status do_decode(Decoder& d, jpeggpu_img* img, void* d_tmp, size_t tmp_s
         int du        = 0;
         for (int a = 0; a < sc.num_comp; ++a) {
             const ScanComponent& c = sc.comp[a];
-            sp.dc_slot |= static_cast<uint32_t>(c.dc_id * 2) << (4 * a);
-            sp.ac_slot |= static_cast<uint32_t>(c.ac_id * 2 + 1) << (4 * a);
+            sp.dc_offs |= static_cast<uint64_t>(sc.dc_off[a]) << (16 * a);
+            sp.ac_offs |= static_cast<uint64_t>(sc.ac_off[a]) << (16 * a);
             for (int y = 0; y < c.v; ++y) {
                 for (int x = 0; x < c.h; ++x) { // row-major inside the MCU (T.81 A.2.3)
                     sp.du_comp |= static_cast<uint32_t>(a) << (2 * du);
@@ -298,11 +299,11 @@ jpeggpu_status do_decode(Decoder& d, jpeggpu_img* img, void* d_tmp, size_t tmp_s
         st.n  = reinterpret_cast<int*>(base + pl.st_n);
         st.cz = reinterpret_cast<int*>(base + pl.st_cz);
         SeqTails tails{};
-        tails.n = reinterpret_cast<int*>(base + pl.tails_n);
-        for (int k = 0; k < sc.num_comp; ++k) {
-            st.dc[k]    = reinterpret_cast<int*>(base + pl.st_dc[k]);
-            tails.dc[k] = reinterpret_cast<int*>(base + pl.tails_dc[k]);
-        }
+        st.dc01    = reinterpret_cast<uint32_t*>(base + pl.st_dc01);
+        st.dc23    = reinterpret_cast<uint32_t*>(base + pl.st_dc23);
+        tails.n    = reinterpret_cast<int*>(base + pl.tails_n);
+        tails.dc01 = reinterpret_cast<uint32_t*>(base + pl.tails_dc01);
+        tails.dc23 = reinterpret_cast<uint32_t*>(base + pl.tails_dc23);
         const Segment* d_segments = reinterpret_cast<const Segment*>(blob + pl.blob_segments);
         int* d_seg_idx            = reinterpret_cast<int*>(base + pl.seg_idx);
         int16_t* d_coef           = reinterpret_cast<int16_t*>(base + pl.coef);
@@ -326,7 +327,7 @@ jpeggpu_status do_decode(Decoder& d, jpeggpu_img* img, void* d_tmp, size_t tmp_s
                 base + pl.destuffed,
                 d_segments,
                 d_seg_idx,
-                reinterpret_cast<const HuffTableDev*>(blob + pl.blob_tables),
+                blob + pl.blob_tables,
                 sp,
                 st,
                 tails,
@@ -496,10 +497,9 @@ enum jpeggpu_status jpeggpu_ext_get_layout(jpeggpu_decoder_t decoder, struct jpe
         const jg::ScanPlan& pl     = d.plan.scan[i];
         jpeggpu_ext_scan_layout& o = out->scans[i];
         o.num_components           = sc.num_comp;
-        for (int k = 0; k < sc.num_comp; ++k) {
-            o.component_idx[k] = sc.comp[k].comp_idx;
-            o.off_state_dc[k]  = pl.st_dc[k];
-        }
+        for (int k = 0; k < sc.num_comp; ++k) o.component_idx[k] = sc.comp[k].comp_idx;
+        o.off_state_dc01 = pl.st_dc01;
+        o.off_state_dc23 = pl.st_dc23;
         o.num_subsequences   = sc.num_subseq;
         o.num_segments       = static_cast<int>(sc.segments.size());
         o.num_sequences      = pl.num_seq;

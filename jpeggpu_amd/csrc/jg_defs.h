@@ -19,7 +19,6 @@ namespace jg {
 constexpr int kMaxComp      = 4;  // include/jpeggpu/jpeggpu.h:33
 constexpr int kMaxScans     = 4;  // baseline: every component appears in exactly one scan
 constexpr int kMaxDuPerMcu  = 10; // T.81 B.2.3
-constexpr int kHuffSlots    = 8;  // slot = Th*2 + Tc (Tc: 0 = DC, 1 = AC), reference src/reader.cpp:263
 constexpr int kSeqSubseq    = 256; // subsequences per workgroup ("sequence"), reference decode_huffman.cu:777
 constexpr int kDestuffWin   = 4096; // stuffed bytes handled by one destuff workgroup (256 lanes x 16 B)
 
@@ -29,31 +28,40 @@ constexpr int kDestuffWin   = 4096; // stuffed bytes handled by one destuff work
      41, 34, 27, 20, 13, 6,  7,  14, 21, 28, 35, 42, 49, 56, 57, 50, 43, 36, 29, 22, 15, 23,       \
      30, 37, 44, 51, 58, 59, 52, 45, 38, 31, 39, 46, 53, 60, 61, 54, 47, 55, 62, 63}
 
-/// Device Huffman table. Same information as the reference's `huffman_table`
-/// (src/reader.hpp:45-64: 8-bit LUT + maxcode/valptr walk + huffval) but the LUT entry is
-/// pre-digested so the per-symbol step needs one LDS read and no table-class branch:
-///   bits  0..4  code length 1..8, 0 = code longer than 8 bits (slow path)
-///   bits  5..10 total symbol length = code length + magnitude bits
-///   bits 11..14 magnitude category s (0..15)
-///   bit  15     end-of-block (AC symbol with s == 0 and run != 15), always 0 in a DC table
-///   bits 16..20 run + 1 (1..16); 1 in a DC table
-struct HuffTableDev {
-    uint32_t lut[256];
-    int32_t maxcode[16]; // largest code of length l+1, -1 if none (reference reader.cpp:213-223)
-    int32_t valoff[16];  // huffval index of first code of length l+1 minus that code
-    uint8_t huffval[256];
-};
-static_assert(sizeof(HuffTableDev) == 1408, "layout is shared with the kernels");
+/// Device Huffman table pack. Same information as the reference's `huffman_table`
+/// (src/reader.hpp:45-64: 8-bit LUT + maxcode/valptr walk + huffval), re-laid-out for a wave of 64
+/// lanes that all walk different bitstreams: a wide first-level LUT of pre-digested 16-bit entries
+/// (so that almost no lane ever needs the long-code path, which every lane of the wave would have
+/// to wait for), and a long-code path without a dependent chain of table reads.
+///
+///   one table = lut16[1 << LB] | lim16[8] | valoff16[8] | huffval[256]     (LB = 10 for DC, 12 for AC)
+///
+///   lut16 entry, indexed by the LB most significant bits of the 32-bit window:
+///     bits  0..5  total symbol length = code length + magnitude bits (0 = code longer than LB bits)
+///     bits  6..9  magnitude category s
+///     bits 10..14 run + 1 (1..16); 1 in a DC table
+///     bit  15     end-of-block (AC symbol with s == 0 and run != 15), 0 in a DC table
+///   lim16[j], j = 0..7: canonical code counter after length 9+j, left-aligned to 16 bits and
+///     saturated to 0xFFFF; a 16-bit window v holds a code of length <= 9+j iff v < lim16[j]
+///     (equivalent to the reference's maxcode walk, src/decode_huffman.cu:177-187)
+///   valoff16[j]: (huffval index of the first code of length 9+j minus that code) mod 256
+///
+/// A scan's pack holds only the tables its components select; ScanParams carries the byte offsets.
+constexpr int kLutBitsDc   = 10;
+constexpr int kLutBitsAc   = 12;
+constexpr int kHuffAuxSize = 16 + 16 + 256;
+constexpr int kDcTableSize = (2 << kLutBitsDc) + kHuffAuxSize; // 2336
+constexpr int kAcTableSize = (2 << kLutBitsAc) + kHuffAuxSize; // 8480
+constexpr int kMaxTablePack = kMaxComp * (kDcTableSize + kAcTableSize);
 
-JG_HD inline uint32_t huff_entry(int codelen_for_lut, int codelen, uint32_t sym, bool is_dc)
+JG_HD inline uint32_t huff_entry(int codelen, uint32_t sym, bool is_dc)
 {
     // DC: sym is the category (hardened to 4 bits; valid baseline streams use 0..11).
     // AC: sym = run << 4 | category (reference decode_huffman.cu:232-259).
     const uint32_t s   = sym & 15u;
     const uint32_t r   = is_dc ? 0u : (sym >> 4);
     const uint32_t eob = (!is_dc && s == 0 && r != 15) ? 1u : 0u;
-    return static_cast<uint32_t>(codelen_for_lut) | ((codelen + s) << 5) | (s << 11) | (eob << 15) |
-           ((r + 1u) << 16);
+    return (static_cast<uint32_t>(codelen) + s) | (s << 6) | ((r + 1u) << 10) | (eob << 15);
 }
 
 /// One restart segment of a scan inside the destuffed buffer (reference src/reader.hpp:38-43).
@@ -88,8 +96,11 @@ struct ScanParams {
     int total_mcus;
     int subseq_words;     // 32-bit words per subsequence (subsequence bytes / 4)
     uint32_t du_comp;     // 2 bits per data unit of the MCU: scan-component index
-    uint32_t dc_slot;     // 4 bits per scan component: Huffman slot of its DC table
-    uint32_t ac_slot;     // 4 bits per scan component: Huffman slot of its AC table
+    uint32_t tab_bytes;   // size of the scan's Huffman table pack
+    // Byte offset of each scan component's DC / AC table in the pack, 16 bits per component. Packed
+    // scalars, not arrays: a runtime-indexed kernel-argument array is re-read from memory per use.
+    uint64_t dc_offs;
+    uint64_t ac_offs;
 };
 
 /// Geometry for dequant + IDCT reading the stream-order coefficient buffer (replaces the reference's

@@ -12,8 +12,13 @@
 //   * z >= 64 after a symbol closes the data unit whatever the overshoot (only reachable while
 //     decoding from a wrong speculative state or on corrupt input).
 // New relative to the reference: the DC differences committed by a subsequence are summed per scan
-// component (`dc[]`), which lets the write pass emit absolute DC values and removes the separate
-// DC prefix-sum pass over the coefficient buffer (src/decode_dc.cu:88-169).
+// component (`dc01`/`dc23`, four wrapping 16-bit sums), which lets the write pass emit absolute DC
+// values and removes the separate DC prefix-sum pass over the coefficient buffer
+// (src/decode_dc.cu:88-169, which also accumulates in int16).
+//
+// The loop is written for a wave of 64 lanes in lock-step: what one lane needs every lane pays for,
+// so the common path is branch-light, the next bitstream word is fetched one refill ahead, and the
+// long-code path has no chain of dependent table reads (see jg_defs.h for the table pack).
 #ifndef JG_HUFF_CORE_H_
 #define JG_HUFF_CORE_H_
 
@@ -26,16 +31,31 @@ struct LaneState {
     int n; // coefficient slots committed by the subsequence being decoded
     int c; // data unit index inside the MCU
     int z; // zig-zag index
-    int dc[kMaxComp]; // sum of committed DC differences per scan component
+    uint32_t dc01; // wrapping 16-bit sums of committed DC differences: component 0 | component 1 << 16
+    uint32_t dc23; // component 2 | component 3 << 16
 };
+
+JG_HD inline uint32_t pk_add_u16(uint32_t a, uint32_t b)
+{
+    // two independent 16-bit lanes, no carry between them (v_pk_add_u16 on gfx950)
+#if defined(__HIP_DEVICE_COMPILE__)
+    typedef unsigned short us2 __attribute__((ext_vector_type(2)));
+    const us2 r = __builtin_bit_cast(us2, a) + __builtin_bit_cast(us2, b);
+    return __builtin_bit_cast(uint32_t, r);
+#else
+    return ((a + b) & 0xFFFFu) | (((a >> 16) + (b >> 16)) << 16);
+#endif
+}
 
 /// MSB-first 64-bit window over big-endian 32-bit words. `Fetch(w)` returns word `w` of the
 /// segment's destuffed data (zero past the padded end, reference decode_huffman_reader.hpp:110-152).
+/// `nextw` always holds word `widx`, fetched one refill before it is shifted in.
 template <class Fetch>
 struct BitWindow {
     uint64_t win;
     int avail;
-    int next_word;
+    int widx;
+    uint32_t nextw;
 
     JG_HD inline void seek(int p, const Fetch& fetch)
     {
@@ -43,14 +63,16 @@ struct BitWindow {
         const int off = p & 31;
         win           = ((static_cast<uint64_t>(fetch(w)) << 32) | fetch(w + 1)) << off;
         avail         = 64 - off;
-        next_word     = w + 2;
+        widx          = w + 2;
+        nextw         = fetch(widx);
     }
     JG_HD inline uint32_t peek(const Fetch& fetch)
     {
         if (avail < 32) {
-            win |= static_cast<uint64_t>(fetch(next_word)) << (32 - avail);
+            win |= static_cast<uint64_t>(nextw) << (32 - avail);
             avail += 32;
-            ++next_word;
+            ++widx;
+            nextw = fetch(widx);
         }
         return static_cast<uint32_t>(win >> 32);
     }
@@ -61,24 +83,28 @@ struct BitWindow {
     }
 };
 
-/// Decode one Huffman code from the 32 MSB-aligned bits `peek`. Returns the digested entry
-/// (layout: HuffTableDev). Codes longer than 8 bits walk maxcode[] like the reference's
-/// `get_category` (src/decode_huffman.cu:167-194): the 16-bit iteration always accepts and the
+JG_HD inline uint32_t ld_u16(const uint8_t* p) { return *reinterpret_cast<const uint16_t*>(p); }
+
+/// Code longer than the first-level LUT: find its length by counting thresholds (all eight
+/// thresholds come from one 16-byte read), then one huffval read. Reproduces the reference's
+/// `get_category` (src/decode_huffman.cu:167-194): the 16-bit candidate always accepts and the
 /// huffval index is reduced modulo 256, so an invalid code still consumes 9..16 bits.
-JG_HD inline uint32_t huff_lookup(const HuffTableDev* t, uint32_t peek, bool is_dc)
+JG_HD inline uint32_t huff_long_code(const uint8_t* aux, uint32_t peek, bool is_dc)
 {
-    uint32_t e = t->lut[peek >> 24];
-    if ((e & 31u) == 0) {
-        int l = 8; // candidate length - 1
-        int32_t code;
-        for (;; ++l) {
-            code = static_cast<int32_t>(peek >> (31 - l));
-            if (l == 15 || code <= t->maxcode[l]) break;
-        }
-        const uint32_t sym = t->huffval[static_cast<uint8_t>(t->valoff[l] + code)];
-        e                  = huff_entry(0, l + 1, sym, is_dc);
-    }
-    return e;
+    const uint32_t v = peek >> 16;
+    int l            = 9;
+#if defined(__HIP_DEVICE_COMPILE__)
+    typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
+    const u32x4 lim = *reinterpret_cast<const u32x4*>(aux); // one 16-byte LDS read
+#pragma unroll
+    for (int j = 0; j < 7; ++j) l += v >= ((lim[j >> 1] >> (16 * (j & 1))) & 0xFFFFu) ? 1 : 0;
+#else
+    for (int j = 0; j < 7; ++j) l += v >= ld_u16(aux + 2 * j) ? 1 : 0;
+#endif
+    const uint32_t code = v >> (16 - l);
+    const uint32_t off  = ld_u16(aux + 16 + 2 * (l - 9));
+    const uint32_t sym  = aux[32 + ((off + code) & 0xFFu)];
+    return huff_entry(l, sym, is_dc);
 }
 
 JG_HD inline int extend_magnitude(uint32_t bits, int s)
@@ -99,17 +125,17 @@ JG_HD inline uint32_t bits_field(uint32_t peek, int total_len, int s)
 }
 
 struct TableSel {
-    const HuffTableDev* dc;
-    const HuffTableDev* ac;
+    uint32_t dc; // byte offsets into the table pack
+    uint32_t ac;
     int comp;
 };
 
-JG_HD inline TableSel select_tables(const HuffTableDev* tables, const ScanParams& sp, int c)
+JG_HD inline TableSel select_tables(const ScanParams& sp, int c)
 {
     TableSel r;
     r.comp = (sp.du_comp >> (2 * c)) & 3;
-    r.dc   = tables + ((sp.dc_slot >> (4 * r.comp)) & 15);
-    r.ac   = tables + ((sp.ac_slot >> (4 * r.comp)) & 15);
+    r.dc   = static_cast<uint32_t>(sp.dc_offs >> (16 * r.comp)) & 0xFFFFu;
+    r.ac   = static_cast<uint32_t>(sp.ac_offs >> (16 * r.comp)) & 0xFFFFu;
     return r;
 }
 
@@ -122,56 +148,57 @@ struct NoSink {
     JG_HD inline void advance(int) {}
 };
 
-/// Decode subsequence `sub_rel` (index inside its segment) from `st`, committing symbols that end
-/// at or before the subsequence's last bit. `st.n` and `st.dc[]` accumulate.
+/// Decode from `st` up to bit `end_bit` of the segment, committing symbols that end at or before it.
+/// `st.n`, `st.dc01`, `st.dc23` accumulate. `tabs` is the scan's table pack (LDS on the device).
+///
+/// ONE flat loop, one symbol per iteration for every lane: the data-unit boundary is handled with
+/// selects, not with a branch -- a branch there makes the compiler nest the loop, and a nested loop
+/// makes the 64 lanes of a wave wait for the longest data unit among them at every boundary.
 template <class Fetch, class Sink>
 JG_HD inline void decode_subsequence(
     LaneState& st,
     BitWindow<Fetch>& bw,
     const Fetch& fetch,
     int end_bit,
-    const HuffTableDev* tables,
+    const uint8_t* tabs,
     const ScanParams& sp,
     Sink& sink)
 {
-    TableSel ts = select_tables(tables, sp, st.c);
+    TableSel ts = select_tables(sp, st.c);
     while (true) {
         if (Sink::kWrite && sink.full()) break;
         const uint32_t peek = bw.peek(fetch);
         const bool is_dc    = st.z == 0;
-        const uint32_t e    = huff_lookup(is_dc ? ts.dc : ts.ac, peek, is_dc);
-        const int total     = (e >> 5) & 63;
+        const uint8_t* tab  = tabs + (is_dc ? ts.dc : ts.ac);
+        const uint32_t idx  = is_dc ? peek >> (32 - kLutBitsDc) : peek >> (32 - kLutBitsAc);
+        uint32_t e          = ld_u16(tab + 2 * idx);
+        if (e == 0) e = huff_long_code(tab + (is_dc ? (2 << kLutBitsDc) : (2 << kLutBitsAc)), peek, is_dc);
+        const int total = e & 63;
         if (st.p + total > end_bit) break;
         bw.skip(total);
         st.p += total;
-        const int s = (e >> 11) & 15;
-        int adv;
-        if (is_dc) {
-            const int diff = extend_magnitude(bits_field(peek, total, s), s);
-            // unrolled select instead of dc[comp]: a runtime-indexed register array goes to scratch
-            st.dc[0] += ts.comp == 0 ? diff : 0;
-            st.dc[1] += ts.comp == 1 ? diff : 0;
-            st.dc[2] += ts.comp == 2 ? diff : 0;
-            st.dc[3] += ts.comp == 3 ? diff : 0;
-            sink.dc(ts.comp, diff);
-            adv = 1;
-        } else if (e & 0x8000u) {
-            adv = 64 - st.z;
-            sink.advance(adv);
-        } else {
-            adv = (e >> 16) & 31;
-            if (Sink::kWrite) {
-                if (s) sink.ac(adv - 1, extend_magnitude(bits_field(peek, total, s), s));
+        const int s    = (e >> 6) & 15;
+        const int run1 = (e >> 10) & 31;
+        const int adv  = (e & 0x8000u) ? 64 - st.z : run1; // DC entries have run1 == 1, no EOB flag
+        if (Sink::kWrite || is_dc) {
+            const int v = extend_magnitude(bits_field(peek, total, s), s);
+            if (is_dc) {
+                const uint32_t d = (static_cast<uint32_t>(v) & 0xFFFFu) << (16 * (ts.comp & 1));
+                st.dc01          = pk_add_u16(st.dc01, ts.comp < 2 ? d : 0u);
+                st.dc23          = pk_add_u16(st.dc23, ts.comp < 2 ? 0u : d);
+                sink.dc(ts.comp, v);
+            } else if (Sink::kWrite) {
+                if (s) sink.ac(adv - 1, v);
                 else sink.advance(adv);
             }
         }
         st.n += adv;
-        st.z += adv;
-        if (st.z >= 64) {
-            st.z = 0;
-            st.c = st.c + 1 >= sp.du_per_mcu ? 0 : st.c + 1;
-            ts   = select_tables(tables, sp, st.c);
-        }
+        const int z1      = st.z + adv;
+        const bool du_end = z1 >= 64;
+        const int c1      = st.c + 1 >= sp.du_per_mcu ? 0 : st.c + 1;
+        st.z              = du_end ? 0 : z1;
+        st.c              = du_end ? c1 : st.c;
+        ts                = select_tables(sp, st.c); // a few scalar-operand ALU ops, no memory
     }
 }
 

@@ -145,25 +145,25 @@ struct SeqImage {
     static constexpr int kWords  = W * kStride;
 };
 
-/// `edge` holds the three words around the sequence: [0] the word before it (the write pass of the
-/// sequence's first subsequence starts up to 31 bits before its own first bit, reference
-/// decode_huffman_reader.hpp:279-292 carries those bits in `cache`), [1] and [2] the two words after
-/// it (a symbol may be peeked across the sequence's end).
+/// Words just outside the sequence live in the image's pad column, so one address formula serves
+/// every read: the word before the sequence (local index -1; the write pass of the sequence's first
+/// subsequence starts up to 31 bits before its own first bit, reference
+/// decode_huffman_reader.hpp:279-292 carries those bits in `cache`) lands on (k = W-1, t = -1), and the
+/// three words after it (a symbol may be peeked across the sequence's end and the window prefetches
+/// one word ahead) on (k = 0..2, t = T).
 template <int W>
 struct LdsFetch {
+    static constexpr int kLog2W = W == 8 ? 3 : W == 16 ? 4 : 5;
+    static_assert((1 << kLog2W) == W, "subsequence words must be 8, 16 or 32");
     const uint32_t* img;
-    const uint32_t* edge;
     int base;      // word offset of the segment's first word relative to the sequence's first word
     int seg_words; // words in the segment (zero beyond, reference decode_huffman_reader.hpp:110-152)
     __device__ __forceinline__ uint32_t operator()(int w) const
     {
-        if (w >= seg_words) return 0u;
-        const int local = base + w;
-        if (local < 0) return edge[0];
-        const int t = local / W; // W is a power of two
-        const int k = local % W;
-        if (t < T) return img[k * SeqImage<W>::kStride + t];
-        return edge[1 + ((local - T * W) & 1)];
+        // past the segment's end read the zero word at (k = 3, t = T): selecting the ADDRESS keeps
+        // the loaded value free of dependent ALU work, so the prefetch really runs ahead
+        const int local = w < seg_words ? min(base + w, T * W + 2) : T * W + 3;
+        return img[(local & (W - 1)) * SeqImage<W>::kStride + (local >> kLog2W)];
     }
 };
 
@@ -178,27 +178,43 @@ struct GlobalFetch {
 
 template <int W>
 __device__ __forceinline__ void load_sequence(
-    uint32_t* img, uint32_t* edge, const uint32_t* __restrict__ scan32, int first_sub, int nsub, int num_subseq)
+    uint32_t* img, const uint32_t* __restrict__ scan32, int first_sub, int nsub, int num_subseq)
 {
     const uint32_t* src = scan32 + static_cast<size_t>(first_sub) * W;
     const int nwords    = nsub * W;
     for (int i = threadIdx.x; i < nwords; i += T) {
         img[(i % W) * SeqImage<W>::kStride + i / W] = __builtin_bswap32(src[i]);
     }
-    if (threadIdx.x < 2) {
-        const bool more       = first_sub + nsub < num_subseq;
-        edge[1 + threadIdx.x] = more ? __builtin_bswap32(src[nwords + threadIdx.x]) : 0u;
+    if (threadIdx.x < 3) {
+        // words T*W + 0..2 -> (k = 0..2, t = T); the destuffed buffer has 256 spare bytes at its end
+        const bool more = nsub == T && first_sub + nsub < num_subseq;
+        img[threadIdx.x * SeqImage<W>::kStride + T] = more ? __builtin_bswap32(src[T * W + threadIdx.x]) : 0u;
     }
-    if (threadIdx.x == 2) edge[0] = first_sub > 0 ? __builtin_bswap32(src[-1]) : 0u;
+    if (threadIdx.x == 3) img[3 * SeqImage<W>::kStride + T] = 0u; // the zero word
+    if (threadIdx.x == 4) {
+        // word -1 -> (k = W-1, t = -1)
+        img[(W - 1) * SeqImage<W>::kStride - 1] = first_sub > 0 ? __builtin_bswap32(src[-1]) : 0u;
+    }
 }
 
-__device__ __forceinline__ void load_tables(HuffTableDev* s_tab, const HuffTableDev* __restrict__ g_tab)
+/// Copy the scan's Huffman table pack (a multiple of 16 bytes) into LDS.
+__device__ __forceinline__ void load_tables(uint8_t* s_tab, const uint8_t* __restrict__ g_tab, uint32_t bytes)
 {
-    constexpr int n    = kHuffSlots * sizeof(HuffTableDev) / 4;
-    uint32_t* d        = reinterpret_cast<uint32_t*>(s_tab);
-    const uint32_t* s  = reinterpret_cast<const uint32_t*>(g_tab);
-    for (int i = threadIdx.x; i < n; i += blockDim.x) d[i] = s[i];
+    uint4* d       = reinterpret_cast<uint4*>(s_tab);
+    const uint4* s = reinterpret_cast<const uint4*>(g_tab);
+    for (uint32_t i = threadIdx.x; i < bytes / 16; i += blockDim.x) d[i] = s[i];
 }
+
+/// Carve of the dynamic LDS of the two sequence-wide Huffman kernels.
+template <int W>
+struct SeqLds {
+    static constexpr uint32_t kImg   = 0;
+    static constexpr uint32_t kState = kImg + SeqImage<W>::kWords * 4;
+    static constexpr uint32_t kTabs  = (kState + 6 * (T + 1) * 4 + 64 + 15) / 16 * 16; // 5 state arrays / scan scratch
+    static_assert(kTabs % 16 == 0, "the table pack is read with 16-byte loads");
+};
+
+__device__ __forceinline__ uint32_t pk_add(uint32_t a, uint32_t b) { return pk_add_u16(a, b); }
 
 // ------------------------------------------------------------------------------------------------
 // Huffman: speculative decode + intra-sequence synchronisation
@@ -213,27 +229,31 @@ __global__ __launch_bounds__(T) void huff_sync_intra(
     const uint32_t* __restrict__ scan32,
     const Segment* __restrict__ segments,
     const int* __restrict__ seg_idx,
-    const HuffTableDev* __restrict__ g_tables,
+    const uint8_t* __restrict__ g_tables,
     ScanParams sp,
     SubseqState out)
 {
-    __shared__ uint32_t s_img[SeqImage<W>::kWords];
-    __shared__ uint32_t s_tail[3];
-    __shared__ HuffTableDev s_tab[kHuffSlots];
-    __shared__ int s_p[T], s_n[T], s_cz[T], s_dc[kMaxComp][T];
+    extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
+    uint32_t* s_img  = reinterpret_cast<uint32_t*>(smem + SeqLds<W>::kImg);
+    int* s_p         = reinterpret_cast<int*>(smem + SeqLds<W>::kState);
+    int* s_n         = s_p + T;
+    int* s_cz        = s_n + T;
+    uint32_t* s_dc01 = reinterpret_cast<uint32_t*>(s_cz + T);
+    uint32_t* s_dc23 = s_dc01 + T;
+    uint8_t* s_tab   = smem + SeqLds<W>::kTabs;
 
     const int t         = threadIdx.x;
     const int first_sub = blockIdx.x * T;
     const int nsub      = min(T, sp.num_subseq - first_sub);
 
-    load_tables(s_tab, g_tables);
-    load_sequence<W>(s_img, s_tail, scan32, first_sub, nsub, sp.num_subseq);
+    load_tables(s_tab, g_tables, sp.tab_bytes);
+    load_sequence<W>(s_img, scan32, first_sub, nsub, sp.num_subseq);
     __syncthreads();
 
     const bool active = t < nsub;
     LaneState st{};
     BitWindow<LdsFetch<W>> bw{};
-    LdsFetch<W> fetch{s_img, s_tail, 0, 0};
+    LdsFetch<W> fetch{s_img, 0, 0};
     int end_bit = 0;
     int lim     = 0; // flows stay below this local index: end of the segment or of the sequence
     NoSink sink;
@@ -248,11 +268,11 @@ __global__ __launch_bounds__(T) void huff_sync_intra(
         end_bit           = (rel + 1) * (W * 32);
         bw.seek(st.p, fetch);
         decode_subsequence(st, bw, fetch, end_bit, s_tab, sp, sink);
-        s_p[t]  = st.p;
-        s_n[t]  = st.n;
-        s_cz[t] = st.c | (st.z << 8);
-#pragma unroll
-        for (int k = 0; k < kMaxComp; ++k) s_dc[k][t] = st.dc[k];
+        s_p[t]    = st.p;
+        s_n[t]    = st.n;
+        s_cz[t]   = st.c | (st.z << 8);
+        s_dc01[t] = st.dc01;
+        s_dc23[t] = st.dc23;
     }
     __syncthreads();
 
@@ -260,18 +280,18 @@ __global__ __launch_bounds__(T) void huff_sync_intra(
     for (int iter = 0; iter < T; ++iter) {
         const int j = t + 1 + iter;
         if (flowing && j < lim) {
-            st.n = 0;
-#pragma unroll
-            for (int k = 0; k < kMaxComp; ++k) st.dc[k] = 0;
+            st.n    = 0;
+            st.dc01 = 0;
+            st.dc23 = 0;
             end_bit += W * 32;
             decode_subsequence(st, bw, fetch, end_bit, s_tab, sp, sink);
             const int cz = st.c | (st.z << 8);
             if (st.p == s_p[j] && cz == s_cz[j]) flowing = false; // synchronised; still store n / dc
-            s_p[j]  = st.p;
-            s_n[j]  = st.n;
-            s_cz[j] = cz;
-#pragma unroll
-            for (int k = 0; k < kMaxComp; ++k) s_dc[k][j] = st.dc[k];
+            s_p[j]    = st.p;
+            s_n[j]    = st.n;
+            s_cz[j]   = cz;
+            s_dc01[j] = st.dc01;
+            s_dc23[j] = st.dc23;
         } else {
             flowing = false;
         }
@@ -283,7 +303,8 @@ __global__ __launch_bounds__(T) void huff_sync_intra(
         out.p[sub]    = s_p[t];
         out.n[sub]    = s_n[t];
         out.cz[sub]   = s_cz[t];
-        for (int k = 0; k < sp.num_comp; ++k) out.dc[k][sub] = s_dc[k][t];
+        out.dc01[sub] = s_dc01[t];
+        out.dc23[sub] = s_dc23[t];
     }
 }
 
@@ -296,18 +317,20 @@ __global__ __launch_bounds__(T) void huff_sync_intra(
 /// in lock-step inside ONE workgroup, groups of boundaries are processed in stream order, so a flow
 /// that started further upstream always overwrites later and, unlike the
 /// reference (Appendix B-4), no pair of boundaries is left unordered. State lives in global memory,
-/// bitstream words are read straight from the destuffed buffer.
+/// bitstream words are read straight from the destuffed buffer (one refill ahead, so the load
+/// latency is off the critical path).
 template <int W>
 __global__ __launch_bounds__(1024) void huff_sync_inter(
     const uint32_t* __restrict__ scan32,
     const Segment* __restrict__ segments,
     const int* __restrict__ seg_idx,
-    const HuffTableDev* __restrict__ g_tables,
+    const uint8_t* __restrict__ g_tables,
     ScanParams sp,
     SubseqState g)
 {
-    __shared__ HuffTableDev s_tab[kHuffSlots];
-    load_tables(s_tab, g_tables);
+    extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
+    uint8_t* s_tab = smem;
+    load_tables(s_tab, g_tables, sp.tab_bytes);
     __syncthreads();
 
     const int num_seq = (sp.num_subseq + T - 1) / T;
@@ -340,17 +363,18 @@ __global__ __launch_bounds__(1024) void huff_sync_inter(
         }
         while (true) {
             if (flowing && j < lim) {
-                st.n = 0;
-#pragma unroll
-                for (int k = 0; k < kMaxComp; ++k) st.dc[k] = 0;
+                st.n    = 0;
+                st.dc01 = 0;
+                st.dc23 = 0;
                 end_bit += W * 32;
                 decode_subsequence(st, bw, fetch, end_bit, s_tab, sp, sink);
                 const int cz = st.c | (st.z << 8);
                 if (st.p == g.p[j] && cz == g.cz[j]) flowing = false;
-                g.p[j]  = st.p;
-                g.n[j]  = st.n;
-                g.cz[j] = cz;
-                for (int k = 0; k < sp.num_comp; ++k) g.dc[k][j] = st.dc[k];
+                g.p[j]    = st.p;
+                g.n[j]    = st.n;
+                g.cz[j]   = cz;
+                g.dc01[j] = st.dc01;
+                g.dc23[j] = st.dc23;
                 ++j;
             } else {
                 flowing = false;
@@ -366,13 +390,18 @@ __global__ __launch_bounds__(1024) void huff_sync_inter(
 // Huffman: per-sequence tails
 // ------------------------------------------------------------------------------------------------
 
-__device__ __forceinline__ int block_sum_256(int v, int* s_red)
+template <bool kPacked>
+__device__ __forceinline__ uint32_t block_sum_256(uint32_t v, uint32_t* s_red)
 {
 #pragma unroll
-    for (int d = 32; d > 0; d >>= 1) v += __shfl_down(v, d);
+    for (int d = 32; d > 0; d >>= 1) {
+        const uint32_t o = __shfl_down(v, d);
+        v                = kPacked ? pk_add(v, o) : v + o;
+    }
     __syncthreads();
     if (lane_id() == 0) s_red[threadIdx.x >> 6] = v;
     __syncthreads();
+    if (kPacked) return pk_add(pk_add(s_red[0], s_red[1]), pk_add(s_red[2], s_red[3]));
     return s_red[0] + s_red[1] + s_red[2] + s_red[3];
 }
 
@@ -386,7 +415,7 @@ __global__ __launch_bounds__(T) void huff_seq_tails(
     SubseqState g,
     SeqTails tails)
 {
-    __shared__ int s_red[4];
+    __shared__ uint32_t s_red[4];
     const int t         = threadIdx.x;
     const int first_sub = blockIdx.x * T;
     const int nsub      = min(T, sp.num_subseq - first_sub);
@@ -394,11 +423,13 @@ __global__ __launch_bounds__(T) void huff_seq_tails(
     const int open_from = segments[last_seg].subseq_offset; // global index of that segment's start
     const int sub       = first_sub + t;
     const bool take     = t < nsub && sub >= open_from;
-    const int n         = block_sum_256(take ? g.n[sub] : 0, s_red);
-    if (t == 0) tails.n[blockIdx.x] = n;
-    for (int k = 0; k < sp.num_comp; ++k) {
-        const int d = block_sum_256(take ? g.dc[k][sub] : 0, s_red);
-        if (t == 0) tails.dc[k][blockIdx.x] = d;
+    const uint32_t n    = block_sum_256<false>(take ? g.n[sub] : 0, s_red);
+    const uint32_t d01  = block_sum_256<true>(take ? g.dc01[sub] : 0u, s_red);
+    const uint32_t d23  = block_sum_256<true>(take ? g.dc23[sub] : 0u, s_red);
+    if (t == 0) {
+        tails.n[blockIdx.x]    = static_cast<int>(n);
+        tails.dc01[blockIdx.x] = d01;
+        tails.dc23[blockIdx.x] = d23;
     }
 }
 
@@ -439,20 +470,35 @@ struct CoefSink {
 };
 
 /// Exclusive prefix over the 256 lanes of `v` (plain, not segmented), result left in s_scan[0..T].
-__device__ __forceinline__ void block_excl_scan_256(int v, int* s_scan, int* s_wave)
+template <bool kPacked>
+__device__ __forceinline__ void block_excl_scan_256(uint32_t v, uint32_t* s_scan, uint32_t* s_wave)
 {
-    const int t       = threadIdx.x;
-    const uint32_t in = wave_incl_scan(static_cast<uint32_t>(v));
-    __syncthreads(); // previous use of s_scan / s_wave is over
-    if (lane_id() == 63) s_wave[t >> 6] = static_cast<int>(in);
-    __syncthreads();
-    int off = 0;
+    const int t = threadIdx.x;
+    uint32_t in = v;
 #pragma unroll
-    for (int k = 0; k < 4; ++k) off += k < (t >> 6) ? s_wave[k] : 0;
-    s_scan[t] = static_cast<int>(in) - v + off;
-    if (t == T - 1) s_scan[T] = static_cast<int>(in) + off;
+    for (int d = 1; d < 64; d <<= 1) {
+        const uint32_t o = __shfl_up(in, d);
+        if (lane_id() >= d) in = kPacked ? pk_add(in, o) : in + o;
+    }
+    __syncthreads(); // previous use of s_scan / s_wave is over
+    if (lane_id() == 63) s_wave[t >> 6] = in;
+    __syncthreads();
+    uint32_t off = 0;
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+        const uint32_t w = k < (t >> 6) ? s_wave[k] : 0u;
+        off              = kPacked ? pk_add(off, w) : off + w;
+    }
+    const uint32_t incl = kPacked ? pk_add(in, off) : in + off;
+    // exclusive = inclusive - v, per 16-bit half when packed
+    s_scan[t] = kPacked ? pk_add(incl, pk_add(~v, 0x00010001u)) : incl - v;
+    if (t == T - 1) s_scan[T] = incl;
     __syncthreads();
 }
+
+__device__ __forceinline__ uint32_t pk_sub(uint32_t a, uint32_t b) { return pk_add(a, pk_add(~b, 0x00010001u)); }
+__device__ __forceinline__ int lo16(uint32_t v) { return static_cast<int16_t>(v & 0xFFFFu); }
+__device__ __forceinline__ int hi16(uint32_t v) { return static_cast<int16_t>(v >> 16); }
 
 /// Re-decode every subsequence from its predecessor's synchronised exit state and store the
 /// non-zero coefficients in stream order (data unit after data unit, natural order inside, DC
@@ -463,26 +509,26 @@ __global__ __launch_bounds__(T) void huff_write(
     const uint32_t* __restrict__ scan32,
     const Segment* __restrict__ segments,
     const int* __restrict__ seg_idx,
-    const HuffTableDev* __restrict__ g_tables,
+    const uint8_t* __restrict__ g_tables,
     ScanParams sp,
     SubseqState g,
     SeqTails tails,
     int16_t* __restrict__ coef)
 {
-    __shared__ uint32_t s_img[SeqImage<W>::kWords];
-    __shared__ uint32_t s_tail[3];
-    __shared__ HuffTableDev s_tab[kHuffSlots];
-    __shared__ int s_scan[T + 1];
-    __shared__ int s_wave[4];
-    __shared__ int s_carry[1 + kMaxComp];
-    __shared__ uint8_t s_nat[64];
+    extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
+    uint32_t* s_img  = reinterpret_cast<uint32_t*>(smem + SeqLds<W>::kImg);
+    uint32_t* s_scan = reinterpret_cast<uint32_t*>(smem + SeqLds<W>::kState); // T + 1
+    uint32_t* s_wave = s_scan + T + 1;                                         // 4
+    uint32_t* s_carry = s_wave + 4;                                            // 3
+    uint8_t* s_nat   = reinterpret_cast<uint8_t*>(s_carry + 3);                // 64
+    uint8_t* s_tab   = smem + SeqLds<W>::kTabs;
 
     const int t         = threadIdx.x;
     const int first_sub = blockIdx.x * T;
     const int nsub      = min(T, sp.num_subseq - first_sub);
 
-    load_tables(s_tab, g_tables);
-    load_sequence<W>(s_img, s_tail, scan32, first_sub, nsub, sp.num_subseq);
+    load_tables(s_tab, g_tables, sp.tab_bytes);
+    load_sequence<W>(s_img, scan32, first_sub, nsub, sp.num_subseq);
     if (t < 64) {
         constexpr uint8_t nat[64] = JG_ORDER_NATURAL;
         s_nat[t]                  = nat[t];
@@ -492,18 +538,21 @@ __global__ __launch_bounds__(T) void huff_write(
     {
         const Segment seg0 = segments[seg_idx[first_sub]];
         const int a        = seg0.subseq_offset / T; // sequence holding the segment's start
-        int cn = 0, cd[kMaxComp] = {0, 0, 0, 0};
+        uint32_t cn = 0, c01 = 0, c23 = 0;
         if (seg0.subseq_offset < first_sub) {
             for (int b = a + t; b < static_cast<int>(blockIdx.x); b += T) {
-                cn += tails.n[b];
-                for (int k = 0; k < sp.num_comp; ++k) cd[k] += tails.dc[k][b];
+                cn += static_cast<uint32_t>(tails.n[b]);
+                c01 = pk_add(c01, tails.dc01[b]);
+                c23 = pk_add(c23, tails.dc23[b]);
             }
         }
-        cn = block_sum_256(cn, s_wave);
-        if (t == 0) s_carry[0] = cn;
-        for (int k = 0; k < sp.num_comp; ++k) {
-            const int d = block_sum_256(cd[k], s_wave);
-            if (t == 0) s_carry[1 + k] = d;
+        cn  = block_sum_256<false>(cn, s_wave);
+        c01 = block_sum_256<true>(c01, s_wave);
+        c23 = block_sum_256<true>(c23, s_wave);
+        if (t == 0) {
+            s_carry[0] = cn;
+            s_carry[1] = c01;
+            s_carry[2] = c23;
         }
     }
     __syncthreads();
@@ -526,16 +575,16 @@ __global__ __launch_bounds__(T) void huff_write(
     sink.natural = s_nat;
     int nprefix  = 0;
     {
-        block_excl_scan_256(active ? g.n[sub] : 0, s_scan, s_wave);
-        nprefix = s_scan[t] - s_scan[ts] + (carried ? s_carry[0] : 0);
-#pragma unroll
-        for (int k = 0; k < kMaxComp; ++k) {
-            sink.pred[k] = 0;
-            if (k < sp.num_comp) {
-                block_excl_scan_256(active ? g.dc[k][sub] : 0, s_scan, s_wave);
-                sink.pred[k] = s_scan[t] - s_scan[ts] + (carried ? s_carry[1 + k] : 0);
-            }
-        }
+        block_excl_scan_256<false>(active ? static_cast<uint32_t>(g.n[sub]) : 0u, s_scan, s_wave);
+        nprefix = static_cast<int>(s_scan[t] - s_scan[ts] + (carried ? s_carry[0] : 0u));
+        block_excl_scan_256<true>(active ? g.dc01[sub] : 0u, s_scan, s_wave);
+        const uint32_t p01 = pk_add(pk_sub(s_scan[t], s_scan[ts]), carried ? s_carry[1] : 0u);
+        block_excl_scan_256<true>(active ? g.dc23[sub] : 0u, s_scan, s_wave);
+        const uint32_t p23 = pk_add(pk_sub(s_scan[t], s_scan[ts]), carried ? s_carry[2] : 0u);
+        sink.pred[0] = lo16(p01);
+        sink.pred[1] = hi16(p01);
+        sink.pred[2] = lo16(p23);
+        sink.pred[3] = hi16(p23);
     }
     if (!active) return;
 
@@ -552,7 +601,7 @@ __global__ __launch_bounds__(T) void huff_write(
         st.c         = cz & 0xFF;
         st.z         = cz >> 8;
     }
-    LdsFetch<W> fetch{s_img, s_tail, (seg.subseq_offset - first_sub) * W, seg.subseq_count * W};
+    LdsFetch<W> fetch{s_img, (seg.subseq_offset - first_sub) * W, seg.subseq_count * W};
     BitWindow<LdsFetch<W>> bw{};
     bw.seek(st.p, fetch);
     decode_subsequence(st, bw, fetch, (rel + 1) * (W * 32), s_tab, sp, sink);
@@ -692,36 +741,48 @@ __global__ __launch_bounds__(256) void upsample_kernel(
     }
 }
 
+template <class K>
+hipError_t allow_lds(K kernel, size_t bytes)
+{
+    // more than 64 KiB of dynamic LDS has to be requested per kernel; gfx950 has 160 KiB per CU
+    if (bytes <= 64 * 1024) return hipSuccess;
+    return hipFuncSetAttribute(reinterpret_cast<const void*>(kernel), hipFuncAttributeMaxDynamicSharedMemorySize, static_cast<int>(bytes));
+}
+
 template <int W>
 hipError_t launch_huffman_w(
     HuffStage which,
     const uint32_t* scan32,
     const Segment* d_segments,
     const int* d_seg_idx,
-    const HuffTableDev* d_tables,
+    const uint8_t* d_tables,
     const ScanParams& sp,
     SubseqState st,
     SeqTails tails,
     int16_t* d_coef,
     hipStream_t stream)
 {
-    const int num_seq = (sp.num_subseq + T - 1) / T;
+    const int num_seq      = (sp.num_subseq + T - 1) / T;
+    const size_t seq_lds   = SeqLds<W>::kTabs + sp.tab_bytes;
+    hipError_t err         = hipSuccess;
     switch (which) {
     case kHuffSyncIntra:
-        huff_sync_intra<W><<<num_seq, T, 0, stream>>>(scan32, d_segments, d_seg_idx, d_tables, sp, st);
+        if ((err = allow_lds(huff_sync_intra<W>, seq_lds)) != hipSuccess) return err;
+        huff_sync_intra<W><<<num_seq, T, seq_lds, stream>>>(scan32, d_segments, d_seg_idx, d_tables, sp, st);
         break;
     case kHuffSyncInter:
         if (num_seq > 1) {
             const int want  = ((num_seq - 1 + 63) / 64) * 64;
             const int lanes = want < 1024 ? want : 1024;
-            huff_sync_inter<W><<<1, lanes, 0, stream>>>(scan32, d_segments, d_seg_idx, d_tables, sp, st);
+            huff_sync_inter<W><<<1, lanes, sp.tab_bytes, stream>>>(scan32, d_segments, d_seg_idx, d_tables, sp, st);
         }
         break;
     case kHuffTails:
         huff_seq_tails<<<num_seq, T, 0, stream>>>(d_segments, d_seg_idx, sp, st, tails);
         break;
     case kHuffWrite:
-        huff_write<W><<<num_seq, T, 0, stream>>>(scan32, d_segments, d_seg_idx, d_tables, sp, st, tails, d_coef);
+        if ((err = allow_lds(huff_write<W>, seq_lds)) != hipSuccess) return err;
+        huff_write<W><<<num_seq, T, seq_lds, stream>>>(scan32, d_segments, d_seg_idx, d_tables, sp, st, tails, d_coef);
         break;
     }
     return hipGetLastError();
@@ -752,7 +813,7 @@ hipError_t launch_huffman_stage(
     const uint8_t* d_destuffed,
     const Segment* d_segments,
     const int* d_seg_idx,
-    const HuffTableDev* d_tables,
+    const uint8_t* d_tables,
     const ScanParams& sp,
     SubseqState st,
     SeqTails tails,

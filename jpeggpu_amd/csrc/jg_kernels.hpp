@@ -14,13 +14,15 @@ struct SubseqState {
     int* p;             // bit position after the last committed symbol, relative to the segment
     int* n;             // coefficient slots committed
     int* cz;            // c | z << 8
-    int* dc[kMaxComp];  // sum of committed DC differences per scan component
+    uint32_t* dc01;     // wrapping 16-bit sums of committed DC differences, scan components 0 | 1 << 16
+    uint32_t* dc23;     // scan components 2 | 3 << 16
 };
 
 /// Per-sequence (workgroup) aggregate used to place the write pass without a device-wide scan.
 struct SeqTails {
     int* n;
-    int* dc[kMaxComp];
+    uint32_t* dc01;
+    uint32_t* dc23;
 };
 
 bool subseq_bytes_supported(int subseq_bytes);
@@ -43,7 +45,7 @@ hipError_t launch_huffman_stage(
     const uint8_t* d_destuffed,
     const Segment* d_segments,
     const int* d_seg_idx,
-    const HuffTableDev* d_tables,
+    const uint8_t* d_tables, // the scan's table pack (jg_defs.h)
     const ScanParams& sp,
     SubseqState st,
     SeqTails tails,

@@ -15,38 +15,39 @@ inline int ceil_div(int a, int b) { return (a + b - 1) / b; }
 } // namespace
 
 void build_huff_table(
-    HuffTableDev& t, const uint8_t (&num_codes)[16], const uint8_t* huffval, int count, bool is_dc)
+    std::vector<uint8_t>& t, const uint8_t (&num_codes)[16], const uint8_t* huffval, int count, bool is_dc)
 {
-    std::memset(&t, 0, sizeof(t));
-    for (int i = 0; i < count && i < 256; ++i) t.huffval[i] = huffval[i];
-    // canonical code assignment, T.81 Annex C; lut entry 0 = "longer than 8 bits or undefined"
-    uint16_t huffcode[256];
+    const int lb        = is_dc ? kLutBitsDc : kLutBitsAc;
+    const size_t lut_sz = static_cast<size_t>(2) << lb;
+    t.assign(lut_sz + kHuffAuxSize, 0);
+    uint16_t* lut  = reinterpret_cast<uint16_t*>(t.data());
+    uint16_t* lim  = reinterpret_cast<uint16_t*>(t.data() + lut_sz);
+    uint16_t* voff = lim + 8;
+    uint8_t* hv    = t.data() + lut_sz + 32;
+    for (int i = 0; i < count && i < 256; ++i) hv[i] = huffval[i];
+    // canonical code assignment, T.81 Annex C; lut entry 0 = "longer than LB bits or undefined"
     int idx       = 0;
     uint32_t code = 0;
-    for (int l = 0; l < 16; ++l) {
-        for (int i = 0; i < num_codes[l] && idx < 256; ++i) {
-            huffcode[idx] = static_cast<uint16_t>(code);
-            if (l < 8) {
-                const int shift   = 7 - l;
-                const uint32_t e  = huff_entry(l + 1, l + 1, t.huffval[idx], is_dc);
-                const uint32_t lo = (code << shift) & 0xFF;
-                for (uint32_t j = 0; j < (1u << shift); ++j) t.lut[(lo + j) & 0xFF] = e;
+    for (int l = 1; l <= 16; ++l) {
+        const int first_idx = idx;
+        const uint32_t first_code = code;
+        for (int i = 0; i < num_codes[l - 1] && idx < 256; ++i) {
+            if (l <= lb) {
+                const int shift  = lb - l;
+                const uint32_t e = huff_entry(l, hv[idx], is_dc);
+                const uint32_t lo = (code << shift) & ((1u << lb) - 1);
+                for (uint32_t j = 0; j < (1u << shift); ++j) lut[(lo + j) & ((1u << lb) - 1)] = static_cast<uint16_t>(e);
             }
             ++idx;
             ++code;
         }
-        code <<= 1;
-    }
-    idx = 0;
-    for (int l = 0; l < 16; ++l) {
-        if (num_codes[l] && idx < 256) {
-            t.valoff[l] = idx - huffcode[idx];
-            idx         = std::min(idx + num_codes[l], 256);
-            t.maxcode[l] = huffcode[idx - 1];
-        } else {
-            t.maxcode[l] = -1;
-            t.valoff[l]  = 0;
+        if (l >= 9) {
+            // `code` now counts every code of length <= l; left-aligned it separates them from longer ones
+            const uint32_t left = code << (16 - l);
+            lim[l - 9]  = static_cast<uint16_t>(left > 0xFFFFu ? 0xFFFFu : left);
+            voff[l - 9] = num_codes[l - 1] ? static_cast<uint16_t>((first_idx - static_cast<int>(first_code)) & 0xFF) : 0;
         }
+        code <<= 1;
     }
 }
 
@@ -154,9 +155,13 @@ jpeggpu_status Reader::read_dht(const Logger& log)
             code <<= 1;
         }
         log.log("\t%s Huffman table index %d\n", tc == 0 ? "DC" : "AC", th);
-        const int slot = th * 2 + tc;
-        build_huff_table(cur_tables_[slot], num_codes, cur_, count, tc == 0);
-        ht_defined_[slot] = true;
+        if (tc == 0) {
+            build_huff_table(dc_tab_[th], num_codes, cur_, count, true);
+            dc_defined_[th] = true;
+        } else {
+            build_huff_table(ac_tab_[th], num_codes, cur_, count, false);
+            ac_defined_[th] = true;
+        }
         cur_ += count;
         rem -= count;
     }
@@ -269,7 +274,7 @@ jpeggpu_status Reader::read_sos(const Logger& log)
         if (a > 0 && ci <= scan.comp[a - 1].comp_idx) return JPEGGPU_INVALID_JPEG;
         if (comp_in_scan_[ci]) return JPEGGPU_INVALID_JPEG;
         if (id_dc > 3 || id_ac > 3) return JPEGGPU_INVALID_JPEG;
-        if (!ht_defined_[id_dc * 2] || !ht_defined_[id_ac * 2 + 1]) return JPEGGPU_INVALID_JPEG;
+        if (!dc_defined_[id_dc] || !ac_defined_[id_ac]) return JPEGGPU_INVALID_JPEG;
         const Component& comp = s.comp[ci];
         if (!qt_defined_[comp.qidx]) {
             log.log("\tquantization table at index %d not defined\n", comp.qidx);
@@ -301,7 +306,27 @@ jpeggpu_status Reader::read_sos(const Logger& log)
     u8(); // spectral selection end (63)
     u8(); // successive approximation (0)
 
-    std::memcpy(scan.tables, cur_tables_, sizeof(cur_tables_)); // tables in force for this scan
+    // pack the tables in force for this scan; components that select the same table share it
+    for (int a = 0; a < ns; ++a) {
+        const ScanComponent& sc = scan.comp[a];
+        int same_dc = -1, same_ac = -1;
+        for (int b = 0; b < a; ++b) {
+            if (scan.comp[b].dc_id == sc.dc_id) same_dc = b;
+            if (scan.comp[b].ac_id == sc.ac_id) same_ac = b;
+        }
+        if (same_dc >= 0) {
+            scan.dc_off[a] = scan.dc_off[same_dc];
+        } else {
+            scan.dc_off[a] = static_cast<uint16_t>(scan.table_pack.size());
+            scan.table_pack.insert(scan.table_pack.end(), dc_tab_[sc.dc_id].begin(), dc_tab_[sc.dc_id].end());
+        }
+        if (same_ac >= 0) {
+            scan.ac_off[a] = scan.ac_off[same_ac];
+        } else {
+            scan.ac_off[a] = static_cast<uint16_t>(scan.table_pack.size());
+            scan.table_pack.insert(scan.table_pack.end(), ac_tab_[sc.ac_id].begin(), ac_tab_[sc.ac_id].end());
+        }
+    }
     const int total_mcus  = scan.mcus_x * scan.mcus_y;
     scan.mcus_per_segment = s.restart_interval ? s.restart_interval : total_mcus;
     scan.num_du           = total_mcus * scan.du_per_mcu;
@@ -420,8 +445,8 @@ jpeggpu_status Reader::parse(const uint8_t* data, size_t size, int subseq_bytes,
     subseq_bytes_ = subseq_bytes;
     found_sof_    = false;
     std::memset(qt_defined_, 0, sizeof(qt_defined_));
-    std::memset(ht_defined_, 0, sizeof(ht_defined_));
-    std::memset(cur_tables_, 0, sizeof(cur_tables_));
+    std::memset(dc_defined_, 0, sizeof(dc_defined_));
+    std::memset(ac_defined_, 0, sizeof(ac_defined_));
     std::memset(comp_in_scan_, 0, sizeof(comp_in_scan_));
     if (size >= (1ull << 31)) return JPEGGPU_NOT_SUPPORTED;
 

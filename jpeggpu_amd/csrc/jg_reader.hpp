@@ -59,7 +59,9 @@ struct Scan {
     int mcus_per_segment = 0;
     int num_subseq = 0;
     int num_du = 0;
-    HuffTableDev tables[kHuffSlots]; // snapshot of the tables in force at SOS
+    std::vector<uint8_t> table_pack; // tables in force at SOS that this scan's components select
+    uint16_t dc_off[kMaxComp] = {};  // byte offset in table_pack per scan component
+    uint16_t ac_off[kMaxComp] = {};
     std::vector<Segment> segments;
     std::vector<DestuffChunk> chunks;
 };
@@ -90,8 +92,8 @@ struct Reader {
     int subseq_bytes_    = 128;
     bool found_sof_      = false;
     bool qt_defined_[4]{};
-    bool ht_defined_[kHuffSlots]{};
-    HuffTableDev cur_tables_[kHuffSlots];
+    bool dc_defined_[4]{}, ac_defined_[4]{};
+    std::vector<uint8_t> dc_tab_[4], ac_tab_[4]; // device-format tables by table id (T.81 Th)
     bool comp_in_scan_[kMaxComp]{};
 
     size_t remaining() const { return static_cast<size_t>(end_ - cur_); }
@@ -112,7 +114,8 @@ struct Reader {
 
 /// Build the device form of one Huffman table from a DHT payload
 /// (reference compute_huffman_table, src/reader.cpp:186-224).
-void build_huff_table(HuffTableDev& t, const uint8_t (&num_codes)[16], const uint8_t* huffval, int count, bool is_dc);
+void build_huff_table(
+    std::vector<uint8_t>& t, const uint8_t (&num_codes)[16], const uint8_t* huffval, int count, bool is_dc);
 
 } // namespace jg
 

@@ -54,7 +54,8 @@ struct HostSink {
 };
 
 struct St {
-    int p, n, cz, dc[kMaxComp];
+    int p, n, cz;
+    uint32_t dc01, dc23;
 };
 
 void emu_destuff(const uint8_t* bytes, const Scan& sc, int subseq_bytes, std::vector<uint8_t>& dst, std::vector<int>& seg_idx)
@@ -127,12 +128,14 @@ int emu_decode_scan(
     sp.mcus_per_segment = sc.mcus_per_segment;
     sp.total_mcus       = sc.mcus_x * sc.mcus_y;
     sp.subseq_words     = subseq_bytes / 4;
+    sp.tab_bytes        = static_cast<uint32_t>(sc.table_pack.size());
     int du              = 0;
     for (int a = 0; a < sc.num_comp; ++a) {
-        sp.dc_slot |= static_cast<uint32_t>(sc.comp[a].dc_id * 2) << (4 * a);
-        sp.ac_slot |= static_cast<uint32_t>(sc.comp[a].ac_id * 2 + 1) << (4 * a);
+        sp.dc_offs |= static_cast<uint64_t>(sc.dc_off[a]) << (16 * a);
+        sp.ac_offs |= static_cast<uint64_t>(sc.ac_off[a]) << (16 * a);
         for (int k = 0; k < sc.comp[a].h * sc.comp[a].v; ++k) sp.du_comp |= static_cast<uint32_t>(a) << (2 * du++);
     }
+    const uint8_t* tabs = sc.table_pack.data();
 
     const int S    = sc.num_subseq;
     const int T    = kSeqSubseq;
@@ -166,10 +169,10 @@ int emu_decode_scan(
             L.s.p              = rel * bits;
             L.end_bit          = (rel + 1) * bits;
             L.bw.seek(L.s.p, L.f);
-            decode_subsequence(L.s, L.bw, L.f, L.end_bit, sc.tables, sp, nosink);
+            decode_subsequence(L.s, L.bw, L.f, L.end_bit, tabs, sp, nosink);
             St& o = st[sub];
             o.p = L.s.p; o.n = L.s.n; o.cz = L.s.c | (L.s.z << 8);
-            for (int k = 0; k < kMaxComp; ++k) o.dc[k] = L.s.dc[k];
+            o.dc01 = L.s.dc01; o.dc23 = L.s.dc23;
             L.flowing = true;
         }
         for (int iter = 0; iter < T; ++iter) {
@@ -179,14 +182,14 @@ int emu_decode_scan(
                 const int j = t + 1 + iter;
                 if (L.flowing && j < L.lim) {
                     L.s.n = 0;
-                    for (int k = 0; k < kMaxComp; ++k) L.s.dc[k] = 0;
+                    L.s.dc01 = L.s.dc23 = 0;
                     L.end_bit += bits;
-                    decode_subsequence(L.s, L.bw, L.f, L.end_bit, sc.tables, sp, nosink);
+                    decode_subsequence(L.s, L.bw, L.f, L.end_bit, tabs, sp, nosink);
                     St& o        = st[first + j];
                     const int cz = L.s.c | (L.s.z << 8);
                     if (L.s.p == o.p && cz == o.cz) L.flowing = false;
                     o.p = L.s.p; o.n = L.s.n; o.cz = cz;
-                    for (int k = 0; k < kMaxComp; ++k) o.dc[k] = L.s.dc[k];
+                    o.dc01 = L.s.dc01; o.dc23 = L.s.dc23;
                 } else {
                     L.flowing = false;
                 }
@@ -226,14 +229,14 @@ int emu_decode_scan(
                 int& j  = jj[t];
                 if (L.flowing && j < L.lim) {
                     L.s.n = 0;
-                    for (int k = 0; k < kMaxComp; ++k) L.s.dc[k] = 0;
+                    L.s.dc01 = L.s.dc23 = 0;
                     L.end_bit += bits;
-                    decode_subsequence(L.s, L.bw, L.f, L.end_bit, sc.tables, sp, nosink);
+                    decode_subsequence(L.s, L.bw, L.f, L.end_bit, tabs, sp, nosink);
                     St& o        = st[j];
                     const int cz = L.s.c | (L.s.z << 8);
                     if (L.s.p == o.p && cz == o.cz) L.flowing = false;
                     o.p = L.s.p; o.n = L.s.n; o.cz = cz;
-                    for (int k = 0; k < kMaxComp; ++k) o.dc[k] = L.s.dc[k];
+                    o.dc01 = L.s.dc01; o.dc23 = L.s.dc23;
                     ++j;
                 } else {
                     L.flowing = false;
@@ -253,7 +256,8 @@ int emu_decode_scan(
         for (int t = 0; t < nsub; ++t) {
             if (first + t >= open_from) {
                 acc.n += st[first + t].n;
-                for (int k = 0; k < kMaxComp; ++k) acc.dc[k] += st[first + t].dc[k];
+                acc.dc01 = pk_add_u16(acc.dc01, st[first + t].dc01);
+                acc.dc23 = pk_add_u16(acc.dc23, st[first + t].dc23);
             }
         }
         tails[b] = acc;
@@ -268,7 +272,8 @@ int emu_decode_scan(
         if (seg0.subseq_offset < first) {
             for (int a = seg0.subseq_offset / T; a < b; ++a) {
                 carry.n += tails[a].n;
-                for (int k = 0; k < kMaxComp; ++k) carry.dc[k] += tails[a].dc[k];
+                carry.dc01 = pk_add_u16(carry.dc01, tails[a].dc01);
+                carry.dc23 = pk_add_u16(carry.dc23, tails[a].dc23);
             }
         }
         std::vector<St> ex(nsub + 1);
@@ -276,7 +281,8 @@ int emu_decode_scan(
         for (int t = 0; t < nsub; ++t) {
             ex[t] = run;
             run.n += st[first + t].n;
-            for (int k = 0; k < kMaxComp; ++k) run.dc[k] += st[first + t].dc[k];
+            run.dc01 = pk_add_u16(run.dc01, st[first + t].dc01);
+            run.dc23 = pk_add_u16(run.dc23, st[first + t].dc23);
         }
         for (int t = 0; t < nsub; ++t) {
             const int sub      = first + t;
@@ -288,7 +294,15 @@ int emu_decode_scan(
             HostSink sink;
             sink.out = coef;
             const int nprefix = ex[t].n - ex[ts].n + (carried ? carry.n : 0);
-            for (int k = 0; k < kMaxComp; ++k) sink.pred[k] = ex[t].dc[k] - ex[ts].dc[k] + (carried ? carry.dc[k] : 0);
+            {
+                const auto sub16 = [](uint32_t a, uint32_t b) { return pk_add_u16(a, pk_add_u16(~b, 0x00010001u)); };
+                const uint32_t p01 = pk_add_u16(sub16(ex[t].dc01, ex[ts].dc01), carried ? carry.dc01 : 0u);
+                const uint32_t p23 = pk_add_u16(sub16(ex[t].dc23, ex[ts].dc23), carried ? carry.dc23 : 0u);
+                sink.pred[0] = static_cast<int16_t>(p01 & 0xFFFF);
+                sink.pred[1] = static_cast<int16_t>(p01 >> 16);
+                sink.pred[2] = static_cast<int16_t>(p23 & 0xFFFF);
+                sink.pred[3] = static_cast<int16_t>(p23 >> 16);
+            }
             const int du_words = sp.du_per_mcu * 64;
             const int m0 = seg_i * sp.mcus_per_segment, m1 = std::min(m0 + sp.mcus_per_segment, sp.total_mcus);
             sink.pos   = m0 * du_words + nprefix;
@@ -302,7 +316,7 @@ int emu_decode_scan(
             HostFetch f{dst.data() + static_cast<size_t>(seg.subseq_offset) * subseq_bytes, seg.subseq_count * W};
             BitWindow<HostFetch> bw;
             bw.seek(ls.p, f);
-            decode_subsequence(ls, bw, f, (rel + 1) * bits, sc.tables, sp, sink);
+            decode_subsequence(ls, bw, f, (rel + 1) * bits, tabs, sp, sink);
         }
     }
 
@@ -312,8 +326,12 @@ int emu_decode_scan(
         if (st_p) st_p[i] = st[i].p;
         if (st_n) st_n[i] = st[i].n;
         if (st_cz) st_cz[i] = st[i].cz;
-        if (st_dc)
-            for (int k = 0; k < kMaxComp; ++k) st_dc[static_cast<size_t>(k) * S + i] = st[i].dc[k];
+        if (st_dc) { // unpacked (sign-extended 16-bit sums) for comparison with the oracle modulo 2^16
+            st_dc[0 * static_cast<size_t>(S) + i] = static_cast<int16_t>(st[i].dc01 & 0xFFFF);
+            st_dc[1 * static_cast<size_t>(S) + i] = static_cast<int16_t>(st[i].dc01 >> 16);
+            st_dc[2 * static_cast<size_t>(S) + i] = static_cast<int16_t>(st[i].dc23 & 0xFFFF);
+            st_dc[3 * static_cast<size_t>(S) + i] = static_cast<int16_t>(st[i].dc23 >> 16);
+        }
     }
     if (out_max_flow_iters) *out_max_flow_iters = max_iters;
     return JPEGGPU_SUCCESS;

@@ -73,9 +73,12 @@ def test_stage_parity(gpu_lib, torch_cuda, inputs, name, subseq_bytes):
         for nm, off, ref in (("p", sl.off_state_p, tw.p), ("n", sl.off_state_n, tw.n), ("cz", sl.off_state_cz, tw.cz)):
             got = _tmp_view(torch, tmp, base, off, S, torch.int32)
             assert np.array_equal(got[ok], ref[ok]), "state " + nm
+        # DC-difference sums are kept modulo 2^16, two scan components per 32-bit word
+        d01 = _tmp_view(torch, tmp, base, sl.off_state_dc01, S, torch.int32).view(np.uint32)
+        d23 = _tmp_view(torch, tmp, base, sl.off_state_dc23, S, torch.int32).view(np.uint32)
+        halves = [d01 & 0xFFFF, d01 >> 16, d23 & 0xFFFF, d23 >> 16]
         for k in range(sl.num_components):
-            got = _tmp_view(torch, tmp, base, sl.off_state_dc[k], S, torch.int32)
-            assert np.array_equal(got[ok], tw.dc[k][ok]), "state dc%d" % k
+            assert np.array_equal(halves[k][ok], tw.dc[k][ok].astype(np.uint32) & 0xFFFF), "state dc%d" % k
         coef = _tmp_view(torch, tmp, base, sl.off_coefficients, sl.num_data_units * 64, torch.int16)
         assert np.array_equal(coef.reshape(-1, 64), tw.stream_coef), "coefficients"
 
