@@ -1,0 +1,318 @@
+#!/usr/bin/env python3
+"""bench.py -- images/s of the baseline-JPEG decode hot path on MI355X (BASELINE.json metric).
+
+    python bench.py --gpus N --steps K --warmup W
+
+One "step" = one pass of the hot path (jpeggpu_decoder_decode: destuff -> Huffman sync/write -> IDCT)
+over one batch of 12 MP 4:2:0 restart-interval JPEGs per GPU (BASELINE.json configs[1]; with N > 1 it
+is configs[2]: images sharded by rank, no data-path collective unless --gather, weak scaling).
+Inputs (entropy-coded bytes + table blobs) are resident in HBM before the timed region starts.
+Rank 0 prints ONE JSON line; see DESIGN.md "Measurement" for the definition of every field.
+
+For N > 1 the driver launches this file with torch.distributed.run, one rank per GPU (RCCL).
+"""
+import argparse
+import json
+import os
+import statistics
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+# The HIP runtime multiplexes streams onto 4 hardware queues by default, which caps the number of
+# kernels in flight at 4 (profiles/r01_bench_kernel_stats_4queues.csv). One decode per stream needs more.
+os.environ.setdefault("GPU_MAX_HW_QUEUES", "16")
+
+HBM_PEAK_GBS = 8000.0  # /opt/skills/guides/MI355X_MICROARCH.md: HBM3E 8.0 TB/s (spec)
+
+
+def parse_args():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--batch", type=int, default=32, help="images per GPU per step")
+    ap.add_argument("--streams", type=int, default=16, help="HIP streams the batch is spread over")
+    ap.add_argument("--unique", type=int, default=2, help="distinct synthetic images per rank (seeded)")
+    ap.add_argument("--workload", default="cfg2", choices=["cfg2", "photo"])
+    ap.add_argument("--subseq-bytes", type=int, default=0, help="0 = library default")
+    ap.add_argument("--gather", action="store_true", help="RCCL gather of the decoded planes to rank 0 each step")
+    ap.add_argument("--latency-iters", type=int, default=50)
+    ap.add_argument("--cpu-seconds", type=float, default=12.0, help="budget of the CPU baseline sample")
+    ap.add_argument("--no-cpu", action="store_true")
+    return ap.parse_args()
+
+
+def make_images(args, rank, world):
+    """Synthetic 12 MP 4:2:0 JPEGs (DRI = one MCU row). Image i of the global batch has seed i mod
+    (unique * world) and is decoded by rank i mod world (jpeggpu_amd.shard), so a rank needs only the
+    `unique` seeds of its own shard."""
+    if args.workload == "photo":
+        with open(os.path.join(ROOT, "tests", "golden", "IMG_6510.JPG"), "rb") as f:
+            return [f.read()]
+    from jpeggpu_amd import shard
+    from tools import jpegsynth
+
+    seeds = shard.shard_indices(args.unique * world, rank, world)
+    return [jpegsynth.config(2, seed=s) for s in seeds]
+
+
+class Slot:
+    """One image in flight: its decoder, its temporary device memory and its output planes."""
+
+    def __init__(self, torch, jp, data, device, subseq_bytes, planes_flat=None, planes_off=0):
+        self.dec = jp.Decoder(subseq_bytes or None)
+        self.data = data
+        self.info = self.dec.parse_header(data)
+        self.tmp_size = self.dec.get_buffer_size()
+        self.tmp = torch.empty(self.tmp_size + 256, dtype=torch.uint8, device=device)
+        self.base = (self.tmp.data_ptr() + 255) // 256 * 256
+        nc = self.info.num_components
+        sizes = [(self.info.sizes_y[c], self.info.sizes_x[c]) for c in range(nc)]
+        self.plane_bytes = sum(h * w for h, w in sizes)
+        if planes_flat is None:
+            planes_flat = torch.empty(self.plane_bytes, dtype=torch.uint8, device=device)
+            planes_off = 0
+        self.planes, o = [], planes_off
+        for h, w in sizes:
+            self.planes.append(planes_flat[o:o + h * w].view(h, w))
+            o += h * w
+        self.ptrs = [p.data_ptr() for p in self.planes]
+        self.pitches = [p.stride(0) for p in self.planes]
+        self.layout = self.dec.layout()
+
+    def transfer(self, stream):
+        self.dec.transfer(self.base, self.tmp_size, stream)
+
+    def decode(self, stream):
+        self.dec.decode(self.ptrs, self.pitches, self.base, self.tmp_size, stream)
+
+
+def algorithmic_bytes(slot):
+    """destuff+Huffman pass B_dh = stuffed scan bytes + 128 B per data unit;
+    end-to-end B_e2e = stuffed scan bytes + plane bytes. Plus the dominant kernel's own bytes."""
+    lay = slot.layout
+    stuffed = lay.transferred_bytes
+    ndu = sum(lay.scans[s].num_data_units for s in range(lay.num_scans))
+    nsub = sum(lay.scans[s].num_subsequences for s in range(lay.num_scans))
+    return {
+        "stuffed": stuffed,
+        "b_dh": stuffed + 128 * ndu,
+        "b_e2e": stuffed + slot.plane_bytes,
+        # sync_intra: destuffed bytes read once + subsequence->segment map read + 20 B of state written
+        "sync_intra": nsub * lay.subsequence_bytes + nsub * 4 + nsub * 20,
+        # write pass: destuffed bytes + state read, coefficient buffer written (128 B per data unit)
+        "write": nsub * lay.subsequence_bytes + nsub * 24 + 128 * ndu,
+        "idct": 128 * ndu + slot.plane_bytes,
+    }
+
+
+def cpu_baseline(args, data):
+    """The oracle (scalar C port of the reference's arithmetic) timed on the host, bounded sample."""
+    from oracle import oracle
+
+    oracle.decode(data)  # warm (page in the library)
+    n, t0 = 0, time.perf_counter()
+    while True:
+        oracle.decode(data)
+        n += 1
+        dt = time.perf_counter() - t0
+        if dt >= args.cpu_seconds or n >= 64:
+            break
+    out = {"value": n / dt, "unit": "images/s", "cores": 1, "kind": "port",
+           "sample": "%d sequential decodes of one 12 MP image by oracle/jpeg_oracle.c, %.1f s" % (n, dt)}
+    # libjpeg-turbo through Pillow, planes only (draft YCbCr, no colour conversion) when available
+    try:
+        import io
+
+        from PIL import Image, features
+
+        ver = features.version_feature("libjpeg_turbo")
+        if ver:
+            m, t1 = 0, time.perf_counter()
+            while time.perf_counter() - t1 < min(4.0, args.cpu_seconds) and m < 64:
+                im = Image.open(io.BytesIO(data))
+                im.draft("YCbCr", im.size)
+                im.load()
+                m += 1
+            out["libjpeg_turbo"] = {"value": m / (time.perf_counter() - t1), "unit": "images/s", "cores": 1,
+                                    "version": ver, "sample": "%d Pillow decodes (YCbCr, incl. chroma upsampling)" % m}
+    except Exception:  # Pillow is optional on the box
+        pass
+    return out
+
+
+def main():
+    args = parse_args()
+    import torch
+    import torch.distributed as dist
+
+    import jpeggpu_amd as jp
+    from jpeggpu_amd import shard
+
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    if world != args.gpus:
+        if world == 1 and args.gpus > 1:
+            raise SystemExit("bench.py --gpus %d must be launched with torch.distributed.run" % args.gpus)
+        args.gpus = world
+    assert torch.cuda.is_available(), "bench.py needs a HIP device (there is no CPU fallback)"
+    torch.cuda.set_device(local_rank)
+    device = torch.device("cuda", local_rank)
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", device_id=device)
+
+    images = make_images(args, rank, world)
+    nstreams = max(1, min(args.streams, args.batch))
+    streams = [torch.cuda.Stream(device=device) for _ in range(nstreams)]
+
+    # all planes of the rank's batch live in one flat tensor so that a gather is one collective
+    probe = Slot(torch, jp, images[0], device, args.subseq_bytes)
+    per_image = probe.plane_bytes
+    planes_flat = torch.empty(per_image * args.batch, dtype=torch.uint8, device=device)
+    slots = [Slot(torch, jp, images[i % len(images)], device, args.subseq_bytes, planes_flat, i * per_image)
+             for i in range(args.batch)]
+    probe.dec.cleanup()
+    del probe
+    for i, s in enumerate(slots):
+        s.transfer(streams[i % nstreams].cuda_stream)
+    torch.cuda.synchronize()
+    gather_list = None
+    if world > 1 and args.gather and rank == 0:
+        gather_list = [torch.empty_like(planes_flat) for _ in range(world)]
+
+    slots[0].dec.set_profiling(True)
+    stage_acc, stage_n = {}, 0
+
+    def step(collect=False):
+        nonlocal stage_acc, stage_n
+        for i, s in enumerate(slots):
+            s.decode(streams[i % nstreams].cuda_stream)
+        if world > 1 and args.gather:
+            for st in streams:
+                torch.cuda.current_stream().wait_stream(st)
+            shard.gather_planes(planes_flat, rank, world, dst=0, gather_list=gather_list)
+        if collect:
+            streams[0].synchronize()
+            ms = slots[0].dec.stage_ms()
+            stage_acc = {k: stage_acc.get(k, 0.0) + v for k, v in ms.items()}
+            stage_n += 1
+
+    def barrier():
+        if world > 1:
+            dist.barrier()
+
+    for _ in range(args.warmup):
+        step()
+    torch.cuda.synchronize()
+    barrier()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        step(collect=True)
+    torch.cuda.synchronize()
+    barrier()
+    torch.cuda.synchronize()
+    elapsed = time.perf_counter() - t0
+    if world > 1:
+        t = torch.tensor([elapsed], dtype=torch.float64, device=device)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+
+    ms_per_step = elapsed / args.steps * 1e3
+    value = world * args.batch * args.steps / elapsed
+    stage_us = {k: v / max(stage_n, 1) * 1e3 for k, v in stage_acc.items()}
+    ab = algorithmic_bytes(slots[0])
+
+    out = None
+    if rank == 0:
+        # single-image latency under the reference's protocol (benchmark/benchmark_jpeggpu.hpp:69-108):
+        # parse_header + get_buffer_size + transfer + decode + stream sync, wall clock, pinned input
+        s0 = slots[0]
+        pinned = torch.empty(len(s0.data), dtype=torch.uint8).pin_memory()
+        pinned.numpy()[:] = memoryview(s0.data)
+        host_ptr, host_n = pinned.data_ptr(), pinned.numel()
+        s0.dec.set_profiling(False)
+        lat = []
+        st = streams[0]
+        for it in range(args.latency_iters + 3):
+            t1 = time.perf_counter()
+            s0.dec.parse_header(host_ptr, host_n)
+            n = s0.dec.get_buffer_size()
+            s0.dec.transfer(s0.base, n, st.cuda_stream)
+            s0.dec.decode(s0.ptrs, s0.pitches, s0.base, n, st.cuda_stream)
+            st.synchronize()
+            if it >= 3:
+                lat.append((time.perf_counter() - t1) * 1e3)
+        # device-only latency of one decode, nothing else running
+        s0.dec.set_profiling(True)
+        solo = {}
+        for _ in range(10):
+            s0.decode(st.cuda_stream)
+            st.synchronize()
+            ms = s0.dec.stage_ms()
+            solo = {k: solo.get(k, 0.0) + v * 100 for k, v in ms.items()}  # us, averaged over 10
+
+        dom = max(stage_us, key=stage_us.get)
+        dom_key = {"sync_intra": "sync_intra", "write": "write", "idct": "idct"}.get(dom)
+        dom_bytes = ab.get(dom_key) if dom_key else None
+        t_pass_us = sum(stage_us[k] for k in ("memset", "destuff", "sync_intra", "sync_inter", "tails", "write"))
+        roofline = {
+            "bound": "hbm", "kernel": "huff_" + dom if dom.startswith("sync") or dom == "write" else dom,
+            "achieved": (dom_bytes / (stage_us[dom] * 1e-6) / 1e9) if dom_bytes and stage_us[dom] > 0 else None,
+            "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": None, "traffic": None,
+            "algorithmic_bytes_per_launch": dom_bytes, "avg_launch_us": stage_us[dom],
+        }
+        if roofline["achieved"] is not None:
+            roofline["frac"] = roofline["achieved"] / HBM_PEAK_GBS
+        pmc = os.path.join(ROOT, "profiles", "pmc_traffic.json")
+        if os.path.exists(pmc):  # HBM bytes per launch from separate rocprofv3 --pmc passes (profiles/)
+            try:
+                with open(pmc) as f:
+                    roofline["traffic"] = json.load(f).get(roofline["kernel"])
+            except Exception:
+                pass
+        out = {
+            "metric": "images/s (12 MP 4:2:0 baseline JPEG decode, inputs resident in HBM)",
+            "value": value, "unit": "images/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": ms_per_step, "higher_is_better": True, "scaling": "weak",
+            "vs_baseline": None,  # BASELINE.md holds no published number for this metric on this hardware
+            "dtype": "int16/int32 fixed point, u8 out", "data": "synthetic",
+            "config": {"workload": "cfg2: 4032x3024 4:2:0 interleaved baseline JPEG, DRI=252 (one MCU row), "
+                                   "%d seeded images per rank" % len(images) if args.workload == "cfg2"
+                       else "cfg1 bytes: tests/golden/IMG_6510.JPG (the reference's 12 MP photo)",
+                       "images_per_gpu_per_step": args.batch, "streams": nstreams,
+                       "subsequence_bytes": slots[0].layout.subsequence_bytes,
+                       "stuffed_scan_bytes": ab["stuffed"], "gather": bool(args.gather and world > 1),
+                       "parallelism": "image-sharded x%d" % world},
+            "roofline": roofline,
+            "roofline_pass": {
+                "what": "destuff+Huffman pass (memset, destuff, sync_intra, sync_inter, tails, write), "
+                        "B_dh = stuffed scan bytes + 128 B per data unit (SURVEY.md 8d)",
+                "bytes_per_image": ab["b_dh"], "sum_kernel_us_under_load": t_pass_us,
+                "throughput_GBs": ab["b_dh"] * value / world / 1e9,
+                "frac_of_hbm_peak": ab["b_dh"] * value / world / 1e9 / HBM_PEAK_GBS},
+            "roofline_e2e": {"bytes_per_image": ab["b_e2e"], "throughput_GBs": ab["b_e2e"] * value / world / 1e9,
+                             "frac_of_hbm_peak": ab["b_e2e"] * value / world / 1e9 / HBM_PEAK_GBS},
+            "stage_us_under_load": stage_us, "stage_us_solo": solo,
+            "latency_ms": {"protocol": "parse+size+transfer+decode+sync, 1 image, 1 stream, pinned input",
+                           "p50": statistics.median(lat), "mean": statistics.fmean(lat), "max": max(lat),
+                           "iters": len(lat), "images_per_s_single_stream": 1e3 / statistics.fmean(lat)},
+        }
+        if not args.no_cpu:
+            out["cpu_baseline"] = cpu_baseline(args, slots[0].data)
+    for s in slots:
+        s.dec.cleanup()
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+    if rank == 0:
+        print(json.dumps(out))
+
+
+if __name__ == "__main__":
+    main()

@@ -1,0 +1,33 @@
+"""Host emulation of the device pipeline's logic (tests/emu) against the oracle's stage twins:
+the subsequence-parallel algorithm, the host-built tables and work lists, without a GPU."""
+import numpy as np
+import pytest
+
+from oracle import oracle
+from tests import cases
+from tests.emu import emu
+
+
+@pytest.mark.parametrize("subseq_bytes", [128, 64, 32])
+def test_emulated_pipeline_equals_sequential_decode(subseq_bytes):
+    for name, data in cases.matrix().items():
+        nscans = oracle.decode(data).nscans
+        for s in range(nscans):
+            rc, r = emu.decode_scan(data, s, subseq_bytes)
+            assert rc == 0, name
+            tw = oracle.scan_stages(data, s, subseq_bytes)
+            assert np.array_equal(r.destuffed, tw.destuffed), (name, "destuffed bytes")
+            assert np.array_equal(r.seg_index, tw.seg_index), (name, "segment index")
+            ok = tw.p >= 0
+            assert np.array_equal(r.p[ok], tw.p[ok]) and np.array_equal(r.n[ok], tw.n[ok]), (name, "p / n")
+            assert np.array_equal(r.cz[ok], tw.cz[ok]), (name, "c, z")
+            for k in range(4):
+                assert np.array_equal(r.dc[k][ok].astype(np.int16), tw.dc[k][ok].astype(np.int16)), (name, "dc sums")
+            assert np.array_equal(r.coef, tw.stream_coef), (name, "coefficients")
+
+
+def test_emulated_photo(photo_bytes):
+    rc, r = emu.decode_scan(photo_bytes, 0, 128)
+    tw = oracle.scan_stages(photo_bytes, 0, 128)
+    assert rc == 0 and np.array_equal(r.coef, tw.stream_coef)
+    assert r.max_flow_iters >= 1

@@ -1,0 +1,157 @@
+"""GPU-side API contract, the additive upsample kernel, and the full-size BASELINE configurations."""
+import threading
+
+import numpy as np
+import pytest
+
+from tests import cases
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def torch_cuda(gpu_lib):
+    import torch
+
+    assert torch.cuda.is_available(), "GPU tests need a HIP device"
+    return torch
+
+
+def _alloc(torch, dec, info, pitch_extra=0):
+    n = dec.get_buffer_size()
+    tmp = torch.empty(n + 256, dtype=torch.uint8, device="cuda:0")
+    base = (tmp.data_ptr() + 255) // 256 * 256
+    planes = [torch.full((info.sizes_y[c], info.sizes_x[c] + pitch_extra), 0xAB, dtype=torch.uint8, device="cuda:0")
+              for c in range(info.num_components)]
+    return n, tmp, base, planes
+
+
+def test_pitch_and_argument_checks(torch_cuda):
+    import jpeggpu_amd
+    from jpeggpu_amd import Status
+    from oracle import oracle
+
+    torch = torch_cuda
+    data = cases.matrix()["odd_partial_mcu"]
+    ref = oracle.decode(data)
+    dec = jpeggpu_amd.Decoder()
+    info = dec.parse_header(data)
+    n, tmp, base, planes = _alloc(torch, dec, info, pitch_extra=13)  # unaligned pitch: byte-store path
+    dec.transfer(base, n, 0)
+    dec.decode([p.data_ptr() for p in planes], [p.stride(0) for p in planes], base, n, 0)
+    torch.cuda.synchronize()
+    for c in range(ref.ncomp):
+        got = planes[c].cpu().numpy()
+        assert np.array_equal(got[:, :info.sizes_x[c]], ref.planes[c])
+        assert (got[:, info.sizes_x[c]:] == 0xAB).all(), "wrote outside the visible plane"
+    # pitch smaller than the width, null plane, unaligned / too small tmp (reference decoder.cpp:345-348)
+    ptrs, pitches = [p.data_ptr() for p in planes], [p.stride(0) for p in planes]
+    for bad_ptrs, bad_pitches, bad_base, bad_n, want in (
+            (ptrs, [info.sizes_x[0] - 1] + pitches[1:], base, n, Status.INVALID_ARGUMENT),
+            ([0] + ptrs[1:], pitches, base, n, Status.INVALID_ARGUMENT),
+            (ptrs, pitches, base + 8, n, Status.INVALID_ARGUMENT),
+            (ptrs, pitches, base, n - 256, Status.INTERNAL_ERROR)):
+        with pytest.raises(jpeggpu_amd.JpegGpuError) as ei:
+            dec.decode(bad_ptrs, bad_pitches, bad_base, bad_n, 0)
+        assert ei.value.status == want
+    with pytest.raises(jpeggpu_amd.JpegGpuError) as ei:
+        dec.transfer(base, n - 256, 0)
+    assert ei.value.status == Status.INTERNAL_ERROR
+    dec.cleanup()
+
+
+def test_decoder_reuse_across_geometries_and_streams(torch_cuda):
+    import jpeggpu_amd
+    from oracle import oracle
+
+    torch = torch_cuda
+    m = cases.matrix()
+    dec = jpeggpu_amd.Decoder()
+    stream = torch.cuda.Stream()
+    for name in ("ss_2x2", "four_comp_opt", "gray", "ni_420_dri", "ss_2x2"):
+        ref = oracle.decode(m[name])
+        info = dec.parse_header(m[name])
+        n, tmp, base, planes = _alloc(torch, dec, info)
+        dec.transfer(base, n, stream.cuda_stream)
+        dec.decode([p.data_ptr() for p in planes], [p.stride(0) for p in planes], base, n, stream.cuda_stream)
+        stream.synchronize()
+        for c in range(ref.ncomp):
+            assert np.array_equal(planes[c].cpu().numpy(), ref.planes[c]), name
+    dec.cleanup()
+
+
+def test_two_decoders_on_two_host_threads(torch_cuda):
+    import jpeggpu_amd
+    from oracle import oracle
+
+    torch = torch_cuda
+    m = cases.matrix()
+    names = ["multi_seq_dri", "multi_seq_nodri"]
+    errors = []
+
+    def work(name):
+        try:
+            ref = oracle.decode(m[name])
+            st = torch.cuda.Stream()
+            with torch.cuda.stream(st):
+                for _ in range(5):
+                    planes, _ = jpeggpu_amd.decode_to_planes(m[name])
+                    for c in range(ref.ncomp):
+                        if not np.array_equal(planes[c].cpu().numpy(), ref.planes[c]):
+                            errors.append((name, c))
+        except Exception as e:  # pragma: no cover
+            errors.append((name, repr(e)))
+
+    ts = [threading.Thread(target=work, args=(n,)) for n in names]
+    [t.start() for t in ts]
+    [t.join() for t in ts]
+    assert not errors, errors
+
+
+def test_upsample_planes(torch_cuda):
+    """Additive chroma-replication kernel vs the integer part of the reference's host helper
+    (util/util.h:62-91): dst[y][x] = src[y * sy / sy_max][x * sx / sx_max]."""
+    import ctypes as C
+
+    import jpeggpu_amd
+    from jpeggpu_amd.api import Img, lib
+
+    torch = torch_cuda
+    for name in ("ss_2x2", "ss_4x1", "ss_1x2", "odd_partial_mcu"):
+        data = cases.matrix()[name]
+        planes, info = jpeggpu_amd.decode_to_planes(data)
+        W, H = info.sizes_x[0] * max(info.subsampling.x[:3]) // info.subsampling.x[0], 0
+        sxm, sym = max(info.subsampling.x[:3]), max(info.subsampling.y[:3])
+        W, H = info.sizes_x[[i for i in range(3) if info.subsampling.x[i] == sxm][0]], \
+            info.sizes_y[[i for i in range(3) if info.subsampling.y[i] == sym][0]]
+        src, dst = Img(), Img()
+        outs = []
+        for c in range(3):
+            src.image[c], src.pitch[c] = planes[c].data_ptr(), planes[c].stride(0)
+            o = torch.zeros((H, W + 3), dtype=torch.uint8, device="cuda:0")
+            outs.append(o)
+            dst.image[c], dst.pitch[c] = o.data_ptr(), o.stride(0)
+        rc = lib().jpeggpu_ext_upsample_planes(C.byref(info), C.byref(src), C.byref(dst), W, H, None)
+        assert rc == 0
+        torch.cuda.synchronize()
+        for c in range(3):
+            p = planes[c].cpu().numpy()
+            ys = np.minimum(np.arange(H) * info.subsampling.y[c] // sym, p.shape[0] - 1)
+            xs = np.minimum(np.arange(W) * info.subsampling.x[c] // sxm, p.shape[1] - 1)
+            assert np.array_equal(outs[c].cpu().numpy()[:, :W], p[ys][:, xs]), (name, c)
+
+
+@pytest.mark.parametrize("cfg", [2, 4, 5])
+def test_baseline_configs_full_size(torch_cuda, cfg):
+    """BASELINE.json configs 2, 4 (39 MP, three non-interleaved scans) and 5 (4 components, 4+4
+    tables, no restart markers) at full size, bit-exact against the oracle."""
+    import jpeggpu_amd
+    from oracle import oracle
+    from tools import jpegsynth
+
+    data = jpegsynth.config(cfg, seed=5)
+    ref = oracle.decode(data)
+    planes, info = jpeggpu_amd.decode_to_planes(data)
+    assert info.num_components == ref.ncomp
+    for c in range(ref.ncomp):
+        assert np.array_equal(planes[c].cpu().numpy(), ref.planes[c]), (cfg, c)

@@ -1,0 +1,189 @@
+"""Host side of the C ABI without a GPU: the library loads, exports every symbol the headers declare,
+parses like the oracle, sizes its buffers, and fails loudly where a device is needed."""
+import ctypes as C
+import os
+import re
+
+import numpy as np
+import pytest
+
+import jpeggpu_amd
+from jpeggpu_amd import Status
+from jpeggpu_amd import build as jbuild
+from oracle import oracle
+from tests import cases
+from tests.conftest import ROOT
+
+
+@pytest.fixture(scope="module")
+def L():
+    jbuild.build()
+    return jpeggpu_amd.lib()
+
+
+def test_exports_every_declared_symbol(L):
+    declared = set()
+    for h in ("jpeggpu.h", "jpeggpu_ext.h"):
+        text = open(os.path.join(ROOT, "include", "jpeggpu", h)).read()
+        text = re.sub(r"/\*.*?\*/", "", text, flags=re.S)
+        declared |= set(re.findall(r"\b(jpeggpu_[a-z_0-9]+|is_css_444)\s*\(", text))
+    assert {"jpeggpu_decoder_startup", "jpeggpu_decoder_parse_header", "jpeggpu_decoder_get_buffer_size",
+            "jpeggpu_decoder_transfer", "jpeggpu_decoder_decode", "jpeggpu_decoder_cleanup",
+            "jpeggpu_set_logging", "jpeggpu_get_status_string", "is_css_444"} <= declared
+    for name in sorted(declared):
+        assert hasattr(L, name), "library does not export " + name
+
+
+def test_status_strings(L):
+    # same strings as the reference (src/jpeggpu.cpp:41-60)
+    want = ["success", "invalid argument", "invalid jpeg", "internal jpeggpu error", "jpeg is not supported",
+            "out of host memory", "incomplete bitstream"]
+    assert [jpeggpu_amd.status_string(i) for i in range(7)] == want
+    assert jpeggpu_amd.status_string(99) == "unknown status"
+
+
+def test_null_arguments(L):
+    dec = C.c_void_p()
+    assert L.jpeggpu_decoder_startup(None) == Status.INVALID_ARGUMENT
+    assert L.jpeggpu_decoder_startup(C.byref(dec)) == Status.SUCCESS
+    info = jpeggpu_amd.ImgInfo()
+    n = C.c_size_t()
+    assert L.jpeggpu_set_logging(None, 1) == Status.INVALID_ARGUMENT
+    assert L.jpeggpu_decoder_parse_header(None, C.byref(info), b"x", 1) == Status.INVALID_ARGUMENT
+    assert L.jpeggpu_decoder_parse_header(dec, None, b"x", 1) == Status.INVALID_ARGUMENT
+    assert L.jpeggpu_decoder_parse_header(dec, C.byref(info), None, 0) == Status.INVALID_ARGUMENT
+    assert L.jpeggpu_decoder_get_buffer_size(dec, None) == Status.INVALID_ARGUMENT
+    assert L.jpeggpu_decoder_get_buffer_size(None, C.byref(n)) == Status.INVALID_ARGUMENT
+    assert L.jpeggpu_decoder_get_buffer_size(dec, C.byref(n)) == Status.INVALID_ARGUMENT  # nothing parsed yet
+    assert L.jpeggpu_decoder_transfer(None, None, 0, None) == Status.INVALID_ARGUMENT
+    assert L.jpeggpu_decoder_decode(None, None, None, 0, None) == Status.INVALID_ARGUMENT
+    assert L.jpeggpu_decoder_decode(dec, None, None, 0, None) == Status.INVALID_ARGUMENT
+    assert L.jpeggpu_decoder_cleanup(None) == Status.INVALID_ARGUMENT
+    assert L.jpeggpu_decoder_cleanup(dec) == Status.SUCCESS
+
+
+def test_is_css_444(L):
+    s = jpeggpu_amd.api.Subsampling()
+    for c in range(3):
+        s.x[c] = s.y[c] = 1
+    assert L.is_css_444(s, 3) == 1 and L.is_css_444(s, 1) == 1
+    s.x[0] = 2
+    assert L.is_css_444(s, 3) == 0
+    assert L.is_css_444(s, 0) == 0 and L.is_css_444(s, 5) == 0
+
+
+def test_parse_matches_oracle_geometry(L):
+    for name, data in cases.matrix().items():
+        ref = oracle.decode(data)
+        dec = jpeggpu_amd.Decoder()
+        info = dec.parse_header(data)
+        assert info.num_components == ref.ncomp, name
+        for c in range(ref.ncomp):
+            assert (info.sizes_y[c], info.sizes_x[c]) == ref.planes[c].shape, name
+            assert (info.subsampling.x[c], info.subsampling.y[c]) == (ref.hs[c], ref.vs[c]), name
+        for c in range(ref.ncomp, 4):
+            assert info.sizes_x[c] == info.sizes_y[c] == 0
+        dec.cleanup()
+
+
+@pytest.mark.parametrize("subseq_bytes", [128, 64, 32])
+def test_layout_matches_oracle_segment_walk(L, photo_bytes, subseq_bytes):
+    """The host walk of the entropy-coded bytes (reference src/reader.cpp:447-489) against the oracle's."""
+    inputs = dict(cases.matrix())
+    inputs["photo"] = photo_bytes
+    for name, data in inputs.items():
+        dec = jpeggpu_amd.Decoder(subseq_bytes)
+        dec.parse_header(data)
+        lay = dec.layout()
+        assert lay.subsequence_bytes == subseq_bytes
+        for s in range(lay.num_scans):
+            li = oracle.scan_info(data, s, subseq_bytes)
+            sl = lay.scans[s]
+            assert (sl.num_subsequences, sl.num_segments, sl.num_data_units) == (li.num_subseq, li.num_segments, li.num_du), name
+            assert sl.num_sequences == (li.num_subseq + 255) // 256
+        assert dec.get_buffer_size() % 256 == 0
+        dec.cleanup()
+
+
+def test_photo_buffer_is_smaller_than_the_references(L, photo_bytes):
+    dec = jpeggpu_amd.Decoder(128)
+    dec.parse_header(photo_bytes)
+    lay = dec.layout()
+    assert lay.scans[0].num_sequences == 89                 # README.md:37
+    assert lay.transferred_bytes < 2_907_282 + 64           # scan bytes only, not the 4 MB file (B-7)
+    assert dec.get_buffer_size() < 50 * 2 ** 20             # the reference needs ~116 MB
+    dec.cleanup()
+
+
+def test_negative_inputs_same_status_as_oracle(L):
+    from tools import jpegsynth
+
+    good = bytearray(jpegsynth.encode(64, 48, seed=3))
+
+    def both(data):
+        dec = jpeggpu_amd.Decoder()
+        try:
+            dec.parse_header(bytes(data))
+            got = 0
+        except jpeggpu_amd.JpegGpuError as e:
+            got = int(e.status)
+        finally:
+            dec.cleanup()
+        try:
+            oracle.decode(bytes(data))
+            want = 0
+        except oracle.OracleError as e:
+            want = e.status
+        return got, want
+
+    variants = {"good": good, "empty": b"\xff", "soi_only": b"\xff\xd8", "truncated": good[:len(good) // 2]}
+    i = good.find(b"\xff\xc0")
+    v = bytearray(good); v[i + 1] = 0xC2; variants["progressive"] = v
+    v = bytearray(good); v[i + 4] = 12; variants["12bit"] = v
+    v = bytearray(good); v[i + 9] = 5; variants["too_many_components"] = v
+    v = bytearray(good); v[i + 11] = 0x51; variants["bad_sampling"] = v
+    j = good.find(b"\xff\xdb")
+    v = bytearray(good); v[j + 4] |= 0x10; variants["dqt16"] = v
+    k = good.find(b"\xff\xc4")
+    v = bytearray(good); v[k + 1] = 0xE5; variants["missing_dht"] = v
+    m = good.find(b"\xff\xda")
+    v = bytearray(good); v[m + 6] = 0x33; variants["undefined_table_id"] = v
+    v = bytearray(good); v[m + 5] = 9; variants["unknown_component"] = v
+    for name, data in variants.items():
+        got, want = both(data)
+        assert got == want, (name, got, want)
+    assert both(variants["progressive"])[0] == Status.NOT_SUPPORTED
+    assert both(variants["truncated"])[0] == Status.INVALID_JPEG
+
+
+def test_decoder_reuse_and_subsequence_knob(L):
+    m = cases.matrix()
+    dec = jpeggpu_amd.Decoder()
+    sizes = []
+    for name in ("ss_2x2", "gray", "four_comp_opt", "ss_2x2"):
+        dec.parse_header(m[name])
+        sizes.append(dec.get_buffer_size())
+    assert sizes[0] == sizes[3]
+    with pytest.raises(jpeggpu_amd.JpegGpuError):
+        dec.set_subsequence_bytes(48)
+    dec.set_subsequence_bytes(32)
+    with pytest.raises(jpeggpu_amd.JpegGpuError):
+        dec.get_buffer_size()  # the knob invalidates the parsed image
+    dec.cleanup()
+
+
+def test_fails_loudly_without_a_device(L):
+    """No CPU fallback: without a HIP device transfer/decode return an error, never fake planes."""
+    import torch
+
+    if torch.cuda.is_available():
+        pytest.skip("a device is present")
+    dec = jpeggpu_amd.Decoder()
+    dec.parse_header(cases.matrix()["ss_2x2"])
+    n = dec.get_buffer_size()
+    buf = np.zeros(n + 256, np.uint8)
+    base = (buf.ctypes.data + 255) // 256 * 256
+    with pytest.raises(jpeggpu_amd.JpegGpuError) as ei:
+        dec.transfer(base, n, 0)
+    assert ei.value.status == Status.INTERNAL_ERROR
+    dec.cleanup()
