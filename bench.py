@@ -3,7 +3,8 @@
 
     python bench.py --gpus N --steps K --warmup W
 
-One "step" = one pass of the hot path (jpeggpu_decoder_decode: destuff -> Huffman sync/write -> IDCT)
+One "step" = one pass of the hot path (destuff -> Huffman sync/write -> IDCT, through
+jpeggpu_ext_decode_batch by default or the drop-in jpeggpu_decoder_decode with --mode streams)
 over one batch of 12 MP 4:2:0 restart-interval JPEGs per GPU (BASELINE.json configs[1]; with N > 1 it
 is configs[2]: images sharded by rank, no data-path collective unless --gather, weak scaling).
 Inputs (entropy-coded bytes + table blobs) are resident in HBM before the timed region starts.
@@ -33,8 +34,12 @@ def parse_args():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=3)
-    ap.add_argument("--batch", type=int, default=32, help="images per GPU per step")
-    ap.add_argument("--streams", type=int, default=16, help="HIP streams the batch is spread over")
+    ap.add_argument("--batch", type=int, default=64, help="images per GPU per step")
+    ap.add_argument("--mode", default="batch", choices=["batch", "streams"],
+                    help="batch: jpeggpu_ext_decode_batch, one launch per stage per group of images; "
+                         "streams: the drop-in jpeggpu_decoder_decode, one image per call")
+    ap.add_argument("--streams", type=int, default=0,
+                    help="HIP streams (batch mode: groups of images, default 2; streams mode: default 16)")
     ap.add_argument("--unique", type=int, default=2, help="distinct synthetic images per rank (seeded)")
     ap.add_argument("--workload", default="cfg2", choices=["cfg2", "photo"])
     ap.add_argument("--subseq-bytes", type=int, default=0, help="0 = library default")
@@ -167,6 +172,8 @@ def main():
         dist.init_process_group("nccl", device_id=device)
 
     images = make_images(args, rank, world)
+    if args.streams <= 0:
+        args.streams = 2 if args.mode == "batch" else 16
     nstreams = max(1, min(args.streams, args.batch))
     streams = [torch.cuda.Stream(device=device) for _ in range(nstreams)]
 
@@ -185,22 +192,32 @@ def main():
     if world > 1 and args.gather and rank == 0:
         gather_list = [torch.empty_like(planes_flat) for _ in range(world)]
 
-    slots[0].dec.set_profiling(True)
-    stage_acc, stage_n = {}, 0
+    # batch mode: the rank's images are split into `nstreams` groups, each group is one
+    # jpeggpu_ext_decode_batch call (7 launches) on its own stream
+    groups = []
+    if args.mode == "batch":
+        for g in range(nstreams):
+            mine = slots[g::nstreams]
+            nscans = sum(s.layout.num_scans for s in mine)
+            bt = jp.Batch(nscans)
+            scratch = torch.empty(bt.scratch_size, dtype=torch.uint8, device=device)
+            bt.set_items([(s.dec, s.ptrs, s.pitches, s.base, s.tmp_size) for s in mine])
+            groups.append((bt, scratch, streams[g], len(mine)))
+        groups[0][0].set_profiling(True)
+    else:
+        slots[0].dec.set_profiling(True)
 
-    def step(collect=False):
-        nonlocal stage_acc, stage_n
-        for i, s in enumerate(slots):
-            s.decode(streams[i % nstreams].cuda_stream)
+    def step():
+        if args.mode == "batch":
+            for bt, scratch, st, _ in groups:
+                bt.decode(scratch.data_ptr(), st.cuda_stream)
+        else:
+            for i, s in enumerate(slots):
+                s.decode(streams[i % nstreams].cuda_stream)
         if world > 1 and args.gather:
             for st in streams:
                 torch.cuda.current_stream().wait_stream(st)
             shard.gather_planes(planes_flat, rank, world, dst=0, gather_list=gather_list)
-        if collect:
-            streams[0].synchronize()
-            ms = slots[0].dec.stage_ms()
-            stage_acc = {k: stage_acc.get(k, 0.0) + v for k, v in ms.items()}
-            stage_n += 1
 
     def barrier():
         if world > 1:
@@ -209,11 +226,13 @@ def main():
     for _ in range(args.warmup):
         step()
     torch.cuda.synchronize()
+    profiled = groups[0][0] if args.mode == "batch" else slots[0].dec
+    profiled.stage_ms()  # drop the warm-up samples, open the measurement window of the timed region
     barrier()
     torch.cuda.synchronize()
     t0 = time.perf_counter()
     for _ in range(args.steps):
-        step(collect=True)
+        step()
     torch.cuda.synchronize()
     barrier()
     torch.cuda.synchronize()
@@ -225,7 +244,10 @@ def main():
 
     ms_per_step = elapsed / args.steps * 1e3
     value = world * args.batch * args.steps / elapsed
-    stage_us = {k: v / max(stage_n, 1) * 1e3 for k, v in stage_acc.items()}
+    # mean duration per stage over the timed region (HIP events on the launch stream); in batch mode
+    # one launch covers `images_per_launch` images
+    stage_us = {k: v * 1e3 for k, v in profiled.stage_ms().items()}
+    images_per_launch = groups[0][3] if args.mode == "batch" else 1
     ab = algorithmic_bytes(slots[0])
 
     out = None
@@ -236,7 +258,6 @@ def main():
         pinned = torch.empty(len(s0.data), dtype=torch.uint8).pin_memory()
         pinned.numpy()[:] = memoryview(s0.data)
         host_ptr, host_n = pinned.data_ptr(), pinned.numel()
-        s0.dec.set_profiling(False)
         lat = []
         st = streams[0]
         for it in range(args.latency_iters + 3):
@@ -250,22 +271,21 @@ def main():
                 lat.append((time.perf_counter() - t1) * 1e3)
         # device-only latency of one decode, nothing else running
         s0.dec.set_profiling(True)
-        solo = {}
         for _ in range(10):
             s0.decode(st.cuda_stream)
-            st.synchronize()
-            ms = s0.dec.stage_ms()
-            solo = {k: solo.get(k, 0.0) + v * 100 for k, v in ms.items()}  # us, averaged over 10
+        st.synchronize()
+        solo = {k: v * 1e3 for k, v in s0.dec.stage_ms().items()}  # us, mean of 10 single-image decodes
 
         dom = max(stage_us, key=stage_us.get)
         dom_key = {"sync_intra": "sync_intra", "write": "write", "idct": "idct"}.get(dom)
-        dom_bytes = ab.get(dom_key) if dom_key else None
-        t_pass_us = sum(stage_us[k] for k in ("memset", "destuff", "sync_intra", "sync_inter", "tails", "write"))
+        dom_bytes = ab.get(dom_key) * images_per_launch if dom_key else None
+        t_pass_us = sum(stage_us[k] for k in ("zero", "destuff", "sync_intra", "sync_inter", "tails", "write"))
         roofline = {
             "bound": "hbm", "kernel": "huff_" + dom if dom.startswith("sync") or dom == "write" else dom,
             "achieved": (dom_bytes / (stage_us[dom] * 1e-6) / 1e9) if dom_bytes and stage_us[dom] > 0 else None,
             "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": None, "traffic": None,
             "algorithmic_bytes_per_launch": dom_bytes, "avg_launch_us": stage_us[dom],
+            "images_per_launch": images_per_launch,
         }
         if roofline["achieved"] is not None:
             roofline["frac"] = roofline["achieved"] / HBM_PEAK_GBS
@@ -285,15 +305,16 @@ def main():
             "config": {"workload": "cfg2: 4032x3024 4:2:0 interleaved baseline JPEG, DRI=252 (one MCU row), "
                                    "%d seeded images per rank" % len(images) if args.workload == "cfg2"
                        else "cfg1 bytes: tests/golden/IMG_6510.JPG (the reference's 12 MP photo)",
-                       "images_per_gpu_per_step": args.batch, "streams": nstreams,
+                       "images_per_gpu_per_step": args.batch, "mode": args.mode, "streams": nstreams,
                        "subsequence_bytes": slots[0].layout.subsequence_bytes,
                        "stuffed_scan_bytes": ab["stuffed"], "gather": bool(args.gather and world > 1),
                        "parallelism": "image-sharded x%d" % world},
             "roofline": roofline,
             "roofline_pass": {
-                "what": "destuff+Huffman pass (memset, destuff, sync_intra, sync_inter, tails, write), "
+                "what": "destuff+Huffman pass (zero, destuff, sync_intra, sync_inter, tails, write), "
                         "B_dh = stuffed scan bytes + 128 B per data unit (SURVEY.md 8d)",
-                "bytes_per_image": ab["b_dh"], "sum_kernel_us_under_load": t_pass_us,
+                "bytes_per_image": ab["b_dh"], "sum_launch_us_under_load": t_pass_us,
+                "images_per_launch": images_per_launch,
                 "throughput_GBs": ab["b_dh"] * value / world / 1e9,
                 "frac_of_hbm_peak": ab["b_dh"] * value / world / 1e9 / HBM_PEAK_GBS},
             "roofline_e2e": {"bytes_per_image": ab["b_e2e"], "throughput_GBs": ab["b_e2e"] * value / world / 1e9,
@@ -305,6 +326,8 @@ def main():
         }
         if not args.no_cpu:
             out["cpu_baseline"] = cpu_baseline(args, slots[0].data)
+    for bt, _, _, _ in groups:
+        bt.destroy()
     for s in slots:
         s.dec.cleanup()
     if world > 1:

@@ -9,6 +9,8 @@
  *   jpeggpu_ext_set_profiling /        per-stage device time of a decode from HIP events recorded on the
  *   jpeggpu_ext_get_stage_ms           caller's stream (the reference has wall-clock timing only,
  *                                      benchmark/benchmark_jpeggpu.hpp:96-102)
+ *   jpeggpu_ext_decode_batch           one launch per stage for many images; the
+ *                                      reference decodes one image per call sequence
  *   jpeggpu_ext_upsample_planes        nearest-neighbour chroma replication on the device, the integer
  *                                      part of the reference's host helper util/util.h:62-91
  */
@@ -50,6 +52,7 @@ struct jpeggpu_ext_scan_layout {
 
 struct jpeggpu_ext_layout {
     int subsequence_bytes;
+    int subsequences_per_sequence; /* owned by one workgroup of the Huffman kernels */
     int num_scans;
     size_t transferred_bytes;  /* entropy-coded byte range copied by jpeggpu_decoder_transfer */
     size_t blob_bytes;         /* table blob copied by jpeggpu_decoder_transfer */
@@ -62,9 +65,10 @@ enum jpeggpu_status jpeggpu_ext_get_layout(jpeggpu_decoder_t decoder, struct jpe
 
 /* Stage timing: when enabled, jpeggpu_decoder_decode records HIP events on the caller's stream
  * between its launches; after the stream has been synchronised jpeggpu_ext_get_stage_ms returns the
- * milliseconds of the LAST decode per stage (summed over scans). */
+ * mean milliseconds per stage (summed over scans) of the decodes since the previous call (at most the
+ * last 64), and starts a new measurement window. */
 enum jpeggpu_ext_stage {
-    JPEGGPU_EXT_STAGE_MEMSET     = 0, /* zero-fill of the coefficient buffer */
+    JPEGGPU_EXT_STAGE_ZERO       = 0, /* zero-fill of the coefficient buffer */
     JPEGGPU_EXT_STAGE_DESTUFF    = 1,
     JPEGGPU_EXT_STAGE_SYNC_INTRA = 2,
     JPEGGPU_EXT_STAGE_SYNC_INTER = 3,
@@ -75,6 +79,37 @@ enum jpeggpu_ext_stage {
 };
 enum jpeggpu_status jpeggpu_ext_set_profiling(jpeggpu_decoder_t decoder, int enable);
 enum jpeggpu_status jpeggpu_ext_get_stage_ms(jpeggpu_decoder_t decoder, float* ms /* [JPEGGPU_EXT_NUM_STAGES] */);
+
+/* Batched decode: ONE launch per stage for all scans of all items (grid.y = scan), which is what fills
+ * a 256-CU device; the drop-in jpeggpu_decoder_decode launches per image. Every item must have been
+ * parsed and transferred (jpeggpu_decoder_transfer) into its own d_tmp, and all decoders must use the
+ * same subsequence size. `d_scratch` is caller-owned device memory of at least
+ * jpeggpu_ext_batch_scratch_size(total number of scans) bytes, private to the stream. The batch
+ * handle owns page-locked host staging only. */
+struct jpeggpu_batch;
+typedef struct jpeggpu_batch* jpeggpu_batch_t;
+struct jpeggpu_ext_batch_item {
+    jpeggpu_decoder_t decoder;
+    struct jpeggpu_img* img;
+    void* d_tmp;
+    size_t tmp_size;
+};
+size_t jpeggpu_ext_batch_scratch_size(int max_scans);
+enum jpeggpu_status jpeggpu_ext_batch_create(jpeggpu_batch_t* batch, int max_scans);
+enum jpeggpu_status jpeggpu_ext_decode_batch(
+    jpeggpu_batch_t batch,
+    const struct jpeggpu_ext_batch_item* items,
+    int num_items,
+    void* d_scratch,
+    size_t scratch_size,
+    jpeggpu_stream_t stream);
+enum jpeggpu_status jpeggpu_ext_batch_destroy(jpeggpu_batch_t batch);
+/* Lock-step flow iterations inside the per-sequence sync kernel before unfinished flows are handed to
+ * the low-footprint tail kernel (default 3; the drop-in decode keeps all flows in the sequence kernel). */
+enum jpeggpu_status jpeggpu_ext_batch_set_sync_iterations(jpeggpu_batch_t batch, int iterations);
+/* Stage timing of batched decodes; same contract as jpeggpu_ext_set_profiling / _get_stage_ms. */
+enum jpeggpu_status jpeggpu_ext_batch_set_profiling(jpeggpu_batch_t batch, int enable);
+enum jpeggpu_status jpeggpu_ext_batch_get_stage_ms(jpeggpu_batch_t batch, float* ms /* [JPEGGPU_EXT_NUM_STAGES] */);
 
 /* Replicate every plane of `src` (as produced by jpeggpu_decoder_decode for `info`) to the full
  * image resolution: dst[c][y][x] = src[c][y * sy_c / sy_max][x * sx_c / sx_max]. */

@@ -13,7 +13,7 @@ import os
 from . import build as _build
 
 MAX_COMP = 4
-STAGES = ("memset", "destuff", "sync_intra", "sync_inter", "tails", "write", "idct")
+STAGES = ("zero", "destuff", "sync_intra", "sync_inter", "tails", "write", "idct")
 
 
 class Status(enum.IntEnum):
@@ -53,11 +53,15 @@ class ExtScanLayout(C.Structure):
 
 class ExtLayout(C.Structure):
     _fields_ = [
-        ("subsequence_bytes", C.c_int), ("num_scans", C.c_int),
+        ("subsequence_bytes", C.c_int), ("subsequences_per_sequence", C.c_int), ("num_scans", C.c_int),
         ("transferred_bytes", C.c_size_t), ("blob_bytes", C.c_size_t),
         ("off_bytes", C.c_size_t), ("off_qtables", C.c_size_t),
         ("scans", ExtScanLayout * MAX_COMP),
     ]
+
+
+class BatchItem(C.Structure):
+    _fields_ = [("decoder", C.c_void_p), ("img", C.POINTER(Img)), ("d_tmp", C.c_void_p), ("tmp_size", C.c_size_t)]
 
 
 class JpegGpuError(RuntimeError):
@@ -101,6 +105,14 @@ def lib():
     L.jpeggpu_ext_get_layout.argtypes = [dec, C.POINTER(ExtLayout)]
     L.jpeggpu_ext_set_profiling.argtypes = [dec, C.c_int]
     L.jpeggpu_ext_get_stage_ms.argtypes = [dec, C.POINTER(C.c_float)]
+    L.jpeggpu_ext_batch_scratch_size.restype = C.c_size_t
+    L.jpeggpu_ext_batch_scratch_size.argtypes = [C.c_int]
+    L.jpeggpu_ext_batch_create.argtypes = [C.POINTER(C.c_void_p), C.c_int]
+    L.jpeggpu_ext_decode_batch.argtypes = [C.c_void_p, C.POINTER(BatchItem), C.c_int, C.c_void_p, C.c_size_t, C.c_void_p]
+    L.jpeggpu_ext_batch_destroy.argtypes = [C.c_void_p]
+    L.jpeggpu_ext_batch_set_profiling.argtypes = [C.c_void_p, C.c_int]
+    L.jpeggpu_ext_batch_set_sync_iterations.argtypes = [C.c_void_p, C.c_int]
+    L.jpeggpu_ext_batch_get_stage_ms.argtypes = [C.c_void_p, C.POINTER(C.c_float)]
     L.jpeggpu_ext_upsample_planes.argtypes = [
         C.POINTER(ImgInfo), C.POINTER(Img), C.POINTER(Img), C.c_int, C.c_int, C.c_void_p]
     _lib = L
@@ -186,6 +198,61 @@ class Decoder:
     def __del__(self):
         try:
             self.cleanup()
+        except Exception:
+            pass
+
+
+class Batch:
+    """jpeggpu_ext_decode_batch: one launch per stage for many parsed + transferred images."""
+
+    def __init__(self, max_scans: int):
+        self._h = C.c_void_p()
+        self.max_scans = max_scans
+        _check(lib().jpeggpu_ext_batch_create(C.byref(self._h), max_scans), "jpeggpu_ext_batch_create")
+        self.scratch_size = lib().jpeggpu_ext_batch_scratch_size(max_scans)
+        self._items = None
+        self._keep = None
+
+    def set_items(self, entries):
+        """entries: list of (Decoder, plane_ptrs, pitches, d_tmp, tmp_size). Built once, reused per call."""
+        n = len(entries)
+        arr = (BatchItem * n)()
+        imgs = []
+        for i, (dec, ptrs, pitches, d_tmp, tmp_size) in enumerate(entries):
+            img = Img()
+            for c, (p, pitch) in enumerate(zip(ptrs, pitches)):
+                img.image[c] = p
+                img.pitch[c] = pitch
+            imgs.append(img)
+            arr[i].decoder = dec._h
+            arr[i].img = C.pointer(img)
+            arr[i].d_tmp = d_tmp
+            arr[i].tmp_size = tmp_size
+        self._items, self._keep = arr, (imgs, entries)
+
+    def decode(self, d_scratch: int, stream: int = 0):
+        _check(lib().jpeggpu_ext_decode_batch(self._h, self._items, len(self._items), d_scratch, self.scratch_size, stream),
+               "jpeggpu_ext_decode_batch")
+
+    def set_sync_iterations(self, n: int):
+        _check(lib().jpeggpu_ext_batch_set_sync_iterations(self._h, n), "jpeggpu_ext_batch_set_sync_iterations")
+
+    def set_profiling(self, on: bool):
+        _check(lib().jpeggpu_ext_batch_set_profiling(self._h, int(on)), "jpeggpu_ext_batch_set_profiling")
+
+    def stage_ms(self):
+        ms = (C.c_float * len(STAGES))()
+        _check(lib().jpeggpu_ext_batch_get_stage_ms(self._h, ms), "jpeggpu_ext_batch_get_stage_ms")
+        return dict(zip(STAGES, ms))
+
+    def destroy(self):
+        if self._h:
+            lib().jpeggpu_ext_batch_destroy(self._h)
+            self._h = C.c_void_p()
+
+    def __del__(self):
+        try:
+            self.destroy()
         except Exception:
             pass
 

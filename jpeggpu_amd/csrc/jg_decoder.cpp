@@ -65,10 +65,10 @@ struct StagingBuffer {
 
 struct ScanPlan {
     // offsets inside the blob (and, shifted by off_blob, inside d_tmp)
-    size_t blob_tables = 0, blob_segments = 0, blob_chunks = 0;
+    size_t blob_tables = 0, blob_segments = 0, blob_chunks = 0, blob_parts = 0;
     // offsets inside d_tmp
     size_t destuffed = 0, seg_idx = 0, st_p = 0, st_n = 0, st_cz = 0, st_dc01 = 0, st_dc23 = 0;
-    size_t tails_n = 0, tails_dc01 = 0, tails_dc23 = 0;
+    size_t tails_n = 0, tails_dc01 = 0, tails_dc23 = 0, pending = 0, flow_list = 0;
     size_t coef = 0;
     int num_seq = 0;
 };
@@ -94,11 +94,21 @@ struct Decoder {
     int subseq_bytes    = 128;
     bool parsed         = false;
 
-    // optional stage timing (jpeggpu_ext_set_profiling): events recorded between the launches
+    std::vector<ScanJob> jobs; // scratch of the last decode
+
+    // optional stage timing (jpeggpu_ext_set_profiling): events recorded between the launches. A ring
+    // of event sets so that several decodes can be in flight before the times are read back.
+    static constexpr int kEventSets = 64;
+    struct EventSet {
+        std::vector<hipEvent_t> events;
+        std::vector<int> stage; // stage that ENDS at event i (event 0 has none)
+        size_t used = 0;
+    };
     bool profiling = false;
-    std::vector<hipEvent_t> events;
-    std::vector<int> event_stage; // stage that ENDS at event i (event 0 has none)
-    size_t events_used = 0;
+    std::vector<EventSet> sets;
+    int cur_set    = -1;
+    int sets_valid = 0;
+    void next_event_set();
     bool mark(int stage, hipStream_t stream);
 
     void make_plan();
@@ -122,6 +132,8 @@ void Decoder::make_plan()
         b += align_up(sc.segments.size() * sizeof(Segment), 256);
         sp.blob_chunks    = b;
         b += align_up(sc.chunks.size() * sizeof(DestuffChunk), 256);
+        sp.blob_parts     = b;
+        b += align_up(sc.tail_parts.size() * sizeof(int), 256);
     }
     p.blob_size = b;
 
@@ -151,6 +163,10 @@ void Decoder::make_plan()
         o += align_up(S * 4, 256);
         sp.st_dc23 = o;
         o += align_up(S * 4, 256);
+        sp.pending = o;
+        o += align_up(S, 256);
+        sp.flow_list = o;
+        o += align_up(S * 4, 256);
         sp.tails_n = o;
         o += align_up(static_cast<size_t>(sp.num_seq) * 4, 256);
         sp.tails_dc01 = o;
@@ -169,17 +185,27 @@ void Decoder::make_plan()
     plan             = p;
 }
 
+void Decoder::next_event_set()
+{
+    if (!profiling) return;
+    if (sets.empty()) sets.resize(kEventSets);
+    cur_set = (cur_set + 1) % kEventSets;
+    sets[cur_set].used = 0;
+    if (sets_valid < kEventSets) ++sets_valid;
+}
+
 bool Decoder::mark(int stage, hipStream_t stream)
 {
-    if (!profiling) return true;
-    if (events_used == events.size()) {
+    if (!profiling || cur_set < 0) return true;
+    EventSet& es = sets[cur_set];
+    if (es.used == es.events.size()) {
         hipEvent_t e;
         if (hipEventCreate(&e) != hipSuccess) return false;
-        events.push_back(e);
-        event_stage.push_back(0);
+        es.events.push_back(e);
+        es.stage.push_back(0);
     }
-    event_stage[events_used] = stage;
-    return hipEventRecord(events[events_used++], stream) == hipSuccess;
+    es.stage[es.used] = stage;
+    return hipEventRecord(es.events[es.used++], stream) == hipSuccess;
 }
 
 bool Decoder::fill_blob()
@@ -196,6 +222,7 @@ bool Decoder::fill_blob()
             std::memcpy(blob.ptr + sp.blob_segments, sc.segments.data(), sc.segments.size() * sizeof(Segment));
         if (!sc.chunks.empty())
             std::memcpy(blob.ptr + sp.blob_chunks, sc.chunks.data(), sc.chunks.size() * sizeof(DestuffChunk));
+        std::memcpy(blob.ptr + sp.blob_parts, sc.tail_parts.data(), sc.tail_parts.size() * sizeof(int));
     }
     return true;
 }
@@ -232,7 +259,9 @@ jpeggpu_status do_transfer(Decoder& d, void* d_tmp, size_t tmp_size, hipStream_t
     return JPEGGPU_SUCCESS;
 }
 
-jpeggpu_status do_decode(Decoder& d, jpeggpu_img* img, void* d_tmp, size_t tmp_size, hipStream_t stream)
+/// Validate the arguments of a decode and describe every scan of the image as a ScanJob.
+jpeggpu_status build_jobs(
+    Decoder& d, const jpeggpu_img* img, void* d_tmp, size_t tmp_size, int max_intra_iters, std::vector<jg::ScanJob>& jobs)
 {
     using namespace jg;
     if (!d.parsed) return JPEGGPU_INVALID_ARGUMENT;
@@ -242,22 +271,15 @@ jpeggpu_status do_decode(Decoder& d, jpeggpu_img* img, void* d_tmp, size_t tmp_s
     }
     if (!d_tmp || (reinterpret_cast<uintptr_t>(d_tmp) & 255)) return JPEGGPU_INVALID_ARGUMENT;
     if (tmp_size < d.plan.total) return JPEGGPU_INTERNAL_ERROR;
-    uint8_t* base     = static_cast<uint8_t*>(d_tmp);
-    const Plan& plan  = d.plan;
-    uint8_t* blob     = base + plan.off_blob;
-
-    d.events_used = 0;
-    d.mark(-1, stream);
-    // only non-zero coefficients are stored by the write pass
-    if (plan.coef_all_bytes)
-        JG_CHECK_HIP(hipMemsetAsync(base + plan.off_coef_all, 0, plan.coef_all_bytes, stream));
-    d.mark(JPEGGPU_EXT_STAGE_MEMSET, stream);
+    uint8_t* base    = static_cast<uint8_t*>(d_tmp);
+    const Plan& plan = d.plan;
+    uint8_t* blob    = base + plan.off_blob;
 
     for (int i = 0; i < s.num_scans; ++i) {
         const Scan& sc     = s.scans[i];
         const ScanPlan& pl = plan.scan[i];
-
-        ScanParams sp{};
+        ScanJob job{};
+        ScanParams& sp      = job.sp;
         sp.num_subseq       = sc.num_subseq;
         sp.num_segments     = static_cast<int>(sc.segments.size());
         sp.du_per_mcu       = sc.du_per_mcu;
@@ -266,11 +288,12 @@ jpeggpu_status do_decode(Decoder& d, jpeggpu_img* img, void* d_tmp, size_t tmp_s
         sp.total_mcus       = sc.mcus_x * sc.mcus_y;
         sp.subseq_words     = d.subseq_bytes / 4;
         sp.tab_bytes        = static_cast<uint32_t>(sc.table_pack.size());
-        IdctParams ip{};
-        ip.num_du     = sc.num_du;
-        ip.du_per_mcu = sc.du_per_mcu;
-        ip.mcus_x     = sc.mcus_x;
-        int du        = 0;
+        sp.max_intra_iters  = max_intra_iters;
+        IdctParams& ip = job.ip;
+        ip.num_du      = sc.num_du;
+        ip.du_per_mcu  = sc.du_per_mcu;
+        ip.mcus_x      = sc.mcus_x;
+        int du         = 0;
         for (int a = 0; a < sc.num_comp; ++a) {
             const ScanComponent& c = sc.comp[a];
             sp.dc_offs |= static_cast<uint64_t>(sc.dc_off[a]) << (16 * a);
@@ -293,50 +316,52 @@ jpeggpu_status do_decode(Decoder& d, jpeggpu_img* img, void* d_tmp, size_t tmp_s
             ip.qidx[a]          = fc.qidx;
             ip.plane[a]         = img->image[c.comp_idx];
         }
+        job.bytes      = base + plan.off_bytes;
+        job.chunks     = reinterpret_cast<const DestuffChunk*>(blob + pl.blob_chunks);
+        job.segments   = reinterpret_cast<const Segment*>(blob + pl.blob_segments);
+        job.tables     = blob + pl.blob_tables;
+        job.qtables    = blob + plan.blob_qtables;
+        job.destuffed  = base + pl.destuffed;
+        job.seg_idx    = reinterpret_cast<int*>(base + pl.seg_idx);
+        job.st_p       = reinterpret_cast<int*>(base + pl.st_p);
+        job.st_n       = reinterpret_cast<int*>(base + pl.st_n);
+        job.st_cz      = reinterpret_cast<int*>(base + pl.st_cz);
+        job.st_dc01    = reinterpret_cast<uint32_t*>(base + pl.st_dc01);
+        job.st_dc23    = reinterpret_cast<uint32_t*>(base + pl.st_dc23);
+        job.pending    = base + pl.pending;
+        job.flow_list  = reinterpret_cast<int*>(base + pl.flow_list);
+        job.tail_parts = reinterpret_cast<const int*>(blob + pl.blob_parts);
+        job.num_tail_parts = static_cast<int>(sc.tail_parts.size()) - 1;
+        job.tails_n    = reinterpret_cast<int*>(base + pl.tails_n);
+        job.tails_dc01 = reinterpret_cast<uint32_t*>(base + pl.tails_dc01);
+        job.tails_dc23 = reinterpret_cast<uint32_t*>(base + pl.tails_dc23);
+        job.coef       = reinterpret_cast<int16_t*>(base + pl.coef);
+        job.coef_bytes = static_cast<uint64_t>(sc.num_du) * 128;
+        job.num_chunks = static_cast<int>(sc.chunks.size());
+        job.num_seq    = pl.num_seq;
+        jobs.push_back(job);
+    }
+    return JPEGGPU_SUCCESS;
+}
 
-        SubseqState st{};
-        st.p  = reinterpret_cast<int*>(base + pl.st_p);
-        st.n  = reinterpret_cast<int*>(base + pl.st_n);
-        st.cz = reinterpret_cast<int*>(base + pl.st_cz);
-        SeqTails tails{};
-        st.dc01    = reinterpret_cast<uint32_t*>(base + pl.st_dc01);
-        st.dc23    = reinterpret_cast<uint32_t*>(base + pl.st_dc23);
-        tails.n    = reinterpret_cast<int*>(base + pl.tails_n);
-        tails.dc01 = reinterpret_cast<uint32_t*>(base + pl.tails_dc01);
-        tails.dc23 = reinterpret_cast<uint32_t*>(base + pl.tails_dc23);
-        const Segment* d_segments = reinterpret_cast<const Segment*>(blob + pl.blob_segments);
-        int* d_seg_idx            = reinterpret_cast<int*>(base + pl.seg_idx);
-        int16_t* d_coef           = reinterpret_cast<int16_t*>(base + pl.coef);
-
+jpeggpu_status do_decode(Decoder& d, jpeggpu_img* img, void* d_tmp, size_t tmp_size, hipStream_t stream)
+{
+    using namespace jg;
+    d.jobs.clear();
+    // one image: latency matters, keep every flow inside the sequence's workgroup
+    const jpeggpu_status st = build_jobs(d, img, d_tmp, tmp_size, jg::kSeqLanes, d.jobs);
+    if (st != JPEGGPU_SUCCESS) return st;
+    d.next_event_set();
+    d.mark(-1, stream);
+    for (size_t i = 0; i < d.jobs.size(); ++i) {
+        const ScanJob& job = d.jobs[i];
         d.logger.log(
             "scan %d: %d chunks, %d subsequences of %d bytes, %d sequences, %d segments\n",
-            i, static_cast<int>(sc.chunks.size()), sc.num_subseq, d.subseq_bytes, pl.num_seq, sp.num_segments);
-
-        JG_CHECK_HIP(launch_destuff(
-            base + plan.off_bytes,
-            base + pl.destuffed,
-            d_seg_idx,
-            reinterpret_cast<const DestuffChunk*>(blob + pl.blob_chunks),
-            static_cast<int>(sc.chunks.size()),
-            d.subseq_bytes,
-            stream));
-        d.mark(JPEGGPU_EXT_STAGE_DESTUFF, stream);
-        for (int hs = kHuffSyncIntra; hs <= kHuffWrite; ++hs) {
-            JG_CHECK_HIP(launch_huffman_stage(
-                static_cast<HuffStage>(hs),
-                base + pl.destuffed,
-                d_segments,
-                d_seg_idx,
-                blob + pl.blob_tables,
-                sp,
-                st,
-                tails,
-                d_coef,
-                stream));
-            d.mark(JPEGGPU_EXT_STAGE_SYNC_INTRA + hs, stream);
+            static_cast<int>(i), job.num_chunks, job.sp.num_subseq, d.subseq_bytes, job.num_seq, job.sp.num_segments);
+        for (int stage = 0; stage < kNumStages; ++stage) {
+            JG_CHECK_HIP(launch_stage(static_cast<Stage>(stage), job, stream));
+            d.mark(stage, stream);
         }
-        JG_CHECK_HIP(launch_idct(d_coef, blob + plan.blob_qtables, ip, stream));
-        d.mark(JPEGGPU_EXT_STAGE_IDCT, stream);
     }
     return JPEGGPU_SUCCESS;
 }
@@ -443,7 +468,8 @@ enum jpeggpu_status jpeggpu_decoder_cleanup(jpeggpu_decoder_t decoder)
 {
     if (!decoder) return JPEGGPU_INVALID_ARGUMENT;
     decoder->d.blob.release();
-    for (hipEvent_t e : decoder->d.events) (void)hipEventDestroy(e);
+    for (auto& es : decoder->d.sets)
+        for (hipEvent_t e : es.events) (void)hipEventDestroy(e);
     delete decoder;
     return JPEGGPU_SUCCESS;
 }
@@ -459,8 +485,9 @@ enum jpeggpu_status jpeggpu_ext_set_subsequence_bytes(jpeggpu_decoder_t decoder,
 enum jpeggpu_status jpeggpu_ext_set_profiling(jpeggpu_decoder_t decoder, int enable)
 {
     if (!decoder) return JPEGGPU_INVALID_ARGUMENT;
-    decoder->d.profiling   = enable != 0;
-    decoder->d.events_used = 0;
+    decoder->d.profiling  = enable != 0;
+    decoder->d.cur_set    = -1;
+    decoder->d.sets_valid = 0;
     return JPEGGPU_SUCCESS;
 }
 
@@ -469,13 +496,20 @@ enum jpeggpu_status jpeggpu_ext_get_stage_ms(jpeggpu_decoder_t decoder, float* m
     if (!decoder || !ms) return JPEGGPU_INVALID_ARGUMENT;
     Decoder& d = decoder->d;
     for (int i = 0; i < JPEGGPU_EXT_NUM_STAGES; ++i) ms[i] = 0.f;
-    if (!d.profiling || d.events_used < 2) return JPEGGPU_INVALID_ARGUMENT;
-    for (size_t i = 1; i < d.events_used; ++i) {
-        float t = 0.f;
-        if (hipEventElapsedTime(&t, d.events[i - 1], d.events[i]) != hipSuccess) return JPEGGPU_INTERNAL_ERROR;
-        const int st = d.event_stage[i];
-        if (st >= 0 && st < JPEGGPU_EXT_NUM_STAGES) ms[st] += t;
+    if (!d.profiling || d.sets_valid == 0) return JPEGGPU_INVALID_ARGUMENT;
+    // mean over the decodes recorded since profiling was (re-)enabled, at most the last kEventSets
+    for (int k = 0; k < d.sets_valid; ++k) {
+        const Decoder::EventSet& es = d.sets[k];
+        for (size_t i = 1; i < es.used; ++i) {
+            float t = 0.f;
+            if (hipEventElapsedTime(&t, es.events[i - 1], es.events[i]) != hipSuccess) return JPEGGPU_INTERNAL_ERROR;
+            const int st = es.stage[i];
+            if (st >= 0 && st < JPEGGPU_EXT_NUM_STAGES) ms[st] += t;
+        }
     }
+    for (int i = 0; i < JPEGGPU_EXT_NUM_STAGES; ++i) ms[i] /= static_cast<float>(d.sets_valid);
+    decoder->d.cur_set    = -1; // start a new measurement window
+    decoder->d.sets_valid = 0;
     return JPEGGPU_SUCCESS;
 }
 
@@ -487,6 +521,7 @@ enum jpeggpu_status jpeggpu_ext_get_layout(jpeggpu_decoder_t decoder, struct jpe
     const jg::Stream& s = d.reader.s;
     std::memset(out, 0, sizeof(*out));
     out->subsequence_bytes = d.subseq_bytes;
+    out->subsequences_per_sequence = jg::kSeqSubseq;
     out->num_scans         = s.num_scans;
     out->transferred_bytes = d.plan.bytes_len;
     out->blob_bytes        = d.plan.blob_size;
@@ -515,6 +550,147 @@ enum jpeggpu_status jpeggpu_ext_get_layout(jpeggpu_decoder_t decoder, struct jpe
         o.off_state_cz       = pl.st_cz;
         o.off_coefficients   = pl.coef;
     }
+    return JPEGGPU_SUCCESS;
+}
+
+struct jpeggpu_batch {
+    static constexpr int kRing = 4;
+    int max_jobs = 0;
+    jg::ScanJob* staging[kRing] = {};
+    hipEvent_t copied[kRing]    = {};
+    bool in_use[kRing]          = {};
+    int next                    = 0;
+    int sync_iters              = 3; // throughput: short-lived sync workgroups, stragglers go to the tail kernel
+    std::vector<jg::ScanJob> jobs;
+    // optional stage timing, same contract as the decoder's
+    bool profiling = false;
+    std::vector<std::vector<hipEvent_t>> sets; // ring of kNumStages + 1 events
+    int cur_set = -1, sets_valid = 0;
+};
+
+size_t jpeggpu_ext_batch_scratch_size(int max_scans) { return static_cast<size_t>(max_scans > 0 ? max_scans : 0) * sizeof(jg::ScanJob); }
+
+enum jpeggpu_status jpeggpu_ext_batch_create(jpeggpu_batch_t* batch, int max_scans)
+{
+    if (!batch || max_scans <= 0) return JPEGGPU_INVALID_ARGUMENT;
+    jpeggpu_batch* b = new (std::nothrow) jpeggpu_batch();
+    if (!b) return JPEGGPU_OUT_OF_HOST_MEMORY;
+    b->max_jobs = max_scans;
+    for (int r = 0; r < jpeggpu_batch::kRing; ++r) {
+        void* p = nullptr;
+        if (hipHostMalloc(&p, sizeof(jg::ScanJob) * max_scans, hipHostMallocDefault) != hipSuccess ||
+            hipEventCreateWithFlags(&b->copied[r], hipEventDisableTiming) != hipSuccess) {
+            (void)hipGetLastError();
+            jpeggpu_ext_batch_destroy(b);
+            return JPEGGPU_INTERNAL_ERROR; // the batch path needs a device: no fallback
+        }
+        b->staging[r] = static_cast<jg::ScanJob*>(p);
+    }
+    *batch = b;
+    return JPEGGPU_SUCCESS;
+}
+
+enum jpeggpu_status jpeggpu_ext_batch_destroy(jpeggpu_batch_t batch)
+{
+    if (!batch) return JPEGGPU_INVALID_ARGUMENT;
+    for (int r = 0; r < jpeggpu_batch::kRing; ++r) {
+        if (batch->staging[r]) (void)hipHostFree(batch->staging[r]);
+        if (batch->copied[r]) (void)hipEventDestroy(batch->copied[r]);
+    }
+    for (auto& set : batch->sets)
+        for (hipEvent_t e : set) (void)hipEventDestroy(e);
+    delete batch;
+    return JPEGGPU_SUCCESS;
+}
+
+enum jpeggpu_status jpeggpu_ext_decode_batch(
+    jpeggpu_batch_t batch,
+    const struct jpeggpu_ext_batch_item* items,
+    int num_items,
+    void* d_scratch,
+    size_t scratch_size,
+    jpeggpu_stream_t stream)
+{
+    if (!batch || !items || num_items < 0 || !d_scratch) return JPEGGPU_INVALID_ARGUMENT;
+    if (num_items == 0) return JPEGGPU_SUCCESS;
+    batch->jobs.clear();
+    int subseq_bytes = 0;
+    for (int i = 0; i < num_items; ++i) {
+        const jpeggpu_ext_batch_item& it = items[i];
+        if (!it.decoder || !it.img) return JPEGGPU_INVALID_ARGUMENT;
+        if (i == 0) subseq_bytes = it.decoder->d.subseq_bytes;
+        if (it.decoder->d.subseq_bytes != subseq_bytes) return JPEGGPU_INVALID_ARGUMENT; // one kernel variant per launch
+        const jpeggpu_status st = build_jobs(it.decoder->d, it.img, it.d_tmp, it.tmp_size, batch->sync_iters, batch->jobs);
+        if (st != JPEGGPU_SUCCESS) return st;
+    }
+    const int n = static_cast<int>(batch->jobs.size());
+    if (n > batch->max_jobs || scratch_size < sizeof(jg::ScanJob) * static_cast<size_t>(n)) return JPEGGPU_INVALID_ARGUMENT;
+    const int r = batch->next;
+    batch->next = (r + 1) % jpeggpu_batch::kRing;
+    // the staging buffer may still be the source of a copy enqueued kRing batches ago
+    if (batch->in_use[r] && hipEventSynchronize(batch->copied[r]) != hipSuccess) return JPEGGPU_INTERNAL_ERROR;
+    std::memcpy(batch->staging[r], batch->jobs.data(), sizeof(jg::ScanJob) * n);
+    jg::JobExtent extent;
+    for (const jg::ScanJob& j : batch->jobs) jg::extend(extent, j);
+    if (hipMemcpyAsync(d_scratch, batch->staging[r], sizeof(jg::ScanJob) * n, hipMemcpyHostToDevice, stream) != hipSuccess ||
+        hipEventRecord(batch->copied[r], stream) != hipSuccess)
+        return JPEGGPU_INTERNAL_ERROR;
+    batch->in_use[r] = true;
+    const jg::ScanJob* d_jobs = static_cast<const jg::ScanJob*>(d_scratch);
+    std::vector<hipEvent_t>* ev = nullptr;
+    if (batch->profiling) {
+        if (batch->sets.empty()) batch->sets.resize(64);
+        batch->cur_set = (batch->cur_set + 1) % 64;
+        if (batch->sets_valid < 64) ++batch->sets_valid;
+        ev = &batch->sets[batch->cur_set];
+        while (ev->size() < static_cast<size_t>(jg::kNumStages) + 1) {
+            hipEvent_t e;
+            if (hipEventCreate(&e) != hipSuccess) return JPEGGPU_INTERNAL_ERROR;
+            ev->push_back(e);
+        }
+        (void)hipEventRecord((*ev)[0], stream);
+    }
+    for (int stage = 0; stage < jg::kNumStages; ++stage) {
+        if (jg::launch_stage_batch(static_cast<jg::Stage>(stage), d_jobs, n, extent, stream) != hipSuccess) {
+            (void)hipGetLastError();
+            return JPEGGPU_INTERNAL_ERROR;
+        }
+        if (ev) (void)hipEventRecord((*ev)[stage + 1], stream);
+    }
+    return JPEGGPU_SUCCESS;
+}
+
+enum jpeggpu_status jpeggpu_ext_batch_set_sync_iterations(jpeggpu_batch_t batch, int iterations)
+{
+    if (!batch || iterations < 0) return JPEGGPU_INVALID_ARGUMENT;
+    batch->sync_iters = iterations;
+    return JPEGGPU_SUCCESS;
+}
+
+enum jpeggpu_status jpeggpu_ext_batch_set_profiling(jpeggpu_batch_t batch, int enable)
+{
+    if (!batch) return JPEGGPU_INVALID_ARGUMENT;
+    batch->profiling  = enable != 0;
+    batch->cur_set    = -1;
+    batch->sets_valid = 0;
+    return JPEGGPU_SUCCESS;
+}
+
+enum jpeggpu_status jpeggpu_ext_batch_get_stage_ms(jpeggpu_batch_t batch, float* ms)
+{
+    if (!batch || !ms) return JPEGGPU_INVALID_ARGUMENT;
+    for (int i = 0; i < JPEGGPU_EXT_NUM_STAGES; ++i) ms[i] = 0.f;
+    if (!batch->profiling || batch->sets_valid == 0) return JPEGGPU_INVALID_ARGUMENT;
+    for (int k = 0; k < batch->sets_valid; ++k) {
+        for (int st = 0; st < jg::kNumStages; ++st) {
+            float t = 0.f;
+            if (hipEventElapsedTime(&t, batch->sets[k][st], batch->sets[k][st + 1]) != hipSuccess) return JPEGGPU_INTERNAL_ERROR;
+            ms[st] += t;
+        }
+    }
+    for (int i = 0; i < JPEGGPU_EXT_NUM_STAGES; ++i) ms[i] /= static_cast<float>(batch->sets_valid);
+    batch->cur_set    = -1;
+    batch->sets_valid = 0;
     return JPEGGPU_SUCCESS;
 }
 

@@ -19,7 +19,10 @@ namespace jg {
 constexpr int kMaxComp      = 4;  // include/jpeggpu/jpeggpu.h:33
 constexpr int kMaxScans     = 4;  // baseline: every component appears in exactly one scan
 constexpr int kMaxDuPerMcu  = 10; // T.81 B.2.3
-constexpr int kSeqSubseq    = 256; // subsequences per workgroup ("sequence"), reference decode_huffman.cu:777
+constexpr int kSeqLanes    = 256; // lanes per workgroup of the Huffman kernels (reference decode_huffman.cu:777)
+constexpr int kSeqOverlap  = 16;  // lanes of the sync kernel that re-decode the tail of the previous sequence
+constexpr int kSeqSubseq   = kSeqLanes - kSeqOverlap; // subsequences owned by one workgroup ("sequence")
+constexpr int kTailPartSubseq = 2048; // target subsequences per workgroup of huff_sync_tail (cut at segment starts)
 constexpr int kDestuffWin   = 4096; // stuffed bytes handled by one destuff workgroup (256 lanes x 16 B)
 
 /// Zig-zag index -> raster index inside a data unit (T.81 figure A.6; reference src/defs.hpp:94-102).
@@ -34,7 +37,7 @@ constexpr int kDestuffWin   = 4096; // stuffed bytes handled by one destuff work
 /// (so that almost no lane ever needs the long-code path, which every lane of the wave would have
 /// to wait for), and a long-code path without a dependent chain of table reads.
 ///
-///   one table = lut16[1 << LB] | lim16[8] | valoff16[8] | huffval[256]     (LB = 10 for DC, 12 for AC)
+///   one table = lut16[1 << LB] | lim16[8] | valoff16[8] | huffval[256]     (LB = 9 for DC, 11 for AC)
 ///
 ///   lut16 entry, indexed by the LB most significant bits of the 32-bit window:
 ///     bits  0..5  total symbol length = code length + magnitude bits (0 = code longer than LB bits)
@@ -47,11 +50,11 @@ constexpr int kDestuffWin   = 4096; // stuffed bytes handled by one destuff work
 ///   valoff16[j]: (huffval index of the first code of length 9+j minus that code) mod 256
 ///
 /// A scan's pack holds only the tables its components select; ScanParams carries the byte offsets.
-constexpr int kLutBitsDc   = 10;
-constexpr int kLutBitsAc   = 12;
+constexpr int kLutBitsDc   = 9;
+constexpr int kLutBitsAc   = 11;
 constexpr int kHuffAuxSize = 16 + 16 + 256;
-constexpr int kDcTableSize = (2 << kLutBitsDc) + kHuffAuxSize; // 2336
-constexpr int kAcTableSize = (2 << kLutBitsAc) + kHuffAuxSize; // 8480
+constexpr int kDcTableSize = (2 << kLutBitsDc) + kHuffAuxSize; // 1312
+constexpr int kAcTableSize = (2 << kLutBitsAc) + kHuffAuxSize; // 4384
 constexpr int kMaxTablePack = kMaxComp * (kDcTableSize + kAcTableSize);
 
 JG_HD inline uint32_t huff_entry(int codelen, uint32_t sym, bool is_dc)
@@ -95,6 +98,7 @@ struct ScanParams {
     int mcus_per_segment; // restart interval, or all MCUs when there is none
     int total_mcus;
     int subseq_words;     // 32-bit words per subsequence (subsequence bytes / 4)
+    int max_intra_iters;  // lock-step flow iterations inside huff_sync_intra before flows are handed to huff_sync_tail
     uint32_t du_comp;     // 2 bits per data unit of the MCU: scan-component index
     uint32_t tab_bytes;   // size of the scan's Huffman table pack
     // Byte offset of each scan component's DC / AC table in the pack, 16 bits per component. Packed
@@ -119,6 +123,36 @@ struct IdctParams {
     int pitch[kMaxComp];
     int qidx[kMaxComp];            // quantisation table index
     uint8_t* plane[kMaxComp];
+};
+
+/// Everything the kernels need to know about one scan of one image: a launch covers one job (passed
+/// by value, the drop-in API) or an array of jobs, one per blockIdx.y (the batch API).
+struct ScanJob {
+    const uint8_t* bytes;        // transferred entropy-coded bytes of the image
+    const DestuffChunk* chunks;
+    const Segment* segments;
+    const uint8_t* tables;       // Huffman table pack of the scan
+    const uint8_t* qtables;      // uint8[4][64], natural order
+    uint8_t* destuffed;
+    int* seg_idx;                // subsequence -> segment
+    int* st_p;                   // sync state, structure of arrays (reference `subsequence_info`,
+    int* st_n;                   //   src/decode_huffman.cu:71-89, plus the DC sums)
+    int* st_cz;                  // c | z << 8
+    uint32_t* st_dc01;           // wrapping 16-bit sums of committed DC differences, components 0 | 1 << 16
+    uint32_t* st_dc23;           // components 2 | 3 << 16
+    uint8_t* pending;            // [num_subseq] 1: a flow that left subsequence i is unfinished (huff_sync_tail)
+    int* flow_list;              // [num_subseq] scratch of huff_sync_tail
+    const int* tail_parts;       // [num_tail_parts + 1] subsequence ranges of huff_sync_tail's workgroups
+    int num_tail_parts;
+    int* tails_n;                // per-sequence aggregates used to place the write pass
+    uint32_t* tails_dc01;
+    uint32_t* tails_dc23;
+    int16_t* coef;               // stream-order coefficients
+    uint64_t coef_bytes;
+    int num_chunks;
+    int num_seq;
+    ScanParams sp;
+    IdctParams ip;
 };
 
 } // namespace jg

@@ -1,17 +1,20 @@
 // jg_kernels.hip -- gfx950 (CDNA4, wave64) kernels of the baseline JPEG decode path.
 //
+//   zero_kernel             zero-fill of the coefficient buffer      (reference decoder.cpp:250-262 memsets)
 //   destuff_kernel          byte-stuffing / restart-marker removal   (reference src/decode_destuff.cu:37-361)
 //   huff_sync_intra         speculative decode + intra-sequence sync (reference decode_huffman.cu:413-524)
-//   huff_sync_inter         inter-sequence sync                      (reference decode_huffman.cu:534-621)
+//   huff_sync_tail          inter-sequence sync + unfinished flows   (reference decode_huffman.cu:534-621)
 //   huff_seq_tails          per-sequence sums of n / DC              (replaces cub ExclusiveScanByKey :818-869
 //                                                                     and the DC scans of decode_dc.cu:88-169)
 //   huff_write              final decode, de-zigzag, absolute DC     (reference decode_huffman.cu:627-682)
 //   idct_kernel             dequant + 8x8 fixed-point IDCT reading stream order
 //                                                                    (reference idct.cu:44-223 + decode_transpose.cu:41-132)
 //
-// Everything is integer / bit-serial: no MFMA. The bitstream slice of a workgroup is staged through
-// LDS with coalesced 4-byte global loads into a padded [word][subsequence] layout so that the 64
-// lanes of a wave, each walking its own subsequence, hit 64 different banks.
+// Everything is integer / bit-serial: no MFMA. Every kernel takes a job source: one ScanJob by
+// value (drop-in API) or an array indexed by blockIdx.y (batch API: one launch per stage for many
+// images, which is what fills 256 CUs). The bitstream slice of a workgroup is staged through LDS with
+// coalesced 4-byte global loads into a padded [word][subsequence] layout so that the 64 lanes of a
+// wave, each walking its own subsequence, hit 64 different banks.
 #include "jg_huff_core.h"
 #include "jg_kernels.hpp"
 
@@ -21,7 +24,18 @@ namespace jg {
 
 namespace {
 
-constexpr int T = kSeqSubseq; // lanes (= subsequences) per workgroup in the Huffman kernels
+constexpr int T   = kSeqLanes;   // lanes per workgroup in the Huffman kernels
+constexpr int SEQ = kSeqSubseq;  // subsequences a workgroup owns
+constexpr int OV  = kSeqOverlap; // lanes that re-decode the tail of the previous sequence
+
+struct JobByValue {
+    ScanJob job;
+    __device__ __forceinline__ const ScanJob& get() const { return job; }
+};
+struct JobArray {
+    const ScanJob* jobs;
+    __device__ __forceinline__ const ScanJob& get() const { return jobs[blockIdx.y]; }
+};
 
 __device__ __forceinline__ int lane_id() { return threadIdx.x & 63; }
 
@@ -36,6 +50,25 @@ __device__ __forceinline__ uint32_t wave_incl_scan(uint32_t v)
 }
 
 // ------------------------------------------------------------------------------------------------
+// zero fill
+// ------------------------------------------------------------------------------------------------
+
+constexpr int kZeroBytesPerBlock = 256 * 16 * 16; // 64 KiB
+
+template <class JS>
+__global__ __launch_bounds__(256) void zero_kernel(JS js)
+{
+    const ScanJob& J    = js.get();
+    const uint64_t base = static_cast<uint64_t>(blockIdx.x) * kZeroBytesPerBlock;
+    if (base >= J.coef_bytes) return;
+    uint4* dst         = reinterpret_cast<uint4*>(reinterpret_cast<uint8_t*>(J.coef) + base);
+    const uint64_t rem = J.coef_bytes - base; // coef_bytes is a multiple of 128
+    const uint64_t n16 = (rem < static_cast<uint64_t>(kZeroBytesPerBlock) ? rem : kZeroBytesPerBlock) / 16;
+    const uint4 z      = make_uint4(0, 0, 0, 0);
+    for (uint64_t i = threadIdx.x; i < n16; i += 256) dst[i] = z;
+}
+
+// ------------------------------------------------------------------------------------------------
 // destuff
 // ------------------------------------------------------------------------------------------------
 
@@ -44,19 +77,19 @@ __device__ __forceinline__ uint32_t wave_incl_scan(uint32_t v)
 /// data iff (prev == FF and b == 00) or (prev != FF and b != FF); the first case stores FF.
 /// The compacted bytes are staged in LDS at the destination's 16-byte phase and leave as whole
 /// 16-byte stores except at the two ragged ends (neighbouring chunks own the other bytes there).
-__global__ __launch_bounds__(256) void destuff_kernel(
-    const uint8_t* __restrict__ src,
-    uint8_t* __restrict__ dst,
-    int* __restrict__ seg_idx,
-    const DestuffChunk* __restrict__ chunks,
-    int subseq_shift)
+template <class JS>
+__global__ __launch_bounds__(256) void destuff_kernel(JS js)
 {
     __shared__ __attribute__((aligned(16))) uint8_t s_out[kDestuffWin + 32];
     __shared__ uint32_t s_wave[4];
 
-    const DestuffChunk ck = chunks[blockIdx.x];
-    const int t           = threadIdx.x;
-    const uint32_t gpos   = ck.win_off + t * 16;
+    const ScanJob& J = js.get();
+    if (static_cast<int>(blockIdx.x) >= J.num_chunks) return;
+    const uint8_t* __restrict__ src = J.bytes;
+    uint8_t* __restrict__ dst       = J.destuffed;
+    const DestuffChunk ck           = J.chunks[blockIdx.x];
+    const int t                     = threadIdx.x;
+    const uint32_t gpos             = ck.win_off + t * 16;
 
     uint32_t w[4];
     {
@@ -86,7 +119,7 @@ __global__ __launch_bounds__(256) void destuff_kernel(
     const uint32_t incl = wave_incl_scan(cnt);
     if (lane_id() == 63) s_wave[t >> 6] = incl;
     __syncthreads();
-    uint32_t off = incl - cnt;
+    uint32_t off   = incl - cnt;
     uint32_t total = 0;
 #pragma unroll
     for (int k = 0; k < 4; ++k) {
@@ -125,9 +158,9 @@ __global__ __launch_bounds__(256) void destuff_kernel(
     }
     // subsequences that start inside this chunk's destination range belong to this segment
     if (total) {
-        const uint32_t sb    = 1u << subseq_shift;
-        const uint32_t first = (ck.dst_off + sb - 1) >> subseq_shift;
-        for (uint32_t s = first + t; (s << subseq_shift) < ck.dst_off + total; s += 256) seg_idx[s] = ck.seg;
+        const uint32_t sb    = static_cast<uint32_t>(J.sp.subseq_words) * 4u;
+        const uint32_t first = (ck.dst_off + sb - 1) / sb;
+        for (uint32_t s = first + t; s * sb < ck.dst_off + total; s += 256) J.seg_idx[s] = ck.seg;
     }
 }
 
@@ -135,7 +168,7 @@ __global__ __launch_bounds__(256) void destuff_kernel(
 // Huffman: bitstream access
 // ------------------------------------------------------------------------------------------------
 
-/// LDS image of one sequence's bitstream: word k of local subsequence t lives at
+/// LDS image of the bitstream of T consecutive subsequences: word k of local subsequence t lives at
 /// k * (T + PAD) + t, PAD = 32 / W (W = words per subsequence, at most 32 here) so that both the
 /// coalesced fill (consecutive k) and the decode-time reads (consecutive t) are bank-conflict-free.
 template <int W>
@@ -145,18 +178,17 @@ struct SeqImage {
     static constexpr int kWords  = W * kStride;
 };
 
-/// Words just outside the sequence live in the image's pad column, so one address formula serves
-/// every read: the word before the sequence (local index -1; the write pass of the sequence's first
-/// subsequence starts up to 31 bits before its own first bit, reference
-/// decode_huffman_reader.hpp:279-292 carries those bits in `cache`) lands on (k = W-1, t = -1), and the
-/// three words after it (a symbol may be peeked across the sequence's end and the window prefetches
-/// one word ahead) on (k = 0..2, t = T).
+/// Words just outside the image live in its pad column, so one address formula serves every read:
+/// the word before it (local index -1; the write pass of a sequence's first subsequence starts up to
+/// 31 bits before its own first bit, reference decode_huffman_reader.hpp:279-292 carries those bits
+/// in `cache`) lands on (k = W-1, t = -1), and the three words after it (a symbol may be peeked across
+/// the end and the window prefetches one word ahead) on (k = 0..2, t = T).
 template <int W>
 struct LdsFetch {
     static constexpr int kLog2W = W == 8 ? 3 : W == 16 ? 4 : 5;
     static_assert((1 << kLog2W) == W, "subsequence words must be 8, 16 or 32");
     const uint32_t* img;
-    int base;      // word offset of the segment's first word relative to the sequence's first word
+    int base;      // word offset of the segment's first word relative to the image's first word
     int seg_words; // words in the segment (zero beyond, reference decode_huffman_reader.hpp:110-152)
     __device__ __forceinline__ uint32_t operator()(int w) const
     {
@@ -176,24 +208,26 @@ struct GlobalFetch {
     }
 };
 
+/// Stage subsequences [img_first, img_first + T) (clipped to [0, num_subseq)) into LDS.
 template <int W>
-__device__ __forceinline__ void load_sequence(
-    uint32_t* img, const uint32_t* __restrict__ scan32, int first_sub, int nsub, int num_subseq)
+__device__ __forceinline__ void load_image(
+    uint32_t* img, const uint32_t* __restrict__ scan32, int img_first, int num_subseq)
 {
-    const uint32_t* src = scan32 + static_cast<size_t>(first_sub) * W;
-    const int nwords    = nsub * W;
-    for (int i = threadIdx.x; i < nwords; i += T) {
+    const int lo        = max(0, -img_first) * W;             // first valid local word
+    const int hi        = min(T, num_subseq - img_first) * W; // one past the last valid local word
+    const uint32_t* src = scan32 + static_cast<ptrdiff_t>(img_first) * W;
+    for (int i = lo + threadIdx.x; i < hi; i += T) {
         img[(i % W) * SeqImage<W>::kStride + i / W] = __builtin_bswap32(src[i]);
     }
     if (threadIdx.x < 3) {
         // words T*W + 0..2 -> (k = 0..2, t = T); the destuffed buffer has 256 spare bytes at its end
-        const bool more = nsub == T && first_sub + nsub < num_subseq;
+        const bool more = img_first + T < num_subseq;
         img[threadIdx.x * SeqImage<W>::kStride + T] = more ? __builtin_bswap32(src[T * W + threadIdx.x]) : 0u;
     }
     if (threadIdx.x == 3) img[3 * SeqImage<W>::kStride + T] = 0u; // the zero word
     if (threadIdx.x == 4) {
         // word -1 -> (k = W-1, t = -1)
-        img[(W - 1) * SeqImage<W>::kStride - 1] = first_sub > 0 ? __builtin_bswap32(src[-1]) : 0u;
+        img[(W - 1) * SeqImage<W>::kStride - 1] = img_first > 0 ? __builtin_bswap32(src[-1]) : 0u;
     }
 }
 
@@ -220,18 +254,16 @@ __device__ __forceinline__ uint32_t pk_add(uint32_t a, uint32_t b) { return pk_a
 // Huffman: speculative decode + intra-sequence synchronisation
 // ------------------------------------------------------------------------------------------------
 
-/// Lane t decodes subsequence t of the sequence from the guessed state (c, z) = (0, 0), then keeps
-/// flowing into subsequences t+1, t+2, ... of the same segment until the state it reaches equals the
-/// one stored there. In iteration i entry j = t+1+i of the LDS state table is
-/// read and written by lane t only, so one workgroup barrier per iteration is enough.
-template <int W>
-__global__ __launch_bounds__(T) void huff_sync_intra(
-    const uint32_t* __restrict__ scan32,
-    const Segment* __restrict__ segments,
-    const int* __restrict__ seg_idx,
-    const uint8_t* __restrict__ g_tables,
-    ScanParams sp,
-    SubseqState out)
+/// Lane t decodes subsequence first_sub - OV + t from the guessed state (c, z) = (0, 0), then keeps
+/// flowing into the following subsequences of the same segment until the state it reaches equals
+/// the one stored there. In iteration i entry j = t+1+i of the LDS state
+/// table is read and written by lane t only, so one workgroup barrier per iteration is enough.
+///
+/// The first OV lanes re-decode the last OV subsequences of the PREVIOUS sequence (their results are
+/// not stored): their flows enter this sequence the way the previous workgroup's would, so the first
+/// subsequences of the sequence are normally already what the inter-sequence kernel will confirm.
+template <int W, class JS>
+__global__ __launch_bounds__(T) void huff_sync_intra(JS js)
 {
     extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
     uint32_t* s_img  = reinterpret_cast<uint32_t*>(smem + SeqLds<W>::kImg);
@@ -240,30 +272,36 @@ __global__ __launch_bounds__(T) void huff_sync_intra(
     int* s_cz        = s_n + T;
     uint32_t* s_dc01 = reinterpret_cast<uint32_t*>(s_cz + T);
     uint32_t* s_dc23 = s_dc01 + T;
+    int* s_pend      = reinterpret_cast<int*>(s_dc23 + T);
     uint8_t* s_tab   = smem + SeqLds<W>::kTabs;
 
+    const ScanJob& J = js.get();
+    if (static_cast<int>(blockIdx.x) >= J.num_seq) return;
+    const ScanParams sp = J.sp;
     const int t         = threadIdx.x;
-    const int first_sub = blockIdx.x * T;
-    const int nsub      = min(T, sp.num_subseq - first_sub);
+    s_pend[t]           = 0;
+    const int first_sub = blockIdx.x * SEQ;                  // first subsequence this workgroup owns
+    const int img_first = first_sub - OV;                    // subsequence of lane 0
+    const int img_end   = min(T, sp.num_subseq - img_first); // lanes below this have a subsequence
 
-    load_tables(s_tab, g_tables, sp.tab_bytes);
-    load_sequence<W>(s_img, scan32, first_sub, nsub, sp.num_subseq);
+    load_tables(s_tab, J.tables, sp.tab_bytes);
+    load_image<W>(s_img, reinterpret_cast<const uint32_t*>(J.destuffed), img_first, sp.num_subseq);
     __syncthreads();
 
-    const bool active = t < nsub;
+    const int sub     = img_first + t;
+    const bool active = sub >= 0 && t < img_end;
     LaneState st{};
     BitWindow<LdsFetch<W>> bw{};
     LdsFetch<W> fetch{s_img, 0, 0};
     int end_bit = 0;
-    int lim     = 0; // flows stay below this local index: end of the segment or of the sequence
+    int lim     = 0; // flows stay below this lane index: end of the segment or of the image
     NoSink sink;
     if (active) {
-        const int sub     = first_sub + t;
-        const Segment seg = segments[seg_idx[sub]];
+        const Segment seg = J.segments[J.seg_idx[sub]];
         const int rel     = sub - seg.subseq_offset;
-        fetch.base        = (seg.subseq_offset - first_sub) * W;
+        fetch.base        = (seg.subseq_offset - img_first) * W;
         fetch.seg_words   = seg.subseq_count * W;
-        lim               = min(nsub, seg.subseq_offset + seg.subseq_count - first_sub);
+        lim               = min(img_end, seg.subseq_offset + seg.subseq_count - img_first);
         st.p              = rel * (W * 32);
         end_bit           = (rel + 1) * (W * 32);
         bw.seek(st.p, fetch);
@@ -277,7 +315,8 @@ __global__ __launch_bounds__(T) void huff_sync_intra(
     __syncthreads();
 
     bool flowing = active;
-    for (int iter = 0; iter < T; ++iter) {
+    int iter     = 0;
+    for (; iter < sp.max_intra_iters; ++iter) {
         const int j = t + 1 + iter;
         if (flowing && j < lim) {
             st.n    = 0;
@@ -297,14 +336,18 @@ __global__ __launch_bounds__(T) void huff_sync_intra(
         }
         if (!__syncthreads_or(flowing && j + 1 < lim)) break;
     }
+    // Flows cut short by the iteration cap continue in huff_sync_tail from the entry they reached
+    // last: mark that entry (flows still inside the overlap zone belong to the previous workgroup).
+    if (iter == sp.max_intra_iters && flowing && t + 1 + iter < lim && t + iter >= OV) s_pend[t + iter] = 1;
+    __syncthreads();
 
-    if (active) {
-        const int sub = first_sub + t;
-        out.p[sub]    = s_p[t];
-        out.n[sub]    = s_n[t];
-        out.cz[sub]   = s_cz[t];
-        out.dc01[sub] = s_dc01[t];
-        out.dc23[sub] = s_dc23[t];
+    if (active && t >= OV) {
+        J.pending[sub] = static_cast<uint8_t>(s_pend[t]);
+        J.st_p[sub]    = s_p[t];
+        J.st_n[sub]    = s_n[t];
+        J.st_cz[sub]   = s_cz[t];
+        J.st_dc01[sub] = s_dc01[t];
+        J.st_dc23[sub] = s_dc23[t];
     }
 }
 
@@ -312,31 +355,56 @@ __global__ __launch_bounds__(T) void huff_sync_intra(
 // Huffman: inter-sequence synchronisation
 // ------------------------------------------------------------------------------------------------
 
-/// One lane per sequence boundary: carry the exit state of the last subsequence of sequence b-1 into
-/// sequence b, b+1, ... until it meets the stored state (or the segment ends). All boundaries advance
-/// in lock-step inside ONE workgroup, groups of boundaries are processed in stream order, so a flow
-/// that started further upstream always overwrites later and, unlike the
-/// reference (Appendix B-4), no pair of boundaries is left unordered. State lives in global memory,
-/// bitstream words are read straight from the destuffed buffer (one refill ahead, so the load
-/// latency is off the critical path).
-template <int W>
-__global__ __launch_bounds__(1024) void huff_sync_inter(
-    const uint32_t* __restrict__ scan32,
-    const Segment* __restrict__ segments,
-    const int* __restrict__ seg_idx,
-    const uint8_t* __restrict__ g_tables,
-    ScanParams sp,
-    SubseqState g)
+/// Continues, from global state, every flow that huff_sync_intra could not finish: one flow per
+/// sequence boundary (carry the exit state of the last subsequence of sequence b-1 into sequence b,
+/// b+1, ... until it meets the stored state or the segment ends) and one per pending mark. A flow
+/// never leaves its segment, so the scan is cut at segment starts into parts that independent
+/// workgroups own. Inside a part all flows advance in lock-step, one subsequence per iteration, and
+/// groups of blockDim flows are processed in stream order, so a flow that started further upstream
+/// always overwrites later and, unlike the reference (Appendix B-4), no pair
+/// of flows is left unordered. Bitstream words come straight from the destuffed buffer, one refill
+/// ahead, so only the Huffman tables need LDS. With the overlap lanes of huff_sync_intra a boundary
+/// flow normally confirms the stored state in its first iteration; this kernel is what makes the
+/// result exact.
+template <int W, class JS>
+__global__ __launch_bounds__(256) void huff_sync_tail(JS js)
 {
     extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
     uint8_t* s_tab = smem;
-    load_tables(s_tab, g_tables, sp.tab_bytes);
-    __syncthreads();
+    __shared__ int s_wave[4];
 
-    const int num_seq = (sp.num_subseq + T - 1) / T;
+    const ScanJob& J = js.get();
+    if (static_cast<int>(blockIdx.x) >= J.num_tail_parts) return;
+    const ScanParams sp    = J.sp;
+    const uint32_t* scan32 = reinterpret_cast<const uint32_t*>(J.destuffed);
+    const int lo           = J.tail_parts[blockIdx.x];
+    const int hi           = J.tail_parts[blockIdx.x + 1];
+    const int tid          = threadIdx.x;
+    load_tables(s_tab, J.tables, sp.tab_bytes);
+
+    // ordered list of flow origins in [lo, hi)
+    int count = 0;
+    for (int base = lo; base < hi; base += 256) {
+        const int sub = base + tid;
+        const bool f  = sub < hi && sub + 1 < sp.num_subseq && (J.pending[sub] != 0 || (sub + 1) % SEQ == 0);
+        const unsigned long long m = __ballot(f);
+        const int before           = __popcll(m & ((1ull << lane_id()) - 1ull));
+        __syncthreads();
+        if (lane_id() == 0) s_wave[tid >> 6] = __popcll(m);
+        __syncthreads();
+        int off = 0, total = 0;
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            off += k < (tid >> 6) ? s_wave[k] : 0;
+            total += s_wave[k];
+        }
+        if (f) J.flow_list[lo + count + off + before] = sub;
+        count += total;
+    }
+    __syncthreads(); // list and tables visible to the whole workgroup
+
     NoSink sink;
-    for (int base = 1; base < num_seq; base += blockDim.x) {
-        const int b = base + threadIdx.x;
+    for (int g = 0; g < count; g += 256) {
         LaneState st{};
         BitWindow<GlobalFetch> bw{};
         GlobalFetch fetch{nullptr, 0};
@@ -344,17 +412,17 @@ __global__ __launch_bounds__(1024) void huff_sync_inter(
         int j        = 0; // global index of the subsequence flowed into next
         int lim      = 0;
         bool flowing = false;
-        if (b < num_seq) {
-            const int from    = b * T - 1;
-            const Segment seg = segments[seg_idx[from]];
+        if (g + tid < count) {
+            const int from    = J.flow_list[lo + g + tid];
+            const Segment seg = J.segments[J.seg_idx[from]];
             lim               = seg.subseq_offset + seg.subseq_count;
             j                 = from + 1;
             flowing           = j < lim;
             if (flowing) {
                 fetch.words     = scan32 + static_cast<size_t>(seg.subseq_offset) * W;
                 fetch.seg_words = seg.subseq_count * W;
-                st.p            = g.p[from];
-                const int cz    = g.cz[from];
+                st.p            = J.st_p[from];
+                const int cz    = J.st_cz[from];
                 st.c            = cz & 0xFF;
                 st.z            = cz >> 8;
                 end_bit         = (from - seg.subseq_offset + 1) * (W * 32);
@@ -369,12 +437,12 @@ __global__ __launch_bounds__(1024) void huff_sync_inter(
                 end_bit += W * 32;
                 decode_subsequence(st, bw, fetch, end_bit, s_tab, sp, sink);
                 const int cz = st.c | (st.z << 8);
-                if (st.p == g.p[j] && cz == g.cz[j]) flowing = false;
-                g.p[j]    = st.p;
-                g.n[j]    = st.n;
-                g.cz[j]   = cz;
-                g.dc01[j] = st.dc01;
-                g.dc23[j] = st.dc23;
+                if (st.p == J.st_p[j] && cz == J.st_cz[j]) flowing = false;
+                J.st_p[j]    = st.p;
+                J.st_n[j]    = st.n;
+                J.st_cz[j]   = cz;
+                J.st_dc01[j] = st.dc01;
+                J.st_dc23[j] = st.dc23;
                 ++j;
             } else {
                 flowing = false;
@@ -408,28 +476,26 @@ __device__ __forceinline__ uint32_t block_sum_256(uint32_t v, uint32_t* s_red)
 /// tails[b] = sum of (n, dc) over the subsequences of sequence b that belong to the segment still
 /// open at the end of b. The write pass of sequence b' > b in the same segment adds tails[a..b'-1]
 /// (a = sequence holding the segment's first subsequence) to get its offset inside the segment.
-__global__ __launch_bounds__(T) void huff_seq_tails(
-    const Segment* __restrict__ segments,
-    const int* __restrict__ seg_idx,
-    ScanParams sp,
-    SubseqState g,
-    SeqTails tails)
+template <class JS>
+__global__ __launch_bounds__(T) void huff_seq_tails(JS js)
 {
     __shared__ uint32_t s_red[4];
+    const ScanJob& J = js.get();
+    if (static_cast<int>(blockIdx.x) >= J.num_seq) return;
     const int t         = threadIdx.x;
-    const int first_sub = blockIdx.x * T;
-    const int nsub      = min(T, sp.num_subseq - first_sub);
-    const int last_seg  = seg_idx[first_sub + nsub - 1];
-    const int open_from = segments[last_seg].subseq_offset; // global index of that segment's start
+    const int first_sub = blockIdx.x * SEQ;
+    const int nsub      = min(SEQ, J.sp.num_subseq - first_sub);
+    const int last_seg  = J.seg_idx[first_sub + nsub - 1];
+    const int open_from = J.segments[last_seg].subseq_offset; // global index of that segment's start
     const int sub       = first_sub + t;
     const bool take     = t < nsub && sub >= open_from;
-    const uint32_t n    = block_sum_256<false>(take ? g.n[sub] : 0, s_red);
-    const uint32_t d01  = block_sum_256<true>(take ? g.dc01[sub] : 0u, s_red);
-    const uint32_t d23  = block_sum_256<true>(take ? g.dc23[sub] : 0u, s_red);
+    const uint32_t n    = block_sum_256<false>(take ? J.st_n[sub] : 0, s_red);
+    const uint32_t d01  = block_sum_256<true>(take ? J.st_dc01[sub] : 0u, s_red);
+    const uint32_t d23  = block_sum_256<true>(take ? J.st_dc23[sub] : 0u, s_red);
     if (t == 0) {
-        tails.n[blockIdx.x]    = static_cast<int>(n);
-        tails.dc01[blockIdx.x] = d01;
-        tails.dc23[blockIdx.x] = d23;
+        J.tails_n[blockIdx.x]    = static_cast<int>(n);
+        J.tails_dc01[blockIdx.x] = d01;
+        J.tails_dc23[blockIdx.x] = d23;
     }
 }
 
@@ -504,31 +570,27 @@ __device__ __forceinline__ int hi16(uint32_t v) { return static_cast<int16_t>(v 
 /// non-zero coefficients in stream order (data unit after data unit, natural order inside, DC
 /// already absolute). Output position of subsequence i inside its segment = sum of n over the
 /// segment's earlier subsequences: in-sequence part by an LDS scan, earlier sequences via tails.
-template <int W>
-__global__ __launch_bounds__(T) void huff_write(
-    const uint32_t* __restrict__ scan32,
-    const Segment* __restrict__ segments,
-    const int* __restrict__ seg_idx,
-    const uint8_t* __restrict__ g_tables,
-    ScanParams sp,
-    SubseqState g,
-    SeqTails tails,
-    int16_t* __restrict__ coef)
+/// Lanes SEQ..T-1 have no subsequence here (the sequence is SEQ long); they only help with the scans.
+template <int W, class JS>
+__global__ __launch_bounds__(T) void huff_write(JS js)
 {
     extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
-    uint32_t* s_img  = reinterpret_cast<uint32_t*>(smem + SeqLds<W>::kImg);
-    uint32_t* s_scan = reinterpret_cast<uint32_t*>(smem + SeqLds<W>::kState); // T + 1
-    uint32_t* s_wave = s_scan + T + 1;                                         // 4
-    uint32_t* s_carry = s_wave + 4;                                            // 3
-    uint8_t* s_nat   = reinterpret_cast<uint8_t*>(s_carry + 3);                // 64
-    uint8_t* s_tab   = smem + SeqLds<W>::kTabs;
+    uint32_t* s_img   = reinterpret_cast<uint32_t*>(smem + SeqLds<W>::kImg);
+    uint32_t* s_scan  = reinterpret_cast<uint32_t*>(smem + SeqLds<W>::kState); // T + 1
+    uint32_t* s_wave  = s_scan + T + 1;                                         // 4
+    uint32_t* s_carry = s_wave + 4;                                             // 3
+    uint8_t* s_nat    = reinterpret_cast<uint8_t*>(s_carry + 3);                // 64
+    uint8_t* s_tab    = smem + SeqLds<W>::kTabs;
 
+    const ScanJob& J = js.get();
+    if (static_cast<int>(blockIdx.x) >= J.num_seq) return;
+    const ScanParams sp = J.sp;
     const int t         = threadIdx.x;
-    const int first_sub = blockIdx.x * T;
-    const int nsub      = min(T, sp.num_subseq - first_sub);
+    const int first_sub = blockIdx.x * SEQ;
+    const int nsub      = min(SEQ, sp.num_subseq - first_sub);
 
-    load_tables(s_tab, g_tables, sp.tab_bytes);
-    load_sequence<W>(s_img, scan32, first_sub, nsub, sp.num_subseq);
+    load_tables(s_tab, J.tables, sp.tab_bytes);
+    load_image<W>(s_img, reinterpret_cast<const uint32_t*>(J.destuffed), first_sub, sp.num_subseq);
     if (t < 64) {
         constexpr uint8_t nat[64] = JG_ORDER_NATURAL;
         s_nat[t]                  = nat[t];
@@ -536,14 +598,14 @@ __global__ __launch_bounds__(T) void huff_write(
 
     // carry-in of the segment that is open at the sequence's first subsequence
     {
-        const Segment seg0 = segments[seg_idx[first_sub]];
-        const int a        = seg0.subseq_offset / T; // sequence holding the segment's start
+        const Segment seg0 = J.segments[J.seg_idx[first_sub]];
+        const int a        = seg0.subseq_offset / SEQ; // sequence holding the segment's start
         uint32_t cn = 0, c01 = 0, c23 = 0;
         if (seg0.subseq_offset < first_sub) {
             for (int b = a + t; b < static_cast<int>(blockIdx.x); b += T) {
-                cn += static_cast<uint32_t>(tails.n[b]);
-                c01 = pk_add(c01, tails.dc01[b]);
-                c23 = pk_add(c23, tails.dc23[b]);
+                cn += static_cast<uint32_t>(J.tails_n[b]);
+                c01 = pk_add(c01, J.tails_dc01[b]);
+                c23 = pk_add(c23, J.tails_dc23[b]);
             }
         }
         cn  = block_sum_256<false>(cn, s_wave);
@@ -563,23 +625,23 @@ __global__ __launch_bounds__(T) void huff_write(
     Segment seg{0, 0};
     bool carried = false; // segment started before this sequence
     if (active) {
-        seg_i   = seg_idx[sub];
-        seg     = segments[seg_i];
+        seg_i   = J.seg_idx[sub];
+        seg     = J.segments[seg_i];
         rel     = sub - seg.subseq_offset;
         carried = seg.subseq_offset < first_sub;
         ts      = carried ? 0 : seg.subseq_offset - first_sub;
     }
 
     CoefSink sink;
-    sink.out     = coef;
+    sink.out     = J.coef;
     sink.natural = s_nat;
     int nprefix  = 0;
     {
-        block_excl_scan_256<false>(active ? static_cast<uint32_t>(g.n[sub]) : 0u, s_scan, s_wave);
+        block_excl_scan_256<false>(active ? static_cast<uint32_t>(J.st_n[sub]) : 0u, s_scan, s_wave);
         nprefix = static_cast<int>(s_scan[t] - s_scan[ts] + (carried ? s_carry[0] : 0u));
-        block_excl_scan_256<true>(active ? g.dc01[sub] : 0u, s_scan, s_wave);
+        block_excl_scan_256<true>(active ? J.st_dc01[sub] : 0u, s_scan, s_wave);
         const uint32_t p01 = pk_add(pk_sub(s_scan[t], s_scan[ts]), carried ? s_carry[1] : 0u);
-        block_excl_scan_256<true>(active ? g.dc23[sub] : 0u, s_scan, s_wave);
+        block_excl_scan_256<true>(active ? J.st_dc23[sub] : 0u, s_scan, s_wave);
         const uint32_t p23 = pk_add(pk_sub(s_scan[t], s_scan[ts]), carried ? s_carry[2] : 0u);
         sink.pred[0] = lo16(p01);
         sink.pred[1] = hi16(p01);
@@ -596,8 +658,8 @@ __global__ __launch_bounds__(T) void huff_write(
 
     LaneState st{};
     if (rel > 0) {
-        st.p         = g.p[sub - 1];
-        const int cz = g.cz[sub - 1];
+        st.p         = J.st_p[sub - 1];
+        const int cz = J.st_cz[sub - 1];
         st.c         = cz & 0xFF;
         st.z         = cz >> 8;
     }
@@ -646,17 +708,21 @@ __device__ __forceinline__ void idct8(int (&v)[8])
     v[7] = unfixh(a0 - b0);
 }
 
-constexpr int kIdctDuPerBlock = 32;        // 8 lanes per data unit, 256 lanes
-constexpr int kIdctRowStride  = 8 + 2;     // int16 per staged row (+2: column reads spread over banks)
+constexpr int kIdctDuPerBlock = 32;    // 8 lanes per data unit, 256 lanes
+constexpr int kIdctRowStride  = 8 + 2; // int16 per staged row (+2: column reads spread over banks)
 
 /// One data unit per 8 lanes, read straight from the stream-order coefficient buffer (16 bytes =
 /// one row per lane, fully coalesced). Steps and int16 truncation points are those of the reference
 /// `idct_kernel` (src/idct.cu:146-223): (int16)(coef * q) -> column pass -> row pass -> +128 -> clamp.
 /// The MCU geometry (reference decode_transpose.cu:65-131) is applied when the 8x8 pixels are stored.
-__global__ __launch_bounds__(256) void idct_kernel(
-    const int16_t* __restrict__ coef, const uint8_t* __restrict__ qtables, IdctParams ip)
+template <class JS>
+__global__ __launch_bounds__(256) void idct_kernel(JS js)
 {
     __shared__ int16_t s_blk[kIdctDuPerBlock][8][kIdctRowStride];
+
+    const ScanJob& J     = js.get();
+    const IdctParams& ip = J.ip;
+    if (static_cast<int>(blockIdx.x) * kIdctDuPerBlock >= ip.num_du) return;
 
     const int t   = threadIdx.x;
     const int r   = t & 7;  // row (passes 1 and 3) or column (pass 2) handled by this lane
@@ -670,8 +736,8 @@ __global__ __launch_bounds__(256) void idct_kernel(
 
     int v[8];
     if (in) {
-        const uint4 raw = *reinterpret_cast<const uint4*>(coef + static_cast<size_t>(du) * 64 + r * 8);
-        const uint2 qr  = *reinterpret_cast<const uint2*>(qtables + ip.qidx[sc] * 64 + r * 8);
+        const uint4 raw = *reinterpret_cast<const uint4*>(J.coef + static_cast<size_t>(du) * 64 + r * 8);
+        const uint2 qr  = *reinterpret_cast<const uint2*>(J.qtables + ip.qidx[sc] * 64 + r * 8);
         const uint32_t cw[4] = {raw.x, raw.y, raw.z, raw.w};
         const uint32_t qw[2] = {qr.x, qr.y};
 #pragma unroll
@@ -741,102 +807,105 @@ __global__ __launch_bounds__(256) void upsample_kernel(
     }
 }
 
+// ------------------------------------------------------------------------------------------------
+// launches
+// ------------------------------------------------------------------------------------------------
+
 template <class K>
 hipError_t allow_lds(K kernel, size_t bytes)
 {
     // more than 64 KiB of dynamic LDS has to be requested per kernel; gfx950 has 160 KiB per CU
     if (bytes <= 64 * 1024) return hipSuccess;
-    return hipFuncSetAttribute(reinterpret_cast<const void*>(kernel), hipFuncAttributeMaxDynamicSharedMemorySize, static_cast<int>(bytes));
+    return hipFuncSetAttribute(
+        reinterpret_cast<const void*>(kernel), hipFuncAttributeMaxDynamicSharedMemorySize, static_cast<int>(bytes));
 }
 
-template <int W>
-hipError_t launch_huffman_w(
-    HuffStage which,
-    const uint32_t* scan32,
-    const Segment* d_segments,
-    const int* d_seg_idx,
-    const uint8_t* d_tables,
-    const ScanParams& sp,
-    SubseqState st,
-    SeqTails tails,
-    int16_t* d_coef,
-    hipStream_t stream)
+template <int W, class JS>
+hipError_t launch_huff(Stage stage, const JS& js, const JobExtent& e, int grid_y, hipStream_t stream)
 {
-    const int num_seq      = (sp.num_subseq + T - 1) / T;
-    const size_t seq_lds   = SeqLds<W>::kTabs + sp.tab_bytes;
-    hipError_t err         = hipSuccess;
-    switch (which) {
-    case kHuffSyncIntra:
-        if ((err = allow_lds(huff_sync_intra<W>, seq_lds)) != hipSuccess) return err;
-        huff_sync_intra<W><<<num_seq, T, seq_lds, stream>>>(scan32, d_segments, d_seg_idx, d_tables, sp, st);
+    const size_t seq_lds = SeqLds<W>::kTabs + e.max_tab_bytes;
+    hipError_t err       = hipSuccess;
+    switch (stage) {
+    case kStageSyncIntra:
+        if ((err = allow_lds(huff_sync_intra<W, JS>, seq_lds)) != hipSuccess) return err;
+        huff_sync_intra<W, JS><<<dim3(e.max_seq, grid_y), T, seq_lds, stream>>>(js);
         break;
-    case kHuffSyncInter:
-        if (num_seq > 1) {
-            const int want  = ((num_seq - 1 + 63) / 64) * 64;
-            const int lanes = want < 1024 ? want : 1024;
-            huff_sync_inter<W><<<1, lanes, sp.tab_bytes, stream>>>(scan32, d_segments, d_seg_idx, d_tables, sp, st);
-        }
+    case kStageSyncInter:
+        if (e.max_tail_parts > 0) huff_sync_tail<W, JS><<<dim3(e.max_tail_parts, grid_y), 256, e.max_tab_bytes, stream>>>(js);
         break;
-    case kHuffTails:
-        huff_seq_tails<<<num_seq, T, 0, stream>>>(d_segments, d_seg_idx, sp, st, tails);
+    case kStageWrite:
+        if ((err = allow_lds(huff_write<W, JS>, seq_lds)) != hipSuccess) return err;
+        huff_write<W, JS><<<dim3(e.max_seq, grid_y), T, seq_lds, stream>>>(js);
         break;
-    case kHuffWrite:
-        if ((err = allow_lds(huff_write<W>, seq_lds)) != hipSuccess) return err;
-        huff_write<W><<<num_seq, T, seq_lds, stream>>>(scan32, d_segments, d_seg_idx, d_tables, sp, st, tails, d_coef);
-        break;
+    default: return hipErrorInvalidValue;
     }
     return hipGetLastError();
+}
+
+template <class JS>
+hipError_t launch_any(Stage stage, const JS& js, const JobExtent& e, int grid_y, hipStream_t stream)
+{
+    switch (stage) {
+    case kStageZero: {
+        if (e.max_coef_bytes == 0) return hipSuccess;
+        const unsigned gx = static_cast<unsigned>((e.max_coef_bytes + kZeroBytesPerBlock - 1) / kZeroBytesPerBlock);
+        zero_kernel<JS><<<dim3(gx, grid_y), 256, 0, stream>>>(js);
+        return hipGetLastError();
+    }
+    case kStageDestuff:
+        if (e.max_chunks == 0) return hipSuccess;
+        destuff_kernel<JS><<<dim3(e.max_chunks, grid_y), 256, 0, stream>>>(js);
+        return hipGetLastError();
+    case kStageTails:
+        if (e.max_seq == 0) return hipSuccess;
+        huff_seq_tails<JS><<<dim3(e.max_seq, grid_y), T, 0, stream>>>(js);
+        return hipGetLastError();
+    case kStageIdct:
+        if (e.max_idct_blocks == 0) return hipSuccess;
+        idct_kernel<JS><<<dim3(e.max_idct_blocks, grid_y), 256, 0, stream>>>(js);
+        return hipGetLastError();
+    case kStageSyncIntra:
+    case kStageSyncInter:
+    case kStageWrite:
+        if (e.max_seq == 0) return hipSuccess;
+        switch (e.subseq_words) {
+        case 8: return launch_huff<8, JS>(stage, js, e, grid_y, stream);
+        case 16: return launch_huff<16, JS>(stage, js, e, grid_y, stream);
+        case 32: return launch_huff<32, JS>(stage, js, e, grid_y, stream);
+        }
+        return hipErrorInvalidValue;
+    default: return hipErrorInvalidValue;
+    }
 }
 
 } // namespace
 
 bool subseq_bytes_supported(int b) { return b == 32 || b == 64 || b == 128; }
 
-hipError_t launch_destuff(
-    const uint8_t* d_bytes,
-    uint8_t* d_destuffed,
-    int* d_seg_idx,
-    const DestuffChunk* d_chunks,
-    int num_chunks,
-    int subseq_bytes,
-    hipStream_t stream)
+void extend(JobExtent& e, const ScanJob& job)
 {
-    if (num_chunks == 0) return hipSuccess;
-    int shift = 0;
-    while ((1 << shift) < subseq_bytes) ++shift;
-    destuff_kernel<<<num_chunks, 256, 0, stream>>>(d_bytes, d_destuffed, d_seg_idx, d_chunks, shift);
-    return hipGetLastError();
+    e.max_chunks      = job.num_chunks > e.max_chunks ? job.num_chunks : e.max_chunks;
+    e.max_seq         = job.num_seq > e.max_seq ? job.num_seq : e.max_seq;
+    const int blocks  = (job.ip.num_du + kIdctDuPerBlock - 1) / kIdctDuPerBlock;
+    e.max_idct_blocks = blocks > e.max_idct_blocks ? blocks : e.max_idct_blocks;
+    e.max_coef_bytes  = job.coef_bytes > e.max_coef_bytes ? job.coef_bytes : e.max_coef_bytes;
+    e.max_tab_bytes   = job.sp.tab_bytes > e.max_tab_bytes ? job.sp.tab_bytes : e.max_tab_bytes;
+    e.subseq_words    = job.sp.subseq_words;
+    e.max_tail_parts  = job.num_tail_parts > e.max_tail_parts ? job.num_tail_parts : e.max_tail_parts;
 }
 
-hipError_t launch_huffman_stage(
-    HuffStage which,
-    const uint8_t* d_destuffed,
-    const Segment* d_segments,
-    const int* d_seg_idx,
-    const uint8_t* d_tables,
-    const ScanParams& sp,
-    SubseqState st,
-    SeqTails tails,
-    int16_t* d_coef,
-    hipStream_t stream)
+hipError_t launch_stage(Stage stage, const ScanJob& job, hipStream_t stream)
 {
-    if (sp.num_subseq == 0) return hipSuccess;
-    const uint32_t* scan32 = reinterpret_cast<const uint32_t*>(d_destuffed);
-    switch (sp.subseq_words) {
-    case 8: return launch_huffman_w<8>(which, scan32, d_segments, d_seg_idx, d_tables, sp, st, tails, d_coef, stream);
-    case 16: return launch_huffman_w<16>(which, scan32, d_segments, d_seg_idx, d_tables, sp, st, tails, d_coef, stream);
-    case 32: return launch_huffman_w<32>(which, scan32, d_segments, d_seg_idx, d_tables, sp, st, tails, d_coef, stream);
-    }
-    return hipErrorInvalidValue;
+    JobExtent e;
+    extend(e, job);
+    return launch_any(stage, JobByValue{job}, e, 1, stream);
 }
 
-hipError_t launch_idct(
-    const int16_t* d_coef, const uint8_t* d_qtables, const IdctParams& ip, hipStream_t stream)
+hipError_t launch_stage_batch(
+    Stage stage, const ScanJob* d_jobs, int num_jobs, const JobExtent& extent, hipStream_t stream)
 {
-    if (ip.num_du == 0) return hipSuccess;
-    const int blocks = (ip.num_du + kIdctDuPerBlock - 1) / kIdctDuPerBlock;
-    idct_kernel<<<blocks, 256, 0, stream>>>(d_coef, d_qtables, ip);
-    return hipGetLastError();
+    if (num_jobs <= 0) return hipSuccess;
+    return launch_any(stage, JobArray{d_jobs}, extent, num_jobs, stream);
 }
 
 hipError_t launch_upsample(

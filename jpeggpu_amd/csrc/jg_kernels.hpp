@@ -8,52 +8,39 @@
 
 namespace jg {
 
-/// Per-subsequence synchronisation state in device memory, structure-of-arrays
-/// (reference `subsequence_info`, src/decode_huffman.cu:71-89, plus the DC sums).
-struct SubseqState {
-    int* p;             // bit position after the last committed symbol, relative to the segment
-    int* n;             // coefficient slots committed
-    int* cz;            // c | z << 8
-    uint32_t* dc01;     // wrapping 16-bit sums of committed DC differences, scan components 0 | 1 << 16
-    uint32_t* dc23;     // scan components 2 | 3 << 16
-};
-
-/// Per-sequence (workgroup) aggregate used to place the write pass without a device-wide scan.
-struct SeqTails {
-    int* n;
-    uint32_t* dc01;
-    uint32_t* dc23;
-};
-
 bool subseq_bytes_supported(int subseq_bytes);
 
-hipError_t launch_destuff(
-    const uint8_t* d_bytes,
-    uint8_t* d_destuffed,
-    int* d_seg_idx,
-    const DestuffChunk* d_chunks,
-    int num_chunks,
-    int subseq_bytes,
-    hipStream_t stream);
+/// Stages of one decode, in launch order (also the indices of jpeggpu_ext_get_stage_ms).
+enum Stage {
+    kStageZero      = 0, // zero-fill of the coefficient buffer (only non-zeros are stored later)
+    kStageDestuff   = 1,
+    kStageSyncIntra = 2,
+    kStageSyncInter = 3, // huff_sync_tail: sequence boundaries + flows the intra kernel left unfinished
+    kStageTails     = 4,
+    kStageWrite     = 5,
+    kStageIdct      = 6,
+    kNumStages      = 7
+};
 
-/// The four Huffman launches of one scan, in order. `which` selects one of them so the caller can
-/// place timing events between the kernels.
-enum HuffStage { kHuffSyncIntra = 0, kHuffSyncInter = 1, kHuffTails = 2, kHuffWrite = 3 };
+/// Work extents of a launch: the largest count over the jobs it covers (blocks beyond a job's own
+/// count exit at once).
+struct JobExtent {
+    int max_chunks      = 0;
+    int max_seq         = 0;
+    int max_tail_parts  = 0;
+    int max_idct_blocks = 0;
+    uint64_t max_coef_bytes = 0;
+    int subseq_words    = 0; // identical for every job of a launch
+    uint32_t max_tab_bytes = 0;
+};
+void extend(JobExtent& e, const ScanJob& job);
 
-hipError_t launch_huffman_stage(
-    HuffStage which,
-    const uint8_t* d_destuffed,
-    const Segment* d_segments,
-    const int* d_seg_idx,
-    const uint8_t* d_tables, // the scan's table pack (jg_defs.h)
-    const ScanParams& sp,
-    SubseqState st,
-    SeqTails tails,
-    int16_t* d_coef, // stream-order coefficients, must be zero-filled
-    hipStream_t stream);
+/// One stage for ONE job passed by value as a kernel argument (the drop-in single-image API).
+hipError_t launch_stage(Stage stage, const ScanJob& job, hipStream_t stream);
 
-hipError_t launch_idct(
-    const int16_t* d_coef, const uint8_t* d_qtables, const IdctParams& ip, hipStream_t stream);
+/// One stage for `num_jobs` jobs stored in device memory, one per blockIdx.y (the batch API).
+hipError_t launch_stage_batch(
+    Stage stage, const ScanJob* d_jobs, int num_jobs, const JobExtent& extent, hipStream_t stream);
 
 /// Nearest-neighbour replication of one plane: dst[y][x] = src[y * num_y / den_y][x * num_x / den_x]
 /// (integer part of the reference's host helper util/util.h:62-91).

@@ -432,6 +432,14 @@ jpeggpu_status Reader::walk_scan(Scan& scan, const Logger& log)
         return JPEGGPU_INVALID_JPEG;
     }
     s.xfer_end = scan.end;
+    // Flows never cross a segment, so runs of whole segments can be synchronised by independent
+    // workgroups: cut the scan at segment starts into parts of about kTailPartSubseq subsequences.
+    scan.tail_parts.clear();
+    scan.tail_parts.push_back(0);
+    for (const Segment& seg : scan.segments) {
+        if (seg.subseq_offset - scan.tail_parts.back() >= kTailPartSubseq) scan.tail_parts.push_back(seg.subseq_offset);
+    }
+    scan.tail_parts.push_back(scan.num_subseq);
     return JPEGGPU_SUCCESS;
 }
 

@@ -64,6 +64,7 @@ struct Scan {
     uint16_t ac_off[kMaxComp] = {};
     std::vector<Segment> segments;
     std::vector<DestuffChunk> chunks;
+    std::vector<int> tail_parts; // subsequence ranges [parts[i], parts[i+1]) cut at segment starts
 };
 
 struct Stream {

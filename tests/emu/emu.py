@@ -20,7 +20,7 @@ def lib():
             subprocess.check_call(["g++", "-O2", "-std=c++17", "-shared", "-fPIC", "-I" + os.path.join(ROOT, "include"),
                                    "-I" + os.path.join(ROOT, "jpeggpu_amd", "csrc")] + srcs + ["-o", _LIB])
         _lib = C.CDLL(_LIB)
-        _lib.emu_decode_scan.argtypes = [C.c_char_p, C.c_size_t, C.c_int, C.c_int] + [C.c_void_p] * 10
+        _lib.emu_decode_scan.argtypes = [C.c_char_p, C.c_size_t, C.c_int, C.c_int, C.c_int] + [C.c_void_p] * 10
     return _lib
 
 
@@ -28,9 +28,9 @@ class EmuScan:
     pass
 
 
-def decode_scan(data: bytes, scan_idx: int, subseq_bytes: int):
+def decode_scan(data: bytes, scan_idx: int, subseq_bytes: int, max_intra_iters: int = 256):
     ns, nd, it = C.c_int(), C.c_int(), C.c_int()
-    rc = lib().emu_decode_scan(data, len(data), subseq_bytes, scan_idx, C.byref(ns), C.byref(nd),
+    rc = lib().emu_decode_scan(data, len(data), subseq_bytes, max_intra_iters, scan_idx, C.byref(ns), C.byref(nd),
                                None, None, None, None, None, None, None, None)
     if rc:
         return rc, None
@@ -42,7 +42,7 @@ def decode_scan(data: bytes, scan_idx: int, subseq_bytes: int):
     r.dc = np.zeros((4, S), np.int32)
     r.coef = np.zeros((D, 64), np.int16)
     ptr = lambda a: a.ctypes.data if a.size else None
-    rc = lib().emu_decode_scan(data, len(data), subseq_bytes, scan_idx, None, None, ptr(r.destuffed),
+    rc = lib().emu_decode_scan(data, len(data), subseq_bytes, max_intra_iters, scan_idx, None, None, ptr(r.destuffed),
                                ptr(r.seg_index), ptr(r.p), ptr(r.n), ptr(r.cz), ptr(r.dc), r.coef.ctypes.data,
                                C.byref(it))
     r.max_flow_iters = it.value

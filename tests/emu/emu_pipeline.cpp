@@ -84,11 +84,14 @@ void emu_destuff(const uint8_t* bytes, const Scan& sc, int subseq_bytes, std::ve
 
 extern "C" {
 
+int g_active_hist[512];
+
 /// Returns a jpeggpu_status. Outputs are for scan `scan_idx`; pointers may be null.
 int emu_decode_scan(
     const uint8_t* data,
     size_t size,
     int subseq_bytes,
+    int max_intra_iters, // cap of the lock-step loop of huff_sync_intra (kSeqLanes = no cap)
     int scan_idx,
     int* out_num_subseq,
     int* out_num_du,
@@ -153,6 +156,8 @@ int emu_decode_scan(
         bool flowing;
     };
 
+    std::vector<uint8_t> pend(S, 0);
+
     // ---- intra-sequence (huff_sync_intra) ----
     const int num_seq = (S + T - 1) / T;
     for (int b = 0; b < num_seq; ++b) {
@@ -175,8 +180,10 @@ int emu_decode_scan(
             o.dc01 = L.s.dc01; o.dc23 = L.s.dc23;
             L.flowing = true;
         }
-        for (int iter = 0; iter < T; ++iter) {
+        int iter = 0;
+        for (; iter < max_intra_iters; ++iter) {
             bool any = false;
+            for (int t = 0; t < nsub; ++t) if (ln[t].flowing && t + 1 + iter < ln[t].lim && iter < 512) ++g_active_hist[iter];
             for (int t = 0; t < nsub; ++t) { // entry j of iteration `iter` is touched by lane t only
                 Lane& L     = ln[t];
                 const int j = t + 1 + iter;
@@ -198,52 +205,62 @@ int emu_decode_scan(
             if (iter + 1 > max_iters) max_iters = iter + 1;
             if (!any) break;
         }
+        if (iter == max_intra_iters) { // flows cut short continue in the tail pass from the entry they reached
+            for (int t = 0; t < nsub; ++t)
+                if (ln[t].flowing && t + 1 + iter < ln[t].lim) pend[first + t + iter] = 1;
+        }
     }
 
-    // ---- inter-sequence (huff_sync_inter), groups of 1024 boundaries in stream order ----
-    for (int base = 1; base < num_seq; base += 1024) {
-        const int nb = std::min(1024, num_seq - base);
-        std::vector<Lane> ln(nb);
-        std::vector<int> jj(nb);
-        for (int t = 0; t < nb; ++t) {
-            const int from    = (base + t) * T - 1;
-            const Segment seg = sc.segments[segi[from]];
-            Lane& L           = ln[t];
-            L.lim             = seg.subseq_offset + seg.subseq_count;
-            jj[t]             = from + 1;
-            L.flowing         = jj[t] < L.lim;
-            if (L.flowing) {
-                L.f       = HostFetch{dst.data() + static_cast<size_t>(seg.subseq_offset) * subseq_bytes, seg.subseq_count * W};
-                L.s       = LaneState{};
-                L.s.p     = st[from].p;
-                L.s.c     = st[from].cz & 0xFF;
-                L.s.z     = st[from].cz >> 8;
-                L.end_bit = (from - seg.subseq_offset + 1) * bits;
-                L.bw.seek(L.s.p, L.f);
-            }
-        }
-        while (true) {
-            bool any = false;
+    // ---- tail pass (huff_sync_tail): sequence boundaries + pending flows, per part, groups of 256 ----
+    for (size_t part = 0; part + 1 < sc.tail_parts.size(); ++part) {
+        const int lo = sc.tail_parts[part], hi = sc.tail_parts[part + 1];
+        std::vector<int> list;
+        for (int sub = lo; sub < hi; ++sub)
+            if (sub + 1 < S && (pend[sub] || (sub + 1) % T == 0)) list.push_back(sub);
+        for (size_t g = 0; g < list.size(); g += 256) {
+            const int nb = static_cast<int>(std::min<size_t>(256, list.size() - g));
+            std::vector<Lane> ln(nb);
+            std::vector<int> jj(nb);
             for (int t = 0; t < nb; ++t) {
-                Lane& L = ln[t];
-                int& j  = jj[t];
-                if (L.flowing && j < L.lim) {
-                    L.s.n = 0;
-                    L.s.dc01 = L.s.dc23 = 0;
-                    L.end_bit += bits;
-                    decode_subsequence(L.s, L.bw, L.f, L.end_bit, tabs, sp, nosink);
-                    St& o        = st[j];
-                    const int cz = L.s.c | (L.s.z << 8);
-                    if (L.s.p == o.p && cz == o.cz) L.flowing = false;
-                    o.p = L.s.p; o.n = L.s.n; o.cz = cz;
-                    o.dc01 = L.s.dc01; o.dc23 = L.s.dc23;
-                    ++j;
-                } else {
-                    L.flowing = false;
+                const int from    = list[g + t];
+                const Segment seg = sc.segments[segi[from]];
+                Lane& L           = ln[t];
+                L.lim             = seg.subseq_offset + seg.subseq_count;
+                jj[t]             = from + 1;
+                L.flowing         = jj[t] < L.lim;
+                if (L.flowing) {
+                    L.f       = HostFetch{dst.data() + static_cast<size_t>(seg.subseq_offset) * subseq_bytes, seg.subseq_count * W};
+                    L.s       = LaneState{};
+                    L.s.p     = st[from].p;
+                    L.s.c     = st[from].cz & 0xFF;
+                    L.s.z     = st[from].cz >> 8;
+                    L.end_bit = (from - seg.subseq_offset + 1) * bits;
+                    L.bw.seek(L.s.p, L.f);
                 }
-                any |= L.flowing && j < L.lim;
             }
-            if (!any) break;
+            while (true) {
+                bool any = false;
+                for (int t = 0; t < nb; ++t) {
+                    Lane& L = ln[t];
+                    int& j  = jj[t];
+                    if (L.flowing && j < L.lim) {
+                        L.s.n = 0;
+                        L.s.dc01 = L.s.dc23 = 0;
+                        L.end_bit += bits;
+                        decode_subsequence(L.s, L.bw, L.f, L.end_bit, tabs, sp, nosink);
+                        St& o        = st[j];
+                        const int cz = L.s.c | (L.s.z << 8);
+                        if (L.s.p == o.p && cz == o.cz) L.flowing = false;
+                        o.p = L.s.p; o.n = L.s.n; o.cz = cz;
+                        o.dc01 = L.s.dc01; o.dc23 = L.s.dc23;
+                        ++j;
+                    } else {
+                        L.flowing = false;
+                    }
+                    any |= L.flowing && j < L.lim;
+                }
+                if (!any) break;
+            }
         }
     }
 

@@ -8,12 +8,14 @@ from tests import cases
 from tests.emu import emu
 
 
-@pytest.mark.parametrize("subseq_bytes", [128, 64, 32])
-def test_emulated_pipeline_equals_sequential_decode(subseq_bytes):
+@pytest.mark.parametrize("subseq_bytes,max_intra_iters", [(128, 256), (64, 256), (32, 256), (128, 3), (32, 1), (64, 0)])
+def test_emulated_pipeline_equals_sequential_decode(subseq_bytes, max_intra_iters):
+    """max_intra_iters < 256 cuts the lock-step loop of the sequence kernel short and hands the
+    unfinished flows to the tail pass (0: every flow runs there)."""
     for name, data in cases.matrix().items():
         nscans = oracle.decode(data).nscans
         for s in range(nscans):
-            rc, r = emu.decode_scan(data, s, subseq_bytes)
+            rc, r = emu.decode_scan(data, s, subseq_bytes, max_intra_iters)
             assert rc == 0, name
             tw = oracle.scan_stages(data, s, subseq_bytes)
             assert np.array_equal(r.destuffed, tw.destuffed), (name, "destuffed bytes")
@@ -27,7 +29,8 @@ def test_emulated_pipeline_equals_sequential_decode(subseq_bytes):
 
 
 def test_emulated_photo(photo_bytes):
-    rc, r = emu.decode_scan(photo_bytes, 0, 128)
     tw = oracle.scan_stages(photo_bytes, 0, 128)
-    assert rc == 0 and np.array_equal(r.coef, tw.stream_coef)
-    assert r.max_flow_iters >= 1
+    for cap in (256, 3):
+        rc, r = emu.decode_scan(photo_bytes, 0, 128, cap)
+        assert rc == 0 and np.array_equal(r.coef, tw.stream_coef)
+        assert r.max_flow_iters >= 1

@@ -141,6 +141,50 @@ def test_upsample_planes(torch_cuda):
             assert np.array_equal(outs[c].cpu().numpy()[:, :W], p[ys][:, xs]), (name, c)
 
 
+def test_batch_decode_equals_single(torch_cuda):
+    """jpeggpu_ext_decode_batch (one launch per stage, grid.y = scan) against the oracle, for a batch of
+    images of different geometry, scan count and table sets, decoded twice through the same handle."""
+    import jpeggpu_amd
+    from oracle import oracle
+
+    torch = torch_cuda
+    m = cases.matrix()
+    names = ["multi_seq_dri", "ni_420_dri", "four_comp_opt", "gray", "multi_seq_nodri", "odd_1x1px", "cfg4_small", "dri_1"]
+    keep, entries, refs = [], [], []
+    total_scans = 0
+    for name in names:
+        dec = jpeggpu_amd.Decoder()
+        info = dec.parse_header(m[name])
+        n, tmp, base, planes = _alloc(torch, dec, info)
+        dec.transfer(base, n, 0)
+        total_scans += dec.layout().num_scans
+        keep.append((dec, tmp, planes))
+        entries.append((dec, [p.data_ptr() for p in planes], [p.stride(0) for p in planes], base, n))
+        refs.append(oracle.decode(m[name]))
+    batch = jpeggpu_amd.Batch(total_scans)
+    scratch = torch.empty(batch.scratch_size, dtype=torch.uint8, device="cuda:0")
+    batch.set_items(entries)
+    for rep, iters in enumerate([3, 0, 1, 256]):  # cap of the sequence kernel's lock-step loop; 0: every flow in the tail kernel
+        batch.set_sync_iterations(iters)
+        for _, _, planes in keep:
+            for p in planes:
+                p.fill_(0xCD)
+        batch.decode(scratch.data_ptr(), 0)
+        torch.cuda.synchronize()
+        for name, ref, (_, _, planes) in zip(names, refs, keep):
+            for c in range(ref.ncomp):
+                assert np.array_equal(planes[c].cpu().numpy(), ref.planes[c]), (name, c, rep)
+    # too small a scratch / handle is rejected
+    small = jpeggpu_amd.Batch(1)
+    small.set_items(entries)
+    with pytest.raises(jpeggpu_amd.JpegGpuError):
+        small.decode(scratch.data_ptr(), 0)
+    small.destroy()
+    batch.destroy()
+    for dec, _, _ in keep:
+        dec.cleanup()
+
+
 @pytest.mark.parametrize("cfg", [2, 4, 5])
 def test_baseline_configs_full_size(torch_cuda, cfg):
     """BASELINE.json configs 2, 4 (39 MP, three non-interleaved scans) and 5 (4 components, 4+4

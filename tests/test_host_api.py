@@ -100,7 +100,8 @@ def test_layout_matches_oracle_segment_walk(L, photo_bytes, subseq_bytes):
             li = oracle.scan_info(data, s, subseq_bytes)
             sl = lay.scans[s]
             assert (sl.num_subsequences, sl.num_segments, sl.num_data_units) == (li.num_subseq, li.num_segments, li.num_du), name
-            assert sl.num_sequences == (li.num_subseq + 255) // 256
+            per = lay.subsequences_per_sequence
+            assert sl.num_sequences == (li.num_subseq + per - 1) // per
         assert dec.get_buffer_size() % 256 == 0
         dec.cleanup()
 
@@ -109,7 +110,8 @@ def test_photo_buffer_is_smaller_than_the_references(L, photo_bytes):
     dec = jpeggpu_amd.Decoder(128)
     dec.parse_header(photo_bytes)
     lay = dec.layout()
-    assert lay.scans[0].num_sequences == 89                 # README.md:37
+    assert lay.scans[0].num_subsequences == 22711 and (22711 + 255) // 256 == 89  # README.md:37-38
+    assert lay.scans[0].num_sequences == -(-22711 // lay.subsequences_per_sequence)
     assert lay.transferred_bytes < 2_907_282 + 64           # scan bytes only, not the 4 MB file (B-7)
     assert dec.get_buffer_size() < 50 * 2 ** 20             # the reference needs ~116 MB
     dec.cleanup()
