@@ -39,7 +39,7 @@ def parse_args():
                     help="batch: jpeggpu_ext_decode_batch, one launch per stage per group of images; "
                          "streams: the drop-in jpeggpu_decoder_decode, one image per call")
     ap.add_argument("--streams", type=int, default=0,
-                    help="HIP streams (batch mode: groups of images, default 2; streams mode: default 16)")
+                    help="HIP streams (batch mode: groups of images, default 4; streams mode: default 16)")
     ap.add_argument("--unique", type=int, default=2, help="distinct synthetic images per rank (seeded)")
     ap.add_argument("--workload", default="cfg2", choices=["cfg2", "photo"])
     ap.add_argument("--subseq-bytes", type=int, default=0, help="0 = library default")
@@ -106,8 +106,15 @@ def algorithmic_bytes(slot):
         "stuffed": stuffed,
         "b_dh": stuffed + 128 * ndu,
         "b_e2e": stuffed + slot.plane_bytes,
-        # sync_intra: destuffed bytes read once + subsequence->segment map read + 20 B of state written
-        "sync_intra": nsub * lay.subsequence_bytes + nsub * 4 + nsub * 20,
+        # per-kernel algorithmic bytes
+        "zero": 128 * ndu,
+        "destuff": 2 * stuffed,
+        # sync_intra: destuffed bytes read once + subsequence->segment map read + 21 B of state written
+        "sync_intra": nsub * lay.subsequence_bytes + nsub * 4 + nsub * 21,
+        # sync_tail: about one subsequence of bitstream per subsequence (the live flows decay
+        # geometrically, summing to ~0.9 lane-passes) + state read and written
+        "sync_inter": nsub * lay.subsequence_bytes + nsub * 40,
+        "tails": nsub * 16,
         # write pass: destuffed bytes + state read, coefficient buffer written (128 B per data unit)
         "write": nsub * lay.subsequence_bytes + nsub * 24 + 128 * ndu,
         "idct": 128 * ndu + slot.plane_bytes,
@@ -165,15 +172,22 @@ def main():
             raise SystemExit("bench.py --gpus %d must be launched with torch.distributed.run" % args.gpus)
         args.gpus = world
     assert torch.cuda.is_available(), "bench.py needs a HIP device (there is no CPU fallback)"
-    torch.cuda.set_device(local_rank)
-    device = torch.device("cuda", local_rank)
+    # JPEGGPU_BENCH_BACKEND=gloo rehearses the N > 1 control flow on a box with fewer GPUs than ranks
+    # (ranks share devices, timing reduction on the CPU); the driver's runs use nccl (= RCCL).
+    backend = os.environ.get("JPEGGPU_BENCH_BACKEND", "nccl")
+    dev_index = local_rank % torch.cuda.device_count() if backend == "gloo" else local_rank
+    torch.cuda.set_device(dev_index)
+    device = torch.device("cuda", dev_index)
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", device_id=device)
+        if backend == "nccl":
+            dist.init_process_group("nccl", device_id=device)
+        else:
+            dist.init_process_group(backend)
 
     images = make_images(args, rank, world)
     if args.streams <= 0:
-        args.streams = 2 if args.mode == "batch" else 16
+        args.streams = 4 if args.mode == "batch" else 16
     nstreams = max(1, min(args.streams, args.batch))
     streams = [torch.cuda.Stream(device=device) for _ in range(nstreams)]
 
@@ -189,6 +203,8 @@ def main():
         s.transfer(streams[i % nstreams].cuda_stream)
     torch.cuda.synchronize()
     gather_list = None
+    if backend != "nccl":
+        args.gather = False  # the plane gather is an RCCL collective on device buffers
     if world > 1 and args.gather and rank == 0:
         gather_list = [torch.empty_like(planes_flat) for _ in range(world)]
 
@@ -238,7 +254,7 @@ def main():
     torch.cuda.synchronize()
     elapsed = time.perf_counter() - t0
     if world > 1:
-        t = torch.tensor([elapsed], dtype=torch.float64, device=device)
+        t = torch.tensor([elapsed], dtype=torch.float64, device=device if backend == "nccl" else "cpu")
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
 
@@ -277,11 +293,13 @@ def main():
         solo = {k: v * 1e3 for k, v in s0.dec.stage_ms().items()}  # us, mean of 10 single-image decodes
 
         dom = max(stage_us, key=stage_us.get)
-        dom_key = {"sync_intra": "sync_intra", "write": "write", "idct": "idct"}.get(dom)
-        dom_bytes = ab.get(dom_key) * images_per_launch if dom_key else None
+        dom_bytes = ab[dom] * images_per_launch
+        kernel_names = {"zero": "zero_kernel", "destuff": "destuff_kernel", "sync_intra": "huff_sync_intra",
+                        "sync_inter": "huff_sync_tail", "tails": "huff_seq_tails", "write": "huff_write",
+                        "idct": "idct_kernel"}
         t_pass_us = sum(stage_us[k] for k in ("zero", "destuff", "sync_intra", "sync_inter", "tails", "write"))
         roofline = {
-            "bound": "hbm", "kernel": "huff_" + dom if dom.startswith("sync") or dom == "write" else dom,
+            "bound": "hbm", "kernel": kernel_names[dom],
             "achieved": (dom_bytes / (stage_us[dom] * 1e-6) / 1e9) if dom_bytes and stage_us[dom] > 0 else None,
             "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": None, "traffic": None,
             "algorithmic_bytes_per_launch": dom_bytes, "avg_launch_us": stage_us[dom],
@@ -290,12 +308,21 @@ def main():
         if roofline["achieved"] is not None:
             roofline["frac"] = roofline["achieved"] / HBM_PEAK_GBS
         pmc = os.path.join(ROOT, "profiles", "pmc_traffic.json")
-        if os.path.exists(pmc):  # HBM bytes per launch from separate rocprofv3 --pmc passes (profiles/)
+        all_kernels = {}
+        pmc_traffic = {}
+        if os.path.exists(pmc):  # HBM bytes per image from separate rocprofv3 --pmc passes (profiles/)
             try:
                 with open(pmc) as f:
-                    roofline["traffic"] = json.load(f).get(roofline["kernel"])
+                    pmc_traffic = json.load(f)
             except Exception:
-                pass
+                pmc_traffic = {}
+        for k, us in stage_us.items():
+            t = pmc_traffic.get(kernel_names[k], {}).get("per_image_bytes")
+            all_kernels[kernel_names[k]] = {
+                "avg_launch_us": us, "algorithmic_bytes_per_launch": ab[k] * images_per_launch,
+                "achieved_GBs": ab[k] * images_per_launch / (us * 1e-6) / 1e9 if us > 0 else None,
+                "traffic_bytes_per_launch": t * images_per_launch if t else None}
+        roofline["traffic"] = all_kernels[kernel_names[dom]]["traffic_bytes_per_launch"]
         out = {
             "metric": "images/s (12 MP 4:2:0 baseline JPEG decode, inputs resident in HBM)",
             "value": value, "unit": "images/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
@@ -319,6 +346,7 @@ def main():
                 "frac_of_hbm_peak": ab["b_dh"] * value / world / 1e9 / HBM_PEAK_GBS},
             "roofline_e2e": {"bytes_per_image": ab["b_e2e"], "throughput_GBs": ab["b_e2e"] * value / world / 1e9,
                              "frac_of_hbm_peak": ab["b_e2e"] * value / world / 1e9 / HBM_PEAK_GBS},
+            "kernels": all_kernels,
             "stage_us_under_load": stage_us, "stage_us_solo": solo,
             "latency_ms": {"protocol": "parse+size+transfer+decode+sync, 1 image, 1 stream, pinned input",
                            "p50": statistics.median(lat), "mean": statistics.fmean(lat), "max": max(lat),

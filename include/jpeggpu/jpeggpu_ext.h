@@ -105,7 +105,7 @@ enum jpeggpu_status jpeggpu_ext_decode_batch(
     jpeggpu_stream_t stream);
 enum jpeggpu_status jpeggpu_ext_batch_destroy(jpeggpu_batch_t batch);
 /* Lock-step flow iterations inside the per-sequence sync kernel before unfinished flows are handed to
- * the low-footprint tail kernel (default 3; the drop-in decode keeps all flows in the sequence kernel). */
+ * the low-footprint, re-packing tail kernel (default 1; the drop-in decode keeps all flows in the sequence kernel). */
 enum jpeggpu_status jpeggpu_ext_batch_set_sync_iterations(jpeggpu_batch_t batch, int iterations);
 /* Stage timing of batched decodes; same contract as jpeggpu_ext_set_profiling / _get_stage_ms. */
 enum jpeggpu_status jpeggpu_ext_batch_set_profiling(jpeggpu_batch_t batch, int enable);

@@ -560,7 +560,7 @@ struct jpeggpu_batch {
     hipEvent_t copied[kRing]    = {};
     bool in_use[kRing]          = {};
     int next                    = 0;
-    int sync_iters              = 3; // throughput: short-lived sync workgroups, stragglers go to the tail kernel
+    int sync_iters              = 1; // throughput: speculate + verify in the sequence kernel, the rest in the tail kernel
     std::vector<jg::ScanJob> jobs;
     // optional stage timing, same contract as the decoder's
     bool profiling = false;

@@ -355,23 +355,53 @@ __global__ __launch_bounds__(T) void huff_sync_intra(JS js)
 // Huffman: inter-sequence synchronisation
 // ------------------------------------------------------------------------------------------------
 
+constexpr int TL = 1024; // lanes of the tail kernel
+
+/// Inclusive block-wide position of the set flags among TL lanes; returns the block total.
+__device__ __forceinline__ int block_rank_1024(bool flag, int* s_wave, int& rank)
+{
+    const unsigned long long m = __ballot(flag);
+    const int before           = __popcll(m & ((1ull << lane_id()) - 1ull));
+    const int w                = threadIdx.x >> 6;
+    __syncthreads(); // previous use of s_wave is over
+    if (lane_id() == 0) s_wave[w] = __popcll(m);
+    __syncthreads();
+    int off = 0, total = 0;
+#pragma unroll
+    for (int k = 0; k < TL / 64; ++k) {
+        const int c = s_wave[k];
+        off += k < w ? c : 0;
+        total += c;
+    }
+    rank = off + before;
+    return total;
+}
+
 /// Continues, from global state, every flow that huff_sync_intra could not finish: one flow per
 /// sequence boundary (carry the exit state of the last subsequence of sequence b-1 into sequence b,
 /// b+1, ... until it meets the stored state or the segment ends) and one per pending mark. A flow
 /// never leaves its segment, so the scan is cut at segment starts into parts that independent
 /// workgroups own. Inside a part all flows advance in lock-step, one subsequence per iteration, and
-/// groups of blockDim flows are processed in stream order, so a flow that started further upstream
-/// always overwrites later and, unlike the reference (Appendix B-4), no pair
-/// of flows is left unordered. Bitstream words come straight from the destuffed buffer, one refill
-/// ahead, so only the Huffman tables need LDS. With the overlap lanes of huff_sync_intra a boundary
-/// flow normally confirms the stored state in its first iteration; this kernel is what makes the
-/// result exact.
+/// groups of TL flows are processed in stream order, so a flow that started further upstream always
+/// overwrites later and, unlike the reference (Appendix B-4), no pair of
+/// flows is left unordered.
+///
+/// About half of the live flows synchronise in every iteration. The survivors are re-packed into the
+/// lowest lanes after each iteration (their state is five words; the bit window is re-seeked from
+/// `p`), so whole waves drop out and the cost follows the geometric decay instead of staying at one
+/// full pass per iteration. Bitstream words come straight from the destuffed buffer, one refill
+/// ahead; only the Huffman tables and the repacking buffer need LDS. With the overlap lanes of
+/// huff_sync_intra a boundary flow normally confirms the stored state in its first iteration; this
+/// kernel is what makes the result exact.
 template <int W, class JS>
-__global__ __launch_bounds__(256) void huff_sync_tail(JS js)
+__global__ __launch_bounds__(TL) void huff_sync_tail(JS js)
 {
     extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
-    uint8_t* s_tab = smem;
-    __shared__ int s_wave[4];
+    __shared__ int s_wave[TL / 64];
+    int* s_j       = reinterpret_cast<int*>(smem); // next subsequence of a surviving flow
+    int* s_pz      = s_j + TL;                     // its bit position
+    int* s_cz      = s_pz + TL;                    // its c | z << 8
+    uint8_t* s_tab = reinterpret_cast<uint8_t*>(s_cz + TL);
 
     const ScanJob& J = js.get();
     if (static_cast<int>(blockIdx.x) >= J.num_tail_parts) return;
@@ -384,71 +414,70 @@ __global__ __launch_bounds__(256) void huff_sync_tail(JS js)
 
     // ordered list of flow origins in [lo, hi)
     int count = 0;
-    for (int base = lo; base < hi; base += 256) {
+    for (int base = lo; base < hi; base += TL) {
         const int sub = base + tid;
         const bool f  = sub < hi && sub + 1 < sp.num_subseq && (J.pending[sub] != 0 || (sub + 1) % SEQ == 0);
-        const unsigned long long m = __ballot(f);
-        const int before           = __popcll(m & ((1ull << lane_id()) - 1ull));
-        __syncthreads();
-        if (lane_id() == 0) s_wave[tid >> 6] = __popcll(m);
-        __syncthreads();
-        int off = 0, total = 0;
-#pragma unroll
-        for (int k = 0; k < 4; ++k) {
-            off += k < (tid >> 6) ? s_wave[k] : 0;
-            total += s_wave[k];
-        }
-        if (f) J.flow_list[lo + count + off + before] = sub;
+        int rank;
+        const int total = block_rank_1024(f, s_wave, rank);
+        if (f) J.flow_list[lo + count + rank] = sub;
         count += total;
     }
     __syncthreads(); // list and tables visible to the whole workgroup
 
     NoSink sink;
-    for (int g = 0; g < count; g += 256) {
-        LaneState st{};
-        BitWindow<GlobalFetch> bw{};
-        GlobalFetch fetch{nullptr, 0};
-        int end_bit  = 0;
-        int j        = 0; // global index of the subsequence flowed into next
-        int lim      = 0;
-        bool flowing = false;
+    for (int g = 0; g < count; g += TL) {
+        // a flow between iterations: it has reached subsequence j - 1 with state (p, c, z)
+        int j = 0, p = 0, cz = 0;
+        bool live = false;
         if (g + tid < count) {
-            const int from    = J.flow_list[lo + g + tid];
-            const Segment seg = J.segments[J.seg_idx[from]];
-            lim               = seg.subseq_offset + seg.subseq_count;
-            j                 = from + 1;
-            flowing           = j < lim;
-            if (flowing) {
-                fetch.words     = scan32 + static_cast<size_t>(seg.subseq_offset) * W;
-                fetch.seg_words = seg.subseq_count * W;
-                st.p            = J.st_p[from];
-                const int cz    = J.st_cz[from];
-                st.c            = cz & 0xFF;
-                st.z            = cz >> 8;
-                end_bit         = (from - seg.subseq_offset + 1) * (W * 32);
-                bw.seek(st.p, fetch);
-            }
+            const int from = J.flow_list[lo + g + tid];
+            j              = from + 1;
+            p              = J.st_p[from];
+            cz             = J.st_cz[from];
+            live           = true;
         }
         while (true) {
-            if (flowing && j < lim) {
-                st.n    = 0;
-                st.dc01 = 0;
-                st.dc23 = 0;
-                end_bit += W * 32;
-                decode_subsequence(st, bw, fetch, end_bit, s_tab, sp, sink);
-                const int cz = st.c | (st.z << 8);
-                if (st.p == J.st_p[j] && cz == J.st_cz[j]) flowing = false;
-                J.st_p[j]    = st.p;
-                J.st_n[j]    = st.n;
-                J.st_cz[j]   = cz;
-                J.st_dc01[j] = st.dc01;
-                J.st_dc23[j] = st.dc23;
-                ++j;
-            } else {
-                flowing = false;
+            bool flowing = false;
+            if (live) {
+                const Segment seg = J.segments[J.seg_idx[j - 1]];
+                const int lim     = seg.subseq_offset + seg.subseq_count;
+                if (j < lim) {
+                    GlobalFetch fetch{scan32 + static_cast<size_t>(seg.subseq_offset) * W, seg.subseq_count * W};
+                    LaneState st{};
+                    st.p = p;
+                    st.c = cz & 0xFF;
+                    st.z = cz >> 8;
+                    BitWindow<GlobalFetch> bw{};
+                    bw.seek(st.p, fetch);
+                    decode_subsequence(st, bw, fetch, (j - seg.subseq_offset + 1) * (W * 32), s_tab, sp, sink);
+                    p        = st.p;
+                    cz       = st.c | (st.z << 8);
+                    flowing  = !(p == J.st_p[j] && cz == J.st_cz[j]) && j + 1 < lim;
+                    J.st_p[j]    = p;
+                    J.st_n[j]    = st.n;
+                    J.st_cz[j]   = cz;
+                    J.st_dc01[j] = st.dc01;
+                    J.st_dc23[j] = st.dc23;
+                    ++j;
+                }
             }
-            // barrier + workgroup-scope fence: next iteration's reads see this iteration's stores
-            if (!__syncthreads_or(flowing && j < lim)) break;
+            // re-pack the survivors into the lowest lanes (also the barrier + workgroup-scope fence
+            // that makes this iteration's state stores visible to the next one)
+            int rank;
+            const int total = block_rank_1024(flowing, s_wave, rank);
+            if (total == 0) break;
+            if (flowing) {
+                s_j[rank]  = j;
+                s_pz[rank] = p;
+                s_cz[rank] = cz;
+            }
+            __syncthreads();
+            live = tid < total;
+            if (live) {
+                j  = s_j[tid];
+                p  = s_pz[tid];
+                cz = s_cz[tid];
+            }
         }
         __syncthreads();
     }
@@ -831,7 +860,8 @@ hipError_t launch_huff(Stage stage, const JS& js, const JobExtent& e, int grid_y
         huff_sync_intra<W, JS><<<dim3(e.max_seq, grid_y), T, seq_lds, stream>>>(js);
         break;
     case kStageSyncInter:
-        if (e.max_tail_parts > 0) huff_sync_tail<W, JS><<<dim3(e.max_tail_parts, grid_y), 256, e.max_tab_bytes, stream>>>(js);
+        if (e.max_tail_parts > 0)
+            huff_sync_tail<W, JS><<<dim3(e.max_tail_parts, grid_y), TL, 3 * TL * 4 + e.max_tab_bytes, stream>>>(js);
         break;
     case kStageWrite:
         if ((err = allow_lds(huff_write<W, JS>, seq_lds)) != hipSuccess) return err;
