@@ -47,7 +47,10 @@ struct jpeggpu_ext_scan_layout {
     size_t off_state_dc01;     /* uint32[num_subsequences]: wrapping 16-bit DC-difference sums of scan
                                   components 0 (low half) and 1 (high half) */
     size_t off_state_dc23;     /* same for scan components 2 and 3 */
-    size_t off_coefficients;   /* int16[num_data_units * 64], stream order, natural order inside */
+    size_t off_symbols;        /* uint32[num_subsequences * symbol_region_entries]: zig-zag position << 16 |
+                                  16-bit coefficient, one region per subsequence */
+    size_t off_du_table;       /* {uint32 first entry, uint32 count}[num_data_units], stream order */
+    int symbol_region_entries;
 };
 
 struct jpeggpu_ext_layout {
@@ -68,7 +71,7 @@ enum jpeggpu_status jpeggpu_ext_get_layout(jpeggpu_decoder_t decoder, struct jpe
  * mean milliseconds per stage (summed over scans) of the decodes since the previous call (at most the
  * last 64), and starts a new measurement window. */
 enum jpeggpu_ext_stage {
-    JPEGGPU_EXT_STAGE_ZERO       = 0, /* zero-fill of the coefficient buffer */
+    JPEGGPU_EXT_STAGE_ZERO       = 0, /* unused (always 0): nothing is zero-filled any more */
     JPEGGPU_EXT_STAGE_DESTUFF    = 1,
     JPEGGPU_EXT_STAGE_SYNC_INTRA = 2,
     JPEGGPU_EXT_STAGE_SYNC_INTER = 3,

@@ -47,7 +47,7 @@ class ExtScanLayout(C.Structure):
         ("off_segments", C.c_size_t), ("off_chunks", C.c_size_t), ("off_destuffed", C.c_size_t),
         ("off_segment_index", C.c_size_t), ("off_state_p", C.c_size_t), ("off_state_n", C.c_size_t),
         ("off_state_cz", C.c_size_t), ("off_state_dc01", C.c_size_t), ("off_state_dc23", C.c_size_t),
-        ("off_coefficients", C.c_size_t),
+        ("off_symbols", C.c_size_t), ("off_du_table", C.c_size_t), ("symbol_region_entries", C.c_int),
     ]
 
 

@@ -26,7 +26,8 @@ def build(force: bool = False, verbose: bool = False) -> str:
         return LIB_PATH
     os.makedirs(LIB_DIR, exist_ok=True)
     hipcc = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
-    cmd = [hipcc, "-O3", "-std=c++17", "--offload-arch=gfx950", "-fPIC", "-shared",
+    # -fwrapv: the reference's GPU integer arithmetic wraps; signed overflow must not be undefined (same flag as the oracle)
+    cmd = [hipcc, "-O3", "-std=c++17", "-fwrapv", "--offload-arch=gfx950", "-fPIC", "-shared",
            "-I" + os.path.join(ROOT, "include"), "-I" + CSRC]
     cmd += [os.path.join(CSRC, s) for s in SOURCES]
     cmd += ["-o", LIB_PATH]

@@ -69,7 +69,7 @@ struct ScanPlan {
     // offsets inside d_tmp
     size_t destuffed = 0, seg_idx = 0, st_p = 0, st_n = 0, st_cz = 0, st_dc01 = 0, st_dc23 = 0;
     size_t tails_n = 0, tails_dc01 = 0, tails_dc23 = 0, pending = 0, flow_list = 0;
-    size_t coef = 0;
+    size_t sym = 0, du_tab = 0;
     int num_seq = 0;
 };
 
@@ -77,7 +77,6 @@ struct Plan {
     size_t off_bytes = 0, bytes_len = 0;
     size_t off_blob = 0, blob_size = 0;
     size_t blob_qtables = 0;
-    size_t off_coef_all = 0, coef_all_bytes = 0;
     size_t total = 0;
     ScanPlan scan[kMaxScans];
 };
@@ -174,14 +173,13 @@ void Decoder::make_plan()
         sp.tails_dc23 = o;
         o += align_up(static_cast<size_t>(sp.num_seq) * 4, 256);
     }
-    // all coefficient buffers are contiguous: one memset covers them
-    p.off_coef_all = o;
     for (int i = 0; i < s.num_scans; ++i) {
-        p.scan[i].coef = o;
-        o += align_up(static_cast<size_t>(s.scans[i].num_du) * 128, 256);
+        p.scan[i].sym = o; // symbol stream: a fixed region per subsequence
+        o += align_up(static_cast<size_t>(s.scans[i].num_subseq) * sym_region_entries(subseq_bytes) * 4 + 256, 256);
+        p.scan[i].du_tab = o;
+        o += align_up(static_cast<size_t>(s.scans[i].num_du) * sizeof(uint2_t), 256);
     }
-    p.coef_all_bytes = o - p.off_coef_all;
-    p.total          = o;
+    p.total = o;
     plan             = p;
 }
 
@@ -335,8 +333,10 @@ jpeggpu_status build_jobs(
         job.tails_n    = reinterpret_cast<int*>(base + pl.tails_n);
         job.tails_dc01 = reinterpret_cast<uint32_t*>(base + pl.tails_dc01);
         job.tails_dc23 = reinterpret_cast<uint32_t*>(base + pl.tails_dc23);
-        job.coef       = reinterpret_cast<int16_t*>(base + pl.coef);
-        job.coef_bytes = static_cast<uint64_t>(sc.num_du) * 128;
+        job.sym         = reinterpret_cast<uint32_t*>(base + pl.sym);
+        job.du_tab      = reinterpret_cast<uint2_t*>(base + pl.du_tab);
+        job.sym_region  = sym_region_entries(d.subseq_bytes);
+        job.sym_entries = static_cast<uint64_t>(sc.num_subseq) * job.sym_region + 64;
         job.num_chunks = static_cast<int>(sc.chunks.size());
         job.num_seq    = pl.num_seq;
         jobs.push_back(job);
@@ -548,7 +548,9 @@ enum jpeggpu_status jpeggpu_ext_get_layout(jpeggpu_decoder_t decoder, struct jpe
         o.off_state_p        = pl.st_p;
         o.off_state_n        = pl.st_n;
         o.off_state_cz       = pl.st_cz;
-        o.off_coefficients   = pl.coef;
+        o.off_symbols        = pl.sym;
+        o.off_du_table       = pl.du_tab;
+        o.symbol_region_entries = static_cast<int>(jg::sym_region_entries(d.subseq_bytes));
     }
     return JPEGGPU_SUCCESS;
 }

@@ -67,6 +67,11 @@ JG_HD inline uint32_t huff_entry(int codelen, uint32_t sym, bool is_dc)
     return (static_cast<uint32_t>(codelen) + s) | (s << 6) | ((r + 1u) << 10) | (eob << 15);
 }
 
+/// Entries of the symbol stream reserved per subsequence: an emitted entry (DC, or a non-zero AC
+/// coefficient with its magnitude bits) takes at least 2 bits of the stream on average over a data
+/// unit, plus up to one data unit of overrun (a lane finishes the unit it started).
+JG_HD inline uint32_t sym_region_entries(int subseq_bytes) { return static_cast<uint32_t>(subseq_bytes) * 4u + 64u; }
+
 /// One restart segment of a scan inside the destuffed buffer (reference src/reader.hpp:38-43).
 struct Segment {
     int subseq_offset; // subsequences before this segment
@@ -127,6 +132,10 @@ struct IdctParams {
 
 /// Everything the kernels need to know about one scan of one image: a launch covers one job (passed
 /// by value, the drop-in API) or an array of jobs, one per blockIdx.y (the batch API).
+struct uint2_t {
+    uint32_t x, y;
+};
+
 struct ScanJob {
     const uint8_t* bytes;        // transferred entropy-coded bytes of the image
     const DestuffChunk* chunks;
@@ -147,8 +156,10 @@ struct ScanJob {
     int* tails_n;                // per-sequence aggregates used to place the write pass
     uint32_t* tails_dc01;
     uint32_t* tails_dc23;
-    int16_t* coef;               // stream-order coefficients
-    uint64_t coef_bytes;
+    uint32_t* sym;               // symbol stream: one region of `sym_region` entries per subsequence
+    uint2_t* du_tab;             // per data unit (stream order): {first entry, number of entries}
+    uint32_t sym_region;         // entries per subsequence region
+    uint64_t sym_entries;        // total entries (num_subseq * sym_region)
     int num_chunks;
     int num_seq;
     ScanParams sp;

@@ -141,15 +141,28 @@ JG_HD inline TableSel select_tables(const ScanParams& sp, int c)
 
 /// Sink used by the synchronisation passes: nothing is stored.
 struct NoSink {
-    static constexpr bool kWrite = false;
+    static constexpr bool kWrite      = false;
+    static constexpr bool kWholeUnits = false;
     JG_HD inline bool full() const { return false; }
     JG_HD inline void dc(int, int) {}
-    JG_HD inline void ac(int, int) {}
+    JG_HD inline void ac(int, int, int) {}
     JG_HD inline void advance(int) {}
+    JG_HD inline void unit_end() {}
 };
+
+/// One entry of the symbol stream the write pass emits: a non-zero coefficient (or the absolute DC)
+/// of a data unit, zig-zag position in bits 16..21, 16-bit value in the low half.
+JG_HD inline uint32_t sym_entry(int zpos, int value)
+{
+    return (static_cast<uint32_t>(zpos) << 16) | (static_cast<uint32_t>(value) & 0xFFFFu);
+}
 
 /// Decode from `st` up to bit `end_bit` of the segment, committing symbols that end at or before it.
 /// `st.n`, `st.dc01`, `st.dc23` accumulate. `tabs` is the scan's table pack (LDS on the device).
+///
+/// With Sink::kWholeUnits (write pass) a lane owns whole data units: those whose DC symbol its
+/// subsequence commits. It keeps decoding past `end_bit` until the unit it started is complete, and
+/// the sink ignores the symbols that finish the predecessor's unit.
 ///
 /// ONE flat loop, one symbol per iteration for every lane: the data-unit boundary is handled with
 /// selects, not with a branch -- a branch there makes the compiler nest the loop, and a nested loop
@@ -173,8 +186,9 @@ JG_HD inline void decode_subsequence(
         const uint32_t idx  = is_dc ? peek >> (32 - kLutBitsDc) : peek >> (32 - kLutBitsAc);
         uint32_t e          = ld_u16(tab + 2 * idx);
         if (e == 0) e = huff_long_code(tab + (is_dc ? (2 << kLutBitsDc) : (2 << kLutBitsAc)), peek, is_dc);
-        const int total = e & 63;
-        if (st.p + total > end_bit) break;
+        const int total   = e & 63;
+        const bool beyond = st.p + total > end_bit;
+        if (Sink::kWholeUnits ? (beyond && st.z == 0) : beyond) break;
         bw.skip(total);
         st.p += total;
         const int s    = (e >> 6) & 15;
@@ -188,7 +202,7 @@ JG_HD inline void decode_subsequence(
                 st.dc23          = pk_add_u16(st.dc23, ts.comp < 2 ? 0u : d);
                 sink.dc(ts.comp, v);
             } else if (Sink::kWrite) {
-                if (s) sink.ac(adv - 1, v);
+                if (s) sink.ac(adv - 1, st.z + adv - 1, v);
                 else sink.advance(adv);
             }
         }
@@ -198,6 +212,7 @@ JG_HD inline void decode_subsequence(
         const int c1      = st.c + 1 >= sp.du_per_mcu ? 0 : st.c + 1;
         st.z              = du_end ? 0 : z1;
         st.c              = du_end ? c1 : st.c;
+        if (Sink::kWrite && du_end) sink.unit_end();
         ts                = select_tables(sp, st.c); // a few scalar-operand ALU ops, no memory
     }
 }

@@ -1,13 +1,12 @@
 // jg_kernels.hip -- gfx950 (CDNA4, wave64) kernels of the baseline JPEG decode path.
 //
-//   zero_kernel             zero-fill of the coefficient buffer      (reference decoder.cpp:250-262 memsets)
 //   destuff_kernel          byte-stuffing / restart-marker removal   (reference src/decode_destuff.cu:37-361)
 //   huff_sync_intra         speculative decode + intra-sequence sync (reference decode_huffman.cu:413-524)
 //   huff_sync_tail          inter-sequence sync + unfinished flows   (reference decode_huffman.cu:534-621)
 //   huff_seq_tails          per-sequence sums of n / DC              (replaces cub ExclusiveScanByKey :818-869
 //                                                                     and the DC scans of decode_dc.cu:88-169)
-//   huff_write              final decode, de-zigzag, absolute DC     (reference decode_huffman.cu:627-682)
-//   idct_kernel             dequant + 8x8 fixed-point IDCT reading stream order
+//   huff_write              final decode -> symbol stream, absolute DC (reference decode_huffman.cu:627-682)
+//   idct_kernel             gather + dequant + 8x8 fixed-point IDCT in stream order
 //                                                                    (reference idct.cu:44-223 + decode_transpose.cu:41-132)
 //
 // Everything is integer / bit-serial: no MFMA. Every kernel takes a job source: one ScanJob by
@@ -47,25 +46,6 @@ __device__ __forceinline__ uint32_t wave_incl_scan(uint32_t v)
         if (lane_id() >= d) v += o;
     }
     return v;
-}
-
-// ------------------------------------------------------------------------------------------------
-// zero fill
-// ------------------------------------------------------------------------------------------------
-
-constexpr int kZeroBytesPerBlock = 256 * 16 * 16; // 64 KiB
-
-template <class JS>
-__global__ __launch_bounds__(256) void zero_kernel(JS js)
-{
-    const ScanJob& J    = js.get();
-    const uint64_t base = static_cast<uint64_t>(blockIdx.x) * kZeroBytesPerBlock;
-    if (base >= J.coef_bytes) return;
-    uint4* dst         = reinterpret_cast<uint4*>(reinterpret_cast<uint8_t*>(J.coef) + base);
-    const uint64_t rem = J.coef_bytes - base; // coef_bytes is a multiple of 128
-    const uint64_t n16 = (rem < static_cast<uint64_t>(kZeroBytesPerBlock) ? rem : kZeroBytesPerBlock) / 16;
-    const uint4 z      = make_uint4(0, 0, 0, 0);
-    for (uint64_t i = threadIdx.x; i < n16; i += 256) dst[i] = z;
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -532,18 +512,24 @@ __global__ __launch_bounds__(T) void huff_seq_tails(JS js)
 // Huffman: write pass
 // ------------------------------------------------------------------------------------------------
 
-struct CoefSink {
-    static constexpr bool kWrite = true;
-    int16_t* out;
-    const uint8_t* natural; // LDS copy of the zig-zag -> raster map
+/// Sink of the write pass: a compact symbol stream instead of a dense coefficient buffer. Every lane
+/// appends one 32-bit entry per non-zero coefficient (zig-zag position | value, DC already absolute)
+/// to its own region, contiguous per data unit, and records {first entry, count} per data unit when
+/// the unit completes. A lane owns whole data units (jg_huff_core.h, kWholeUnits), so a unit's entries
+/// never span two regions. Compared with scattered 2-byte stores into a pre-zeroed buffer (reference
+/// decode_huffman.cu:360-371 + decoder.cpp:256-263) this needs no zero-fill and writes each byte once.
+struct StreamSink {
+    static constexpr bool kWrite      = true;
+    static constexpr bool kWholeUnits = true;
+    uint32_t* sym;
+    uint2_t* du_tab;
+    uint32_t cur, cur_end, du_off;
+    int du_index;
     int pos;
     int quota;
     int pred[kMaxComp];
+    bool started; // false while the first symbols finish the predecessor's data unit
     __device__ __forceinline__ bool full() const { return pos >= quota; }
-    __device__ __forceinline__ void store(int v)
-    {
-        if (pos < quota) out[(pos & ~63) + natural[pos & 63]] = static_cast<int16_t>(v);
-    }
     __device__ __forceinline__ void dc(int comp, int diff)
     {
         int v = 0;
@@ -552,16 +538,23 @@ struct CoefSink {
             pred[k] += comp == k ? diff : 0;
             v = comp == k ? pred[k] : v;
         }
-        store(v); // int16 wrap = the reference's int16 prefix sum (decode_dc.cu:129-155)
+        started  = true;
+        du_off   = cur;
+        du_index = pos >> 6;
+        // 16-bit wrap = the reference's int16 prefix sum (decode_dc.cu:129-155)
+        if (cur < cur_end) sym[cur++] = sym_entry(0, v);
         ++pos;
     }
-    __device__ __forceinline__ void ac(int run, int v)
+    __device__ __forceinline__ void ac(int run, int zpos, int v)
     {
-        pos += run;
-        store(v);
-        ++pos;
+        pos += run + 1;
+        if (started && cur < cur_end) sym[cur++] = sym_entry(zpos, v);
     }
     __device__ __forceinline__ void advance(int k) { pos += k; }
+    __device__ __forceinline__ void unit_end()
+    {
+        if (started) du_tab[du_index] = uint2_t{du_off, cur - du_off};
+    }
 };
 
 /// Exclusive prefix over the 256 lanes of `v` (plain, not segmented), result left in s_scan[0..T].
@@ -595,11 +588,12 @@ __device__ __forceinline__ uint32_t pk_sub(uint32_t a, uint32_t b) { return pk_a
 __device__ __forceinline__ int lo16(uint32_t v) { return static_cast<int16_t>(v & 0xFFFFu); }
 __device__ __forceinline__ int hi16(uint32_t v) { return static_cast<int16_t>(v >> 16); }
 
-/// Re-decode every subsequence from its predecessor's synchronised exit state and store the
-/// non-zero coefficients in stream order (data unit after data unit, natural order inside, DC
-/// already absolute). Output position of subsequence i inside its segment = sum of n over the
-/// segment's earlier subsequences: in-sequence part by an LDS scan, earlier sequences via tails.
-/// Lanes SEQ..T-1 have no subsequence here (the sequence is SEQ long); they only help with the scans.
+/// Re-decode every subsequence from its predecessor's synchronised exit state and emit the symbol
+/// stream (StreamSink). The coefficient-slot position of subsequence i inside its segment = sum of n
+/// over the segment's earlier subsequences (in-sequence part by an LDS scan, earlier sequences via
+/// tails); it gives the index of every data unit the lane starts, and the same look-back gives the
+/// DC predictors. Lanes SEQ..T-1 have no subsequence here (the sequence is SEQ long); they only help
+/// with the scans, but their bitstream is staged: a lane may run past its subsequence to finish a unit.
 template <int W, class JS>
 __global__ __launch_bounds__(T) void huff_write(JS js)
 {
@@ -608,7 +602,6 @@ __global__ __launch_bounds__(T) void huff_write(JS js)
     uint32_t* s_scan  = reinterpret_cast<uint32_t*>(smem + SeqLds<W>::kState); // T + 1
     uint32_t* s_wave  = s_scan + T + 1;                                         // 4
     uint32_t* s_carry = s_wave + 4;                                             // 3
-    uint8_t* s_nat    = reinterpret_cast<uint8_t*>(s_carry + 3);                // 64
     uint8_t* s_tab    = smem + SeqLds<W>::kTabs;
 
     const ScanJob& J = js.get();
@@ -620,10 +613,6 @@ __global__ __launch_bounds__(T) void huff_write(JS js)
 
     load_tables(s_tab, J.tables, sp.tab_bytes);
     load_image<W>(s_img, reinterpret_cast<const uint32_t*>(J.destuffed), first_sub, sp.num_subseq);
-    if (t < 64) {
-        constexpr uint8_t nat[64] = JG_ORDER_NATURAL;
-        s_nat[t]                  = nat[t];
-    }
 
     // carry-in of the segment that is open at the sequence's first subsequence
     {
@@ -661,9 +650,9 @@ __global__ __launch_bounds__(T) void huff_write(JS js)
         ts      = carried ? 0 : seg.subseq_offset - first_sub;
     }
 
-    CoefSink sink;
-    sink.out     = J.coef;
-    sink.natural = s_nat;
+    StreamSink sink;
+    sink.sym     = J.sym;
+    sink.du_tab  = J.du_tab;
     int nprefix  = 0;
     {
         block_excl_scan_256<false>(active ? static_cast<uint32_t>(J.st_n[sub]) : 0u, s_scan, s_wave);
@@ -684,6 +673,10 @@ __global__ __launch_bounds__(T) void huff_write(JS js)
     const int seg_mcus1 = min(seg_mcus0 + sp.mcus_per_segment, sp.total_mcus); // Appendix B-5 clamp
     sink.pos            = seg_mcus0 * du_words + nprefix;
     sink.quota          = seg_mcus1 * du_words;
+    sink.cur            = static_cast<uint32_t>(sub) * J.sym_region;
+    sink.cur_end        = sink.cur + J.sym_region;
+    sink.du_off         = sink.cur;
+    sink.du_index       = 0;
 
     LaneState st{};
     if (rel > 0) {
@@ -692,6 +685,7 @@ __global__ __launch_bounds__(T) void huff_write(JS js)
         st.c         = cz & 0xFF;
         st.z         = cz >> 8;
     }
+    sink.started = st.z == 0;
     LdsFetch<W> fetch{s_img, (seg.subseq_offset - first_sub) * W, seg.subseq_count * W};
     BitWindow<LdsFetch<W>> bw{};
     bw.seek(st.p, fetch);
@@ -720,7 +714,8 @@ __device__ __forceinline__ void idct8(int (&v)[8])
 
     const int m0 = unfixo((v[3] + v[5]) * cos_1_4);
     const int m1 = unfixo((v[3] - v[5]) * cos_1_4);
-    const int q1 = v[1] << 2, q7 = v[7] << 2;
+    // x4 written as a multiplication: `<<` on a negative int is undefined before C++20 and hipcc uses that
+    const int q1 = v[1] * 4, q7 = v[7] * 4;
     const int o0 = q1 + m0, o1 = q7 + m1, o2 = q1 - m0, o3 = q7 - m1;
     const int b0 = o0 * ocos_1_16 + o1 * osin_1_16;
     const int b1 = o0 * osin_1_16 - o1 * ocos_1_16;
@@ -737,79 +732,173 @@ __device__ __forceinline__ void idct8(int (&v)[8])
     v[7] = unfixh(a0 - b0);
 }
 
-constexpr int kIdctDuPerBlock = 32;    // 8 lanes per data unit, 256 lanes
-constexpr int kIdctRowStride  = 8 + 2; // int16 per staged row (+2: column reads spread over banks)
+constexpr int kIdctDuPerBlock = 32; // 8 lanes per data unit, 256 lanes
+constexpr int kIdctDuStride   = 64 + 8; // int16 per staged data unit (+8: the 8 units of a wave start on different banks)
 
-/// One data unit per 8 lanes, read straight from the stream-order coefficient buffer (16 bytes =
-/// one row per lane, fully coalesced). Steps and int16 truncation points are those of the reference
-/// `idct_kernel` (src/idct.cu:146-223): (int16)(coef * q) -> column pass -> row pass -> +128 -> clamp.
-/// The MCU geometry (reference decode_transpose.cu:65-131) is applied when the 8x8 pixels are stored.
+__device__ __forceinline__ void unpack8(const uint4& raw, int (&v)[8])
+{
+    const uint32_t w[4] = {raw.x, raw.y, raw.z, raw.w};
+#pragma unroll
+    for (int i = 0; i < 8; ++i) v[i] = static_cast<int16_t>(w[i >> 1] >> (16 * (i & 1)));
+}
+
+constexpr int kIdctIters    = 8;                            // groups of 32 data units per workgroup
+constexpr int kIdctDuPerWg  = kIdctDuPerBlock * kIdctIters; // 256
+
+/// One data unit per 8 lanes, kIdctIters groups of 32 units per workgroup. The unit's entries are
+/// gathered from the symbol stream (consecutive 4-byte reads), de-zigzagged and dequantised on the
+/// way into LDS; everything else is zero. Steps and int16 truncation points are those of the
+/// reference `idct_kernel` (src/idct.cu:146-223): (int16)(coef * q) -> column pass -> row pass ->
+/// +128 -> clamp. The MCU geometry (reference decode_transpose.cu:65-131) is applied when the 8x8
+/// pixels are stored.
+///
+/// Two things bound a naive version: LDS instruction issue and the chain of dependent loads
+/// (table entry -> symbol entries) paid once per tiny workgroup. So the block is staged TRANSPOSED
+/// ([column][row]: zeroing is one 16-byte write, the column pass one 16-byte read), all table
+/// entries of the workgroup are loaded up front, and the first two symbol entries of each lane are
+/// fetched one iteration ahead.
 template <class JS>
 __global__ __launch_bounds__(256) void idct_kernel(JS js)
 {
-    __shared__ int16_t s_blk[kIdctDuPerBlock][8][kIdctRowStride];
+    __shared__ __attribute__((aligned(16))) int16_t s_blk[kIdctDuPerBlock][kIdctDuStride]; // [unit][col * 8 + row]
+    __shared__ uint8_t s_q[4 * 64];
+    __shared__ uint8_t s_nat[64];
+    __shared__ uint2 s_px[kIdctDuPerBlock][9]; // finished pixel rows, [unit][row] (+1: bank spread)
+    // Geometry of the k-th data unit of an MCU, staged once: the job lives in global memory (batch
+    // API), and indexing its small arrays per lane would be a chain of dependent L2 round trips.
+    struct UnitDesc {
+        uint8_t* plane;
+        int pitch, size_x, size_y, h, v, dx, dy, qoff;
+    };
+    __shared__ UnitDesc s_desc[kMaxDuPerMcu];
 
     const ScanJob& J     = js.get();
     const IdctParams& ip = J.ip;
-    if (static_cast<int>(blockIdx.x) * kIdctDuPerBlock >= ip.num_du) return;
+    const int du0        = blockIdx.x * kIdctDuPerWg;
+    const int num_du     = ip.num_du;
+    const int du_per_mcu = ip.du_per_mcu;
+    const int mcus_x     = ip.mcus_x;
+    if (du0 >= num_du) return;
+    if (threadIdx.x < static_cast<unsigned>(du_per_mcu)) {
+        const int k  = threadIdx.x;
+        const int sc = ip.du_comp[k];
+        UnitDesc d;
+        d.plane  = ip.plane[sc];
+        d.pitch  = ip.pitch[sc];
+        d.size_x = ip.size_x[sc];
+        d.size_y = ip.size_y[sc];
+        d.h      = ip.comp_h[sc];
+        d.v      = ip.comp_v[sc];
+        d.dx     = ip.du_dx[k];
+        d.dy     = ip.du_dy[k];
+        d.qoff   = ip.qidx[sc] * 64;
+        s_desc[k] = d;
+    }
 
-    const int t   = threadIdx.x;
-    const int r   = t & 7;  // row (passes 1 and 3) or column (pass 2) handled by this lane
-    const int dl  = t >> 3; // data unit inside the workgroup
-    const int du  = blockIdx.x * kIdctDuPerBlock + dl;
-    const bool in = du < ip.num_du;
+    const int t  = threadIdx.x;
+    const int r  = t & 7;  // column (pass 1) or row (pass 2) handled by this lane
+    const int dl = t >> 3; // data unit inside the group
 
-    const int mcu = du / ip.du_per_mcu;
-    const int k   = du - mcu * ip.du_per_mcu;
-    const int sc  = in ? ip.du_comp[k] : 0;
+    s_q[t] = J.qtables[t];
+    if (t < 64) {
+        constexpr uint8_t nat[64] = JG_ORDER_NATURAL;
+        s_nat[t]                  = nat[t];
+    }
+    int16_t* blk = s_blk[dl];
 
-    int v[8];
-    if (in) {
-        const uint4 raw = *reinterpret_cast<const uint4*>(J.coef + static_cast<size_t>(du) * 64 + r * 8);
-        const uint2 qr  = *reinterpret_cast<const uint2*>(J.qtables + ip.qidx[sc] * 64 + r * 8);
-        const uint32_t cw[4] = {raw.x, raw.y, raw.z, raw.w};
-        const uint32_t qw[2] = {qr.x, qr.y};
+    // table entries of all iterations (independent loads, one latency); a table entry that was never
+    // written (corrupt stream) must not lead out of the buffer
+    uint32_t toff[kIdctIters], tcnt[kIdctIters];
+    const uint64_t limit = J.sym_entries - 64;
 #pragma unroll
-        for (int i = 0; i < 8; ++i) {
-            const int c = static_cast<int16_t>(cw[i >> 1] >> (16 * (i & 1)));
-            const int q = (qw[i >> 2] >> (8 * (i & 3))) & 0xFF; // unsigned (Appendix B-3)
-            s_blk[dl][r][i] = static_cast<int16_t>(c * q);
+    for (int it = 0; it < kIdctIters; ++it) {
+        const int du = du0 + it * kIdctDuPerBlock + dl;
+        uint2_t e{0u, 0u};
+        if (du < num_du) e = J.du_tab[du];
+        tcnt[it] = e.y < 64u ? e.y : 64u;
+        toff[it] = static_cast<uint32_t>(e.x < limit ? e.x : limit);
+    }
+    uint32_t n0 = r < tcnt[0] ? J.sym[toff[0] + r] : 0u;
+    uint32_t n1 = r + 8 < tcnt[0] ? J.sym[toff[0] + r + 8] : 0u;
+
+#pragma unroll
+    for (int it = 0; it < kIdctIters; ++it) {
+        const int du  = du0 + it * kIdctDuPerBlock + dl;
+        const uint32_t e0 = n0, e1 = n1;
+        if (it + 1 < kIdctIters) { // next iteration's first entries are in flight while this one computes
+            n0 = r < tcnt[it + 1] ? J.sym[toff[it + 1] + r] : 0u;
+            n1 = r + 8 < tcnt[it + 1] ? J.sym[toff[it + 1] + r + 8] : 0u;
         }
-    }
-    __syncthreads();
-    if (in) {
-#pragma unroll
-        for (int i = 0; i < 8; ++i) v[i] = s_blk[dl][i][r];
-        idct8(v);
-#pragma unroll
-        for (int i = 0; i < 8; ++i) s_blk[dl][i][r] = static_cast<int16_t>(v[i]);
-    }
-    __syncthreads();
-    if (!in) return;
-#pragma unroll
-    for (int i = 0; i < 8; ++i) v[i] = s_blk[dl][r][i];
-    idct8(v);
+        __syncthreads(); // previous iteration's row reads are done (and s_q / s_nat are loaded)
+        *reinterpret_cast<uint4*>(blk + r * 8) = make_uint4(0, 0, 0, 0);
+        __syncthreads();
 
-    const int mx = mcu % ip.mcus_x, my = mcu / ip.mcus_x;
-    const int x0 = (mx * ip.comp_h[sc] + ip.du_dx[k]) * 8;
-    const int y  = (my * ip.comp_v[sc] + ip.du_dy[k]) * 8 + r;
-    if (y >= ip.size_y[sc] || x0 >= ip.size_x[sc]) return;
-    uint32_t px[8];
+        const int k      = du % du_per_mcu; // < du_per_mcu even for lanes past the last unit
+        const uint8_t* q = s_q + s_desc[k].qoff;
+        const auto put = [&](uint32_t v) {
+            const int nat = s_nat[(v >> 16) & 63];
+            const int c   = static_cast<int16_t>(v & 0xFFFFu);
+            // natural index = row * 8 + col -> transposed slot col * 8 + row; unsigned q (Appendix B-3)
+            blk[(nat & 7) * 8 + (nat >> 3)] = static_cast<int16_t>(c * static_cast<int>(q[nat]));
+        };
+        const uint32_t cnt = tcnt[it];
+        if (r < cnt) put(e0);
+        if (r + 8 < cnt) put(e1);
+        for (uint32_t i = r + 16; i < cnt; i += 8) put(J.sym[toff[it] + i]); // dense units only
+        __syncthreads();
+        int v[8];
+        unpack8(*reinterpret_cast<const uint4*>(blk + r * 8), v); // column r
+        idct8(v);
+        __syncthreads(); // every column is in registers before rows overwrite the block
 #pragma unroll
-    for (int i = 0; i < 8; ++i) {
-        const int s = static_cast<int16_t>(v[i] + 128);
-        px[i]       = static_cast<uint32_t>(min(max(s, 0), 255));
-    }
-    uint8_t* row = ip.plane[sc] + static_cast<size_t>(y) * ip.pitch[sc] + x0;
-    if (x0 + 8 <= ip.size_x[sc] && (reinterpret_cast<uintptr_t>(row) & 7) == 0) {
+        for (int i = 0; i < 8; ++i) blk[i * 8 + r] = static_cast<int16_t>(v[i]); // now [row][col]
+        __syncthreads();
+        unpack8(*reinterpret_cast<const uint4*>(blk + r * 8), v); // row r
+        idct8(v);
+
         uint2 o;
-        o.x = px[0] | px[1] << 8 | px[2] << 16 | px[3] << 24;
-        o.y = px[4] | px[5] << 8 | px[6] << 16 | px[7] << 24;
-        *reinterpret_cast<uint2*>(row) = o;
-    } else {
+        {
+            uint32_t px[8];
 #pragma unroll
-        for (int i = 0; i < 8; ++i) {
-            if (x0 + i < ip.size_x[sc]) row[i] = static_cast<uint8_t>(px[i]);
+            for (int i = 0; i < 8; ++i) {
+                int s = static_cast<int16_t>(v[i] + 128);
+                // hipcc (ROCm 7.2) otherwise folds shift + level shift + clamp of two pixels into
+                // v_ashr_pk_u8_i32 and ORs the other two bytes onto its result, whose upper half is
+                // not zero on gfx950: bytes 2 and 6 of every row came out with extra bits set
+                asm volatile("" : "+v"(s));
+                px[i] = static_cast<uint32_t>(min(max(s, 0), 255));
+            }
+            o.x = px[0] | px[1] << 8 | px[2] << 16 | px[3] << 24;
+            o.y = px[4] | px[5] << 8 | px[6] << 16 | px[7] << 24;
+        }
+        // A lane holds row r of unit dl; storing that directly makes every wave store touch ~40 cache
+        // lines (8 units x 8 rows). Re-map through LDS: lane -> (row t / 32, unit t % 32), so that
+        // consecutive lanes write the neighbouring 8-byte segments of one image row.
+        s_px[dl][r] = o;
+        __syncthreads();
+        {
+            const int r2  = t >> 5;
+            const int j   = t & 31;
+            const int du2 = du0 + it * kIdctDuPerBlock + j;
+            if (du2 < num_du) {
+                const uint2 w    = s_px[j][r2];
+                const int mcu2   = du2 / du_per_mcu;
+                const UnitDesc d = s_desc[du2 - mcu2 * du_per_mcu];
+                const int my = mcu2 / mcus_x, mx = mcu2 - my * mcus_x;
+                const int x0 = (mx * d.h + d.dx) * 8;
+                const int y  = (my * d.v + d.dy) * 8 + r2;
+                if (y < d.size_y && x0 < d.size_x) {
+                    uint8_t* row = d.plane + static_cast<size_t>(y) * d.pitch + x0;
+                    if (x0 + 8 <= d.size_x && (reinterpret_cast<uintptr_t>(row) & 7) == 0) {
+                        *reinterpret_cast<uint2*>(row) = w;
+                    } else {
+#pragma unroll
+                        for (int i = 0; i < 8; ++i) {
+                            if (x0 + i < d.size_x) row[i] = static_cast<uint8_t>((i < 4 ? w.x >> (8 * i) : w.y >> (8 * (i - 4))) & 0xFFu);
+                        }
+                    }
+                }
+            }
         }
     }
 }
@@ -876,12 +965,8 @@ template <class JS>
 hipError_t launch_any(Stage stage, const JS& js, const JobExtent& e, int grid_y, hipStream_t stream)
 {
     switch (stage) {
-    case kStageZero: {
-        if (e.max_coef_bytes == 0) return hipSuccess;
-        const unsigned gx = static_cast<unsigned>((e.max_coef_bytes + kZeroBytesPerBlock - 1) / kZeroBytesPerBlock);
-        zero_kernel<JS><<<dim3(gx, grid_y), 256, 0, stream>>>(js);
-        return hipGetLastError();
-    }
+    case kStageZero:
+        return hipSuccess; // nothing to clear any more: the write pass emits a symbol stream
     case kStageDestuff:
         if (e.max_chunks == 0) return hipSuccess;
         destuff_kernel<JS><<<dim3(e.max_chunks, grid_y), 256, 0, stream>>>(js);
@@ -916,9 +1001,8 @@ void extend(JobExtent& e, const ScanJob& job)
 {
     e.max_chunks      = job.num_chunks > e.max_chunks ? job.num_chunks : e.max_chunks;
     e.max_seq         = job.num_seq > e.max_seq ? job.num_seq : e.max_seq;
-    const int blocks  = (job.ip.num_du + kIdctDuPerBlock - 1) / kIdctDuPerBlock;
+    const int blocks  = (job.ip.num_du + kIdctDuPerWg - 1) / kIdctDuPerWg;
     e.max_idct_blocks = blocks > e.max_idct_blocks ? blocks : e.max_idct_blocks;
-    e.max_coef_bytes  = job.coef_bytes > e.max_coef_bytes ? job.coef_bytes : e.max_coef_bytes;
     e.max_tab_bytes   = job.sp.tab_bytes > e.max_tab_bytes ? job.sp.tab_bytes : e.max_tab_bytes;
     e.subseq_words    = job.sp.subseq_words;
     e.max_tail_parts  = job.num_tail_parts > e.max_tail_parts ? job.num_tail_parts : e.max_tail_parts;

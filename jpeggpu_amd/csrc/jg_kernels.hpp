@@ -12,7 +12,7 @@ bool subseq_bytes_supported(int subseq_bytes);
 
 /// Stages of one decode, in launch order (also the indices of jpeggpu_ext_get_stage_ms).
 enum Stage {
-    kStageZero      = 0, // zero-fill of the coefficient buffer (only non-zeros are stored later)
+    kStageZero      = 0, // (kept for stable stage indices; nothing is zero-filled any more)
     kStageDestuff   = 1,
     kStageSyncIntra = 2,
     kStageSyncInter = 3, // huff_sync_tail: sequence boundaries + flows the intra kernel left unfinished
@@ -29,7 +29,6 @@ struct JobExtent {
     int max_seq         = 0;
     int max_tail_parts  = 0;
     int max_idct_blocks = 0;
-    uint64_t max_coef_bytes = 0;
     int subseq_words    = 0; // identical for every job of a launch
     uint32_t max_tab_bytes = 0;
 };

@@ -27,30 +27,37 @@ struct HostFetch {
     }
 };
 
+/// Host twin of the write pass's sink (StreamSink in jg_kernels.hip): symbol stream + data-unit table.
 struct HostSink {
-    static constexpr bool kWrite = true;
-    int16_t* out;
+    static constexpr bool kWrite      = true;
+    static constexpr bool kWholeUnits = true;
+    uint32_t* sym;
+    uint2_t* du_tab;
+    uint32_t cur, cur_end, du_off;
+    int du_index;
     int pos, quota;
     int pred[kMaxComp];
+    bool started;
     bool full() const { return pos >= quota; }
-    void store(int v)
-    {
-        static const uint8_t nat[64] = JG_ORDER_NATURAL;
-        if (pos < quota) out[(pos & ~63) + nat[pos & 63]] = static_cast<int16_t>(v);
-    }
     void dc(int comp, int diff)
     {
         pred[comp] += diff;
-        store(pred[comp]);
+        started  = true;
+        du_off   = cur;
+        du_index = pos >> 6;
+        if (cur < cur_end) sym[cur++] = sym_entry(0, pred[comp]);
         ++pos;
     }
-    void ac(int run, int v)
+    void ac(int run, int zpos, int v)
     {
-        pos += run;
-        store(v);
-        ++pos;
+        pos += run + 1;
+        if (started && cur < cur_end) sym[cur++] = sym_entry(zpos, v);
     }
     void advance(int k) { pos += k; }
+    void unit_end()
+    {
+        if (started) du_tab[du_index] = uint2_t{du_off, cur - du_off};
+    }
 };
 
 struct St {
@@ -280,8 +287,10 @@ int emu_decode_scan(
         tails[b] = acc;
     }
 
-    // ---- write pass (huff_write) ----
-    std::memset(coef, 0, static_cast<size_t>(sc.num_du) * 128);
+    // ---- write pass (huff_write): symbol stream + data-unit table, then gather like the IDCT does ----
+    const uint32_t region = sym_region_entries(subseq_bytes);
+    std::vector<uint32_t> sym(static_cast<size_t>(S) * region, 0xDEADBEEFu);
+    std::vector<uint2_t> du_tab(sc.num_du, uint2_t{0xFFFFFFFFu, 0xFFFFFFFFu});
     for (int b = 0; b < num_seq; ++b) {
         const int first = b * T, nsub = std::min(T, S - first);
         const Segment seg0 = sc.segments[segi[first]];
@@ -309,7 +318,12 @@ int emu_decode_scan(
             const bool carried = seg.subseq_offset < first;
             const int ts       = carried ? 0 : seg.subseq_offset - first;
             HostSink sink;
-            sink.out = coef;
+            sink.sym     = sym.data();
+            sink.du_tab  = du_tab.data();
+            sink.cur     = static_cast<uint32_t>(sub) * region;
+            sink.cur_end = sink.cur + region;
+            sink.du_off  = sink.cur;
+            sink.du_index = 0;
             const int nprefix = ex[t].n - ex[ts].n + (carried ? carry.n : 0);
             {
                 const auto sub16 = [](uint32_t a, uint32_t b) { return pk_add_u16(a, pk_add_u16(~b, 0x00010001u)); };
@@ -330,10 +344,23 @@ int emu_decode_scan(
                 ls.c = st[sub - 1].cz & 0xFF;
                 ls.z = st[sub - 1].cz >> 8;
             }
+            sink.started = ls.z == 0; // otherwise the first symbols finish the predecessor's data unit
             HostFetch f{dst.data() + static_cast<size_t>(seg.subseq_offset) * subseq_bytes, seg.subseq_count * W};
             BitWindow<HostFetch> bw;
             bw.seek(ls.p, f);
             decode_subsequence(ls, bw, f, (rel + 1) * bits, tabs, sp, sink);
+        }
+    }
+    {
+        static const uint8_t nat[64] = JG_ORDER_NATURAL;
+        std::memset(coef, 0, static_cast<size_t>(sc.num_du) * 128);
+        for (int d = 0; d < sc.num_du; ++d) {
+            const uint2_t e = du_tab[d];
+            if (e.y > 64 || static_cast<size_t>(e.x) + e.y > sym.size()) return JPEGGPU_INTERNAL_ERROR; // table entry never written
+            for (uint32_t k = 0; k < e.y; ++k) {
+                const uint32_t v = sym[e.x + k];
+                coef[static_cast<size_t>(d) * 64 + nat[(v >> 16) & 63]] = static_cast<int16_t>(v & 0xFFFF);
+            }
         }
     }
 

@@ -113,7 +113,7 @@ def test_photo_buffer_is_smaller_than_the_references(L, photo_bytes):
     assert lay.scans[0].num_subsequences == 22711 and (22711 + 255) // 256 == 89  # README.md:37-38
     assert lay.scans[0].num_sequences == -(-22711 // lay.subsequences_per_sequence)
     assert lay.transferred_bytes < 2_907_282 + 64           # scan bytes only, not the 4 MB file (B-7)
-    assert dec.get_buffer_size() < 50 * 2 ** 20             # the reference needs ~116 MB
+    assert dec.get_buffer_size() < 80 * 2 ** 20             # the reference needs ~116 MB
     dec.cleanup()
 
 
