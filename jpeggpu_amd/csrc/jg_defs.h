@@ -70,7 +70,7 @@ JG_HD inline uint32_t huff_entry(int codelen, uint32_t sym, bool is_dc)
 /// Entries of the symbol stream reserved per subsequence: an emitted entry (DC, or a non-zero AC
 /// coefficient with its magnitude bits) takes at least 2 bits of the stream on average over a data
 /// unit, plus up to one data unit of overrun (a lane finishes the unit it started).
-JG_HD inline uint32_t sym_region_entries(int subseq_bytes) { return static_cast<uint32_t>(subseq_bytes) * 4u + 64u; }
+JG_HD inline uint32_t sym_region_entries(int subseq_bytes) { return static_cast<uint32_t>(subseq_bytes) * 4u + 64u + 8u; } // + a sector of flush slack; a multiple of 8
 
 /// One restart segment of a scan inside the destuffed buffer (reference src/reader.hpp:38-43).
 struct Segment {

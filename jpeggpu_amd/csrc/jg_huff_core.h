@@ -47,32 +47,37 @@ JG_HD inline uint32_t pk_add_u16(uint32_t a, uint32_t b)
 #endif
 }
 
-/// MSB-first 64-bit window over big-endian 32-bit words. `Fetch(w)` returns word `w` of the
-/// segment's destuffed data (zero past the padded end, reference decode_huffman_reader.hpp:110-152).
-/// `nextw` always holds word `widx`, fetched one refill before it is shifted in.
+/// MSB-first 64-bit window over big-endian 32-bit words. A `Fetch` provides `raw(w)`, which issues the
+/// load of word `w` of the segment's destuffed data, and `cook(raw, w)`, which turns the loaded value
+/// into the big-endian word (zero past the segment's padded end, reference
+/// decode_huffman_reader.hpp:110-152). `next_raw` always holds raw(widx), fetched one refill before it
+/// is cooked and shifted in: nothing touches the loaded value in between, so the load's latency is
+/// covered by the symbols decoded meanwhile.
 template <class Fetch>
 struct BitWindow {
     uint64_t win;
     int avail;
     int widx;
-    uint32_t nextw;
+    uint32_t next_raw;
 
     JG_HD inline void seek(int p, const Fetch& fetch)
     {
-        const int w   = p >> 5;
-        const int off = p & 31;
-        win           = ((static_cast<uint64_t>(fetch(w)) << 32) | fetch(w + 1)) << off;
-        avail         = 64 - off;
-        widx          = w + 2;
-        nextw         = fetch(widx);
+        const int w       = p >> 5;
+        const int off     = p & 31;
+        const uint32_t hi = fetch.cook(fetch.raw(w), w);
+        const uint32_t lo = fetch.cook(fetch.raw(w + 1), w + 1);
+        win               = ((static_cast<uint64_t>(hi) << 32) | lo) << off;
+        avail             = 64 - off;
+        widx              = w + 2;
+        next_raw          = fetch.raw(widx);
     }
     JG_HD inline uint32_t peek(const Fetch& fetch)
     {
         if (avail < 32) {
-            win |= static_cast<uint64_t>(nextw) << (32 - avail);
+            win |= static_cast<uint64_t>(fetch.cook(next_raw, widx)) << (32 - avail);
             avail += 32;
             ++widx;
-            nextw = fetch(widx);
+            next_raw = fetch.raw(widx);
         }
         return static_cast<uint32_t>(win >> 32);
     }
@@ -148,6 +153,7 @@ struct NoSink {
     JG_HD inline void ac(int, int, int) {}
     JG_HD inline void advance(int) {}
     JG_HD inline void unit_end() {}
+    JG_HD inline void tick() {}
 };
 
 /// One entry of the symbol stream the write pass emits: a non-zero coefficient (or the absolute DC)
@@ -213,6 +219,7 @@ JG_HD inline void decode_subsequence(
         st.z              = du_end ? 0 : z1;
         st.c              = du_end ? c1 : st.c;
         if (Sink::kWrite && du_end) sink.unit_end();
+        if (Sink::kWrite) sink.tick(); // once per iteration, whatever the symbol was
         ts                = select_tables(sp, st.c); // a few scalar-operand ALU ops, no memory
     }
 }

@@ -170,21 +170,26 @@ struct LdsFetch {
     const uint32_t* img;
     int base;      // word offset of the segment's first word relative to the image's first word
     int seg_words; // words in the segment (zero beyond, reference decode_huffman_reader.hpp:110-152)
-    __device__ __forceinline__ uint32_t operator()(int w) const
+    __device__ __forceinline__ uint32_t raw(int w) const
     {
         // past the segment's end read the zero word at (k = 3, t = T): selecting the ADDRESS keeps
         // the loaded value free of dependent ALU work, so the prefetch really runs ahead
         const int local = w < seg_words ? min(base + w, T * W + 2) : T * W + 3;
         return img[(local & (W - 1)) * SeqImage<W>::kStride + (local >> kLog2W)];
     }
+    __device__ __forceinline__ uint32_t cook(uint32_t v, int) const { return v; } // swapped at fill time
 };
 
+/// Words straight from the destuffed buffer. raw() only issues the load (address clamped into the
+/// segment); the byte swap and the zero-beyond-the-end select happen in cook(), when the word is
+/// shifted into the window one refill later -- a select right behind the load would wait for it.
 struct GlobalFetch {
     const uint32_t* words; // first word of the segment
     int seg_words;
-    __device__ __forceinline__ uint32_t operator()(int w) const
+    __device__ __forceinline__ uint32_t raw(int w) const { return words[min(w, seg_words - 1)]; }
+    __device__ __forceinline__ uint32_t cook(uint32_t v, int w) const
     {
-        return w < seg_words ? __builtin_bswap32(words[w]) : 0u;
+        return w < seg_words ? __builtin_bswap32(v) : 0u;
     }
 };
 
@@ -512,24 +517,44 @@ __global__ __launch_bounds__(T) void huff_seq_tails(JS js)
 // Huffman: write pass
 // ------------------------------------------------------------------------------------------------
 
+constexpr int kStageEntries = 16; // entries of a lane's write-combining ring (a power of two)
+
 /// Sink of the write pass: a compact symbol stream instead of a dense coefficient buffer. Every lane
 /// appends one 32-bit entry per non-zero coefficient (zig-zag position | value, DC already absolute)
 /// to its own region, contiguous per data unit, and records {first entry, count} per data unit when
 /// the unit completes. A lane owns whole data units (jg_huff_core.h, kWholeUnits), so a unit's entries
 /// never span two regions. Compared with scattered 2-byte stores into a pre-zeroed buffer (reference
 /// decode_huffman.cu:360-371 + decoder.cpp:256-263) this needs no zero-fill and writes each byte once.
+///
+/// A lane's 4-byte appends must not go to memory one by one: with many images in flight the ~200 k
+/// open lines do not fit in L2 and every append becomes its own 32-byte sector write (measured: 122 MB
+/// of HBM writes per 12 MP image for a 20 MB stream). Entries are therefore collected in a 16-entry
+/// ring per lane in LDS ([slot][lane], conflict-free) and every 8 iterations ALL lanes flush whole
+/// 32-byte sectors together: at most 7 entries stay behind, at most 8 arrive in between.
 struct StreamSink {
     static constexpr bool kWrite      = true;
     static constexpr bool kWholeUnits = true;
     uint32_t* sym;
     uint2_t* du_tab;
-    uint32_t cur, cur_end, du_off;
+    uint32_t* ring;     // &s_ring[lane]; slot k at ring[k * T]
+    uint32_t flushed;   // entries of this lane already in memory (region base + multiples of 8)
+    uint32_t emitted;   // entries produced so far (region base + count)
+    uint32_t cur_end;   // region end
+    uint32_t du_off;
     int du_index;
     int pos;
     int quota;
+    int ticks;
     int pred[kMaxComp];
     bool started; // false while the first symbols finish the predecessor's data unit
     __device__ __forceinline__ bool full() const { return pos >= quota; }
+    __device__ __forceinline__ void push(uint32_t e)
+    {
+        if (emitted < cur_end) {
+            ring[(emitted & (kStageEntries - 1)) * T] = e;
+            ++emitted;
+        }
+    }
     __device__ __forceinline__ void dc(int comp, int diff)
     {
         int v = 0;
@@ -539,21 +564,41 @@ struct StreamSink {
             v = comp == k ? pred[k] : v;
         }
         started  = true;
-        du_off   = cur;
+        du_off   = emitted;
         du_index = pos >> 6;
-        // 16-bit wrap = the reference's int16 prefix sum (decode_dc.cu:129-155)
-        if (cur < cur_end) sym[cur++] = sym_entry(0, v);
+        push(sym_entry(0, v)); // 16-bit wrap = the reference's int16 prefix sum (decode_dc.cu:129-155)
         ++pos;
     }
     __device__ __forceinline__ void ac(int run, int zpos, int v)
     {
         pos += run + 1;
-        if (started && cur < cur_end) sym[cur++] = sym_entry(zpos, v);
+        if (started) push(sym_entry(zpos, v));
     }
     __device__ __forceinline__ void advance(int k) { pos += k; }
     __device__ __forceinline__ void unit_end()
     {
-        if (started) du_tab[du_index] = uint2_t{du_off, cur - du_off};
+        if (started) du_tab[du_index] = uint2_t{du_off, emitted - du_off};
+    }
+    /// One whole 32-byte sector (8 entries) from the ring to memory; `flushed` is a multiple of 8.
+    __device__ __forceinline__ void flush_sector()
+    {
+        uint32_t e[8];
+#pragma unroll
+        for (int k = 0; k < 8; ++k) e[k] = ring[((flushed + k) & (kStageEntries - 1)) * T];
+        uint4* dst = reinterpret_cast<uint4*>(sym + flushed);
+        dst[0]     = make_uint4(e[0], e[1], e[2], e[3]);
+        dst[1]     = make_uint4(e[4], e[5], e[6], e[7]);
+        flushed += 8;
+    }
+    __device__ __forceinline__ void tick()
+    {
+        if ((++ticks & 7) == 0 && emitted - flushed >= 8) flush_sector();
+    }
+    /// After the loop: everything that is left, rounded up to whole sectors (the entries behind the
+    /// last valid one are never read: the data-unit table bounds every gather).
+    __device__ __forceinline__ void finish()
+    {
+        while (flushed < emitted) flush_sector();
     }
 };
 
@@ -588,21 +633,30 @@ __device__ __forceinline__ uint32_t pk_sub(uint32_t a, uint32_t b) { return pk_a
 __device__ __forceinline__ int lo16(uint32_t v) { return static_cast<int16_t>(v & 0xFFFFu); }
 __device__ __forceinline__ int hi16(uint32_t v) { return static_cast<int16_t>(v >> 16); }
 
+/// Carve of the write kernel's dynamic LDS: scan scratch | write-combining rings | table pack.
+struct WriteLds {
+    static constexpr uint32_t kScan = 0;                                   // T + 1 + 4 + 3 words
+    static constexpr uint32_t kRing = ((T + 8) * 4 + 15) / 16 * 16;
+    static constexpr uint32_t kTabs = kRing + kStageEntries * T * 4;
+    static_assert(kTabs % 16 == 0, "the table pack is read with 16-byte loads");
+};
+
 /// Re-decode every subsequence from its predecessor's synchronised exit state and emit the symbol
 /// stream (StreamSink). The coefficient-slot position of subsequence i inside its segment = sum of n
 /// over the segment's earlier subsequences (in-sequence part by an LDS scan, earlier sequences via
 /// tails); it gives the index of every data unit the lane starts, and the same look-back gives the
 /// DC predictors. Lanes SEQ..T-1 have no subsequence here (the sequence is SEQ long); they only help
-/// with the scans, but their bitstream is staged: a lane may run past its subsequence to finish a unit.
+/// with the scans. The bitstream is read straight from the destuffed buffer, one refill ahead (as in
+/// huff_sync_tail): every word is used once, and without a 33 KB image five workgroups fit on a CU.
 template <int W, class JS>
 __global__ __launch_bounds__(T) void huff_write(JS js)
 {
     extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
-    uint32_t* s_img   = reinterpret_cast<uint32_t*>(smem + SeqLds<W>::kImg);
-    uint32_t* s_scan  = reinterpret_cast<uint32_t*>(smem + SeqLds<W>::kState); // T + 1
-    uint32_t* s_wave  = s_scan + T + 1;                                         // 4
-    uint32_t* s_carry = s_wave + 4;                                             // 3
-    uint8_t* s_tab    = smem + SeqLds<W>::kTabs;
+    uint32_t* s_scan  = reinterpret_cast<uint32_t*>(smem + WriteLds::kScan); // T + 1
+    uint32_t* s_wave  = s_scan + T + 1;                                       // 4
+    uint32_t* s_carry = s_wave + 4;                                           // 3
+    uint32_t* s_ring  = reinterpret_cast<uint32_t*>(smem + WriteLds::kRing);
+    uint8_t* s_tab    = smem + WriteLds::kTabs;
 
     const ScanJob& J = js.get();
     if (static_cast<int>(blockIdx.x) >= J.num_seq) return;
@@ -612,7 +666,6 @@ __global__ __launch_bounds__(T) void huff_write(JS js)
     const int nsub      = min(SEQ, sp.num_subseq - first_sub);
 
     load_tables(s_tab, J.tables, sp.tab_bytes);
-    load_image<W>(s_img, reinterpret_cast<const uint32_t*>(J.destuffed), first_sub, sp.num_subseq);
 
     // carry-in of the segment that is open at the sequence's first subsequence
     {
@@ -653,6 +706,7 @@ __global__ __launch_bounds__(T) void huff_write(JS js)
     StreamSink sink;
     sink.sym     = J.sym;
     sink.du_tab  = J.du_tab;
+    sink.ring    = s_ring + t;
     int nprefix  = 0;
     {
         block_excl_scan_256<false>(active ? static_cast<uint32_t>(J.st_n[sub]) : 0u, s_scan, s_wave);
@@ -673,10 +727,12 @@ __global__ __launch_bounds__(T) void huff_write(JS js)
     const int seg_mcus1 = min(seg_mcus0 + sp.mcus_per_segment, sp.total_mcus); // Appendix B-5 clamp
     sink.pos            = seg_mcus0 * du_words + nprefix;
     sink.quota          = seg_mcus1 * du_words;
-    sink.cur            = static_cast<uint32_t>(sub) * J.sym_region;
-    sink.cur_end        = sink.cur + J.sym_region;
-    sink.du_off         = sink.cur;
+    sink.flushed        = static_cast<uint32_t>(sub) * J.sym_region; // region base, a multiple of 8
+    sink.emitted        = sink.flushed;
+    sink.cur_end        = sink.flushed + J.sym_region;
+    sink.du_off         = sink.flushed;
     sink.du_index       = 0;
+    sink.ticks          = 0;
 
     LaneState st{};
     if (rel > 0) {
@@ -686,10 +742,12 @@ __global__ __launch_bounds__(T) void huff_write(JS js)
         st.z         = cz >> 8;
     }
     sink.started = st.z == 0;
-    LdsFetch<W> fetch{s_img, (seg.subseq_offset - first_sub) * W, seg.subseq_count * W};
-    BitWindow<LdsFetch<W>> bw{};
+    GlobalFetch fetch{reinterpret_cast<const uint32_t*>(J.destuffed) + static_cast<size_t>(seg.subseq_offset) * W,
+                      seg.subseq_count * W};
+    BitWindow<GlobalFetch> bw{};
     bw.seek(st.p, fetch);
     decode_subsequence(st, bw, fetch, (rel + 1) * (W * 32), s_tab, sp, sink);
+    sink.finish();
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -763,7 +821,7 @@ __global__ __launch_bounds__(256) void idct_kernel(JS js)
     __shared__ __attribute__((aligned(16))) int16_t s_blk[kIdctDuPerBlock][kIdctDuStride]; // [unit][col * 8 + row]
     __shared__ uint8_t s_q[4 * 64];
     __shared__ uint8_t s_nat[64];
-    __shared__ uint2 s_px[kIdctDuPerBlock][9]; // finished pixel rows, [unit][row] (+1: bank spread)
+    __shared__ uint2 s_px[2][kIdctDuPerBlock][9]; // finished pixel rows, [buffer][unit][row] (+1: bank spread)
     // Geometry of the k-th data unit of an MCU, staged once: the job lives in global memory (batch
     // API), and indexing its small arrays per lane would be a chain of dependent L2 round trips.
     struct UnitDesc {
@@ -805,6 +863,7 @@ __global__ __launch_bounds__(256) void idct_kernel(JS js)
         s_nat[t]                  = nat[t];
     }
     int16_t* blk = s_blk[dl];
+    __syncthreads(); // s_q, s_nat, s_desc are loaded
 
     // table entries of all iterations (independent loads, one latency); a table entry that was never
     // written (corrupt stream) must not lead out of the buffer
@@ -829,9 +888,10 @@ __global__ __launch_bounds__(256) void idct_kernel(JS js)
             n0 = r < tcnt[it + 1] ? J.sym[toff[it + 1] + r] : 0u;
             n1 = r + 8 < tcnt[it + 1] ? J.sym[toff[it + 1] + r + 8] : 0u;
         }
-        __syncthreads(); // previous iteration's row reads are done (and s_q / s_nat are loaded)
+        // The 8 lanes of a data unit sit in one wave and LDS executes a wave's instructions in order,
+        // so the phases below need no workgroup barrier among themselves; only the pixel re-mapping
+        // at the end crosses waves (one barrier per iteration, buffers alternate).
         *reinterpret_cast<uint4*>(blk + r * 8) = make_uint4(0, 0, 0, 0);
-        __syncthreads();
 
         const int k      = du % du_per_mcu; // < du_per_mcu even for lanes past the last unit
         const uint8_t* q = s_q + s_desc[k].qoff;
@@ -845,15 +905,16 @@ __global__ __launch_bounds__(256) void idct_kernel(JS js)
         if (r < cnt) put(e0);
         if (r + 8 < cnt) put(e1);
         for (uint32_t i = r + 16; i < cnt; i += 8) put(J.sym[toff[it] + i]); // dense units only
-        __syncthreads();
+        __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
         int v[8];
         unpack8(*reinterpret_cast<const uint4*>(blk + r * 8), v); // column r
+        __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront"); // every column is read before rows overwrite the block
         idct8(v);
-        __syncthreads(); // every column is in registers before rows overwrite the block
 #pragma unroll
         for (int i = 0; i < 8; ++i) blk[i * 8 + r] = static_cast<int16_t>(v[i]); // now [row][col]
-        __syncthreads();
+        __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
         unpack8(*reinterpret_cast<const uint4*>(blk + r * 8), v); // row r
+        __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront"); // row reads precede the next iteration's zeroing
         idct8(v);
 
         uint2 o;
@@ -874,14 +935,14 @@ __global__ __launch_bounds__(256) void idct_kernel(JS js)
         // A lane holds row r of unit dl; storing that directly makes every wave store touch ~40 cache
         // lines (8 units x 8 rows). Re-map through LDS: lane -> (row t / 32, unit t % 32), so that
         // consecutive lanes write the neighbouring 8-byte segments of one image row.
-        s_px[dl][r] = o;
+        s_px[it & 1][dl][r] = o;
         __syncthreads();
         {
             const int r2  = t >> 5;
             const int j   = t & 31;
             const int du2 = du0 + it * kIdctDuPerBlock + j;
             if (du2 < num_du) {
-                const uint2 w    = s_px[j][r2];
+                const uint2 w    = s_px[it & 1][j][r2];
                 const int mcu2   = du2 / du_per_mcu;
                 const UnitDesc d = s_desc[du2 - mcu2 * du_per_mcu];
                 const int my = mcu2 / mcus_x, mx = mcu2 - my * mcus_x;
@@ -953,8 +1014,7 @@ hipError_t launch_huff(Stage stage, const JS& js, const JobExtent& e, int grid_y
             huff_sync_tail<W, JS><<<dim3(e.max_tail_parts, grid_y), TL, 3 * TL * 4 + e.max_tab_bytes, stream>>>(js);
         break;
     case kStageWrite:
-        if ((err = allow_lds(huff_write<W, JS>, seq_lds)) != hipSuccess) return err;
-        huff_write<W, JS><<<dim3(e.max_seq, grid_y), T, seq_lds, stream>>>(js);
+        huff_write<W, JS><<<dim3(e.max_seq, grid_y), T, WriteLds::kTabs + e.max_tab_bytes, stream>>>(js);
         break;
     default: return hipErrorInvalidValue;
     }

@@ -19,12 +19,13 @@ namespace {
 struct HostFetch {
     const uint8_t* seg; // first byte of the segment in the destuffed buffer
     int seg_words;
-    uint32_t operator()(int w) const
+    uint32_t raw(int w) const
     {
         if (w >= seg_words) return 0;
         const uint8_t* p = seg + static_cast<size_t>(w) * 4;
         return static_cast<uint32_t>(p[0]) << 24 | p[1] << 16 | p[2] << 8 | p[3];
     }
+    uint32_t cook(uint32_t v, int) const { return v; }
 };
 
 /// Host twin of the write pass's sink (StreamSink in jg_kernels.hip): symbol stream + data-unit table.
@@ -58,6 +59,7 @@ struct HostSink {
     {
         if (started) du_tab[du_index] = uint2_t{du_off, cur - du_off};
     }
+    void tick() {}
 };
 
 struct St {
