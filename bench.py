@@ -45,6 +45,8 @@ def parse_args():
     ap.add_argument("--subseq-bytes", type=int, default=0, help="0 = library default")
     ap.add_argument("--gather", action="store_true", help="RCCL gather of the decoded planes to rank 0 each step")
     ap.add_argument("--latency-iters", type=int, default=50)
+    ap.add_argument("--latency-subseq-bytes", type=int, default=64,
+                    help="subsequence size of the single-image latency probe (64 B: shorter serial chain)")
     ap.add_argument("--cpu-seconds", type=float, default=12.0, help="budget of the CPU baseline sample")
     ap.add_argument("--no-cpu", action="store_true")
     return ap.parse_args()
@@ -270,7 +272,7 @@ def main():
     if rank == 0:
         # single-image latency under the reference's protocol (benchmark/benchmark_jpeggpu.hpp:69-108):
         # parse_header + get_buffer_size + transfer + decode + stream sync, wall clock, pinned input
-        s0 = slots[0]
+        s0 = Slot(torch, jp, slots[0].data, device, args.latency_subseq_bytes)
         pinned = torch.empty(len(s0.data), dtype=torch.uint8).pin_memory()
         pinned.numpy()[:] = memoryview(s0.data)
         host_ptr, host_n = pinned.data_ptr(), pinned.numel()
@@ -349,11 +351,14 @@ def main():
             "kernels": all_kernels,
             "stage_us_under_load": stage_us, "stage_us_solo": solo,
             "latency_ms": {"protocol": "parse+size+transfer+decode+sync, 1 image, 1 stream, pinned input",
+                           "subsequence_bytes": s0.layout.subsequence_bytes,
                            "p50": statistics.median(lat), "mean": statistics.fmean(lat), "max": max(lat),
                            "iters": len(lat), "images_per_s_single_stream": 1e3 / statistics.fmean(lat)},
         }
         if not args.no_cpu:
             out["cpu_baseline"] = cpu_baseline(args, slots[0].data)
+    if rank == 0:
+        s0.dec.cleanup()
     for bt, _, _, _ in groups:
         bt.destroy()
     for s in slots:

@@ -548,12 +548,14 @@ struct StreamSink {
     int pred[kMaxComp];
     bool started; // false while the first symbols finish the predecessor's data unit
     __device__ __forceinline__ bool full() const { return pos >= quota; }
-    __device__ __forceinline__ void push(uint32_t e)
+    /// Branch-free append: a lane that is not emitting (still finishing its predecessor's unit, or
+    /// past its region on a corrupt stream) writes the spare ring row and does not advance.
+    __device__ __forceinline__ void push(uint32_t e, bool emit)
     {
-        if (emitted < cur_end) {
-            ring[(emitted & (kStageEntries - 1)) * T] = e;
-            ++emitted;
-        }
+        emit                = emit && emitted < cur_end;
+        const uint32_t slot = emit ? (emitted & (kStageEntries - 1)) : kStageEntries;
+        ring[slot * T]      = e;
+        emitted += emit ? 1u : 0u;
     }
     __device__ __forceinline__ void dc(int comp, int diff)
     {
@@ -566,13 +568,13 @@ struct StreamSink {
         started  = true;
         du_off   = emitted;
         du_index = pos >> 6;
-        push(sym_entry(0, v)); // 16-bit wrap = the reference's int16 prefix sum (decode_dc.cu:129-155)
+        push(sym_entry(0, v), true); // 16-bit wrap = the reference's int16 prefix sum (decode_dc.cu:129-155)
         ++pos;
     }
     __device__ __forceinline__ void ac(int run, int zpos, int v)
     {
         pos += run + 1;
-        if (started) push(sym_entry(zpos, v));
+        push(sym_entry(zpos, v), started);
     }
     __device__ __forceinline__ void advance(int k) { pos += k; }
     __device__ __forceinline__ void unit_end()
@@ -637,7 +639,7 @@ __device__ __forceinline__ int hi16(uint32_t v) { return static_cast<int16_t>(v 
 struct WriteLds {
     static constexpr uint32_t kScan = 0;                                   // T + 1 + 4 + 3 words
     static constexpr uint32_t kRing = ((T + 8) * 4 + 15) / 16 * 16;
-    static constexpr uint32_t kTabs = kRing + kStageEntries * T * 4;
+    static constexpr uint32_t kTabs = kRing + (kStageEntries + 1) * T * 4; // + the spare row of StreamSink::push
     static_assert(kTabs % 16 == 0, "the table pack is read with 16-byte loads");
 };
 

@@ -185,6 +185,55 @@ def test_batch_decode_equals_single(torch_cuda):
         dec.cleanup()
 
 
+def test_corrupt_entropy_data_is_memory_safe(torch_cuda):
+    """Random damage inside the entropy-coded segment (no new markers): the planes are garbage by
+    definition, but every decode must complete, stay inside its buffers, and leave the decoder and the
+    device usable -- the guards that matter for serving untrusted files (quota, region capacity,
+    table clamps, bounded flows). Canary bytes around tmp and the planes must survive."""
+    import jpeggpu_amd
+    from oracle import oracle
+
+    torch = torch_cuda
+    rng = np.random.default_rng(1234)
+    m = cases.matrix()
+    for name in ("multi_seq_dri", "multi_seq_nodri", "four_comp_opt", "ni_420_dri"):
+        good = m[name]
+        ref = oracle.decode(good)
+        lo, hi = oracle.scan_info(good, 0, 128).scan_begin, oracle.scan_info(good, 0, 128).scan_end
+        for trial in range(6):
+            bad = bytearray(good)
+            for pos in rng.integers(lo + 4, hi - 4, size=int(rng.integers(1, 40))):
+                v = int(rng.integers(0, 255))          # never 0xFF: the marker structure stays intact
+                if bad[pos] != 0xFF and bad[pos - 1] != 0xFF:
+                    bad[pos] = v
+            dec = jpeggpu_amd.Decoder(int(rng.choice([32, 64, 128])))
+            try:
+                info = dec.parse_header(bytes(bad))
+            except jpeggpu_amd.JpegGpuError:
+                dec.cleanup()
+                continue
+            n = dec.get_buffer_size()
+            guard = 4096
+            tmp = torch.full((n + 256 + 2 * guard,), 0x5A, dtype=torch.uint8, device="cuda:0")
+            base = (tmp.data_ptr() + guard + 255) // 256 * 256
+            planes = []
+            for c in range(info.num_components):
+                buf = torch.full((info.sizes_y[c] + 2, info.sizes_x[c]), 0x5A, dtype=torch.uint8, device="cuda:0")
+                planes.append(buf)
+            dec.transfer(base, n, 0)
+            dec.decode([p[1:-1].data_ptr() for p in planes], [p.stride(0) for p in planes], base, n, 0)
+            torch.cuda.synchronize()
+            off = base - tmp.data_ptr()
+            assert (tmp[:off] == 0x5A).all() and (tmp[off + n:] == 0x5A).all(), (name, trial, "tmp overrun")
+            for p in planes:
+                assert (p[0] == 0x5A).all() and (p[-1] == 0x5A).all(), (name, trial, "plane overrun")
+            dec.cleanup()
+        # the device still decodes correctly afterwards
+        planes, _ = jpeggpu_amd.decode_to_planes(good)
+        for c in range(ref.ncomp):
+            assert np.array_equal(planes[c].cpu().numpy(), ref.planes[c]), name
+
+
 @pytest.mark.parametrize("cfg", [2, 4, 5])
 def test_baseline_configs_full_size(torch_cuda, cfg):
     """BASELINE.json configs 2, 4 (39 MP, three non-interleaved scans) and 5 (4 components, 4+4
