@@ -287,6 +287,7 @@ jpeggpu_status build_jobs(
         sp.subseq_words     = d.subseq_bytes / 4;
         sp.tab_bytes        = static_cast<uint32_t>(sc.table_pack.size());
         sp.max_intra_iters  = max_intra_iters;
+        sp.cursor_off       = sc.cursor_off;
         IdctParams& ip = job.ip;
         ip.num_du      = sc.num_du;
         ip.du_per_mcu  = sc.du_per_mcu;
@@ -294,11 +295,8 @@ jpeggpu_status build_jobs(
         int du         = 0;
         for (int a = 0; a < sc.num_comp; ++a) {
             const ScanComponent& c = sc.comp[a];
-            sp.dc_offs |= static_cast<uint64_t>(sc.dc_off[a]) << (16 * a);
-            sp.ac_offs |= static_cast<uint64_t>(sc.ac_off[a]) << (16 * a);
             for (int y = 0; y < c.v; ++y) {
                 for (int x = 0; x < c.h; ++x) { // row-major inside the MCU (T.81 A.2.3)
-                    sp.du_comp |= static_cast<uint32_t>(a) << (2 * du);
                     ip.du_comp[du] = static_cast<uint8_t>(a);
                     ip.du_dx[du]   = static_cast<uint8_t>(x);
                     ip.du_dy[du]   = static_cast<uint8_t>(y);

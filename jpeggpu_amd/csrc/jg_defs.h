@@ -37,25 +37,39 @@ constexpr int kDestuffWin   = 4096; // stuffed bytes handled by one destuff work
 /// (so that almost no lane ever needs the long-code path, which every lane of the wave would have
 /// to wait for), and a long-code path without a dependent chain of table reads.
 ///
-///   one table = lut16[1 << LB] | lim16[8] | valoff16[8] | huffval[256]     (LB = 9 for DC, 11 for AC)
+///   one table = lut16[1 << LB] | lim16[8] | valoff16[8] | huffval[256] | sub16[nsub][32]
+///                                                                    (LB = 9 for DC, 11 for AC)
 ///
 ///   lut16 entry, indexed by the LB most significant bits of the 32-bit window:
-///     bits  0..5  total symbol length = code length + magnitude bits (0 = code longer than LB bits)
-///     bits  6..9  magnitude category s
-///     bits 10..14 run + 1 (1..16); 1 in a DC table
-///     bit  15     end-of-block (AC symbol with s == 0 and run != 15), 0 in a DC table
+///     bits  0..4  total symbol length = code length + magnitude bits, 1..31 (0 = code longer than LB bits)
+///     bits  5..8  magnitude category s
+///     bits  9..15 zig-zag advance: run + 1 (1..16), or 64 for end-of-block (AC symbol with s == 0 and
+///                 run != 15): any advance that reaches index 64 closes the data unit; 1 in a DC table
+///   an entry with bits 0..4 == 0 and a non-zero rest is indirect: (entry >> 5) - 1 is the index of a
+///     second-level table sub16[k][32], indexed by the next 5 window bits, holding entries of the same
+///     format (0 there, or a first-level 0, = take the long-code path below). The host allocates a
+///     second-level table for every LB-bit prefix that starts a valid longer code, up to
+///     kMaxSubTables per table; with the tables of real files that is a handful (the long codes sit
+///     together at the all-ones end of the code space), and no lane then takes the long-code path.
 ///   lim16[j], j = 0..7: canonical code counter after length 9+j, left-aligned to 16 bits and
 ///     saturated to 0xFFFF; a 16-bit window v holds a code of length <= 9+j iff v < lim16[j]
 ///     (equivalent to the reference's maxcode walk, src/decode_huffman.cu:177-187)
 ///   valoff16[j]: (huffval index of the first code of length 9+j minus that code) mod 256
 ///
-/// A scan's pack holds only the tables its components select; ScanParams carries the byte offsets.
+/// A scan's pack holds only the tables its components select, followed by the scan's CURSOR RING:
+/// one 16-byte entry per data unit of the MCU,
+///   { dc table offset | ac table offset << 16,  16 * scan component | data unit index << 8,
+///     byte offset of this entry,  byte offset of the next data unit's entry }   (offsets in the pack)
+/// A lane keeps the entry of the data unit it is in; at the end of a data unit it loads the next one.
+/// This replaces per-symbol table selection arithmetic by one LDS read per symbol.
 constexpr int kLutBitsDc   = 9;
 constexpr int kLutBitsAc   = 11;
+constexpr int kSubBits     = 5;
+constexpr int kSubTableSize = 2 << kSubBits; // bytes
+constexpr int kMaxSubTables = 32;
 constexpr int kHuffAuxSize = 16 + 16 + 256;
-constexpr int kDcTableSize = (2 << kLutBitsDc) + kHuffAuxSize; // 1312
-constexpr int kAcTableSize = (2 << kLutBitsAc) + kHuffAuxSize; // 4384
-constexpr int kMaxTablePack = kMaxComp * (kDcTableSize + kAcTableSize);
+constexpr int kDcTableSize = (2 << kLutBitsDc) + kHuffAuxSize; // 1312, plus second-level tables
+constexpr int kAcTableSize = (2 << kLutBitsAc) + kHuffAuxSize; // 4384, plus second-level tables
 
 JG_HD inline uint32_t huff_entry(int codelen, uint32_t sym, bool is_dc)
 {
@@ -63,14 +77,18 @@ JG_HD inline uint32_t huff_entry(int codelen, uint32_t sym, bool is_dc)
     // AC: sym = run << 4 | category (reference decode_huffman.cu:232-259).
     const uint32_t s   = sym & 15u;
     const uint32_t r   = is_dc ? 0u : (sym >> 4);
-    const uint32_t eob = (!is_dc && s == 0 && r != 15) ? 1u : 0u;
-    return (static_cast<uint32_t>(codelen) + s) | (s << 6) | ((r + 1u) << 10) | (eob << 15);
+    const bool eob = !is_dc && s == 0 && r != 15;
+    return (static_cast<uint32_t>(codelen) + s) | (s << 5) | ((eob ? 64u : r + 1u) << 9);
 }
 
 /// Entries of the symbol stream reserved per subsequence: an emitted entry (DC, or a non-zero AC
 /// coefficient with its magnitude bits) takes at least 2 bits of the stream on average over a data
 /// unit, plus up to one data unit of overrun (a lane finishes the unit it started).
 JG_HD inline uint32_t sym_region_entries(int subseq_bytes) { return static_cast<uint32_t>(subseq_bytes) * 4u + 64u + 8u; } // + a sector of flush slack; a multiple of 8
+
+struct uint2_t {
+    uint32_t x, y;
+};
 
 /// One restart segment of a scan inside the destuffed buffer (reference src/reader.hpp:38-43).
 struct Segment {
@@ -104,13 +122,17 @@ struct ScanParams {
     int total_mcus;
     int subseq_words;     // 32-bit words per subsequence (subsequence bytes / 4)
     int max_intra_iters;  // lock-step flow iterations inside huff_sync_intra before flows are handed to huff_sync_tail
-    uint32_t du_comp;     // 2 bits per data unit of the MCU: scan-component index
-    uint32_t tab_bytes;   // size of the scan's Huffman table pack
-    // Byte offset of each scan component's DC / AC table in the pack, 16 bits per component. Packed
-    // scalars, not arrays: a runtime-indexed kernel-argument array is re-read from memory per use.
-    uint64_t dc_offs;
-    uint64_t ac_offs;
+    uint32_t tab_bytes;   // size of the scan's Huffman table pack (tables + cursor ring)
+    uint32_t cursor_off;  // byte offset of the cursor ring in the pack
 };
+
+struct CursorEntry {
+    uint32_t tabs; // dc table offset | ac table offset << 16
+    uint32_t meta; // 16 * scan component (shift of its 16-bit DC sum) | data unit index << 8
+    uint32_t self; // byte offset of this entry in the pack
+    uint32_t next; // byte offset of the next data unit's entry
+};
+static_assert(sizeof(CursorEntry) == 16, "read with one 16-byte load");
 
 /// Geometry for dequant + IDCT reading the stream-order coefficient buffer (replaces the reference's
 /// separate transpose pass, src/decode_transpose.cu:41-132, plus src/idct.cu:146-223).
@@ -132,9 +154,6 @@ struct IdctParams {
 
 /// Everything the kernels need to know about one scan of one image: a launch covers one job (passed
 /// by value, the drop-in API) or an array of jobs, one per blockIdx.y (the batch API).
-struct uint2_t {
-    uint32_t x, y;
-};
 
 struct ScanJob {
     const uint8_t* bytes;        // transferred entropy-coded bytes of the image

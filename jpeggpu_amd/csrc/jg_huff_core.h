@@ -112,6 +112,20 @@ JG_HD inline uint32_t huff_long_code(const uint8_t* aux, uint32_t peek, bool is_
     return huff_entry(l, sym, is_dc);
 }
 
+/// First-level entry without a length: second-level table if the host built one for this prefix,
+/// else the long-code path.
+JG_HD inline uint32_t huff_second_level(const uint8_t* tab, uint32_t e, uint32_t peek, bool is_dc)
+{
+    const int lb       = is_dc ? kLutBitsDc : kLutBitsAc;
+    const uint8_t* aux = tab + (is_dc ? (2 << kLutBitsDc) : (2 << kLutBitsAc));
+    if (e != 0) {
+        const uint32_t i2 = (peek >> (32 - kSubBits - lb)) & ((1u << kSubBits) - 1u);
+        e                 = ld_u16(aux + kHuffAuxSize - kSubTableSize + (e >> 5) * kSubTableSize + 2 * i2);
+        if (e != 0) return e;
+    }
+    return huff_long_code(aux, peek, is_dc);
+}
+
 JG_HD inline int extend_magnitude(uint32_t bits, int s)
 {
     // T.81 F.2.2.1 EXTEND; reference get_value (decode_huffman.cu:196-200) without the signed shift.
@@ -129,30 +143,14 @@ JG_HD inline uint32_t bits_field(uint32_t peek, int total_len, int s)
 #endif
 }
 
-struct TableSel {
-    uint32_t dc; // byte offsets into the table pack
-    uint32_t ac;
-    int comp;
-};
-
-JG_HD inline TableSel select_tables(const ScanParams& sp, int c)
-{
-    TableSel r;
-    r.comp = (sp.du_comp >> (2 * c)) & 3;
-    r.dc   = static_cast<uint32_t>(sp.dc_offs >> (16 * r.comp)) & 0xFFFFu;
-    r.ac   = static_cast<uint32_t>(sp.ac_offs >> (16 * r.comp)) & 0xFFFFu;
-    return r;
-}
-
 /// Sink used by the synchronisation passes: nothing is stored.
 struct NoSink {
     static constexpr bool kWrite      = false;
     static constexpr bool kWholeUnits = false;
     JG_HD inline bool full() const { return false; }
-    JG_HD inline void dc(int, int) {}
-    JG_HD inline void ac(int, int, int) {}
-    JG_HD inline void advance(int) {}
-    JG_HD inline void unit_end() {}
+    JG_HD inline void dc(int) {}
+    JG_HD inline void ac(int, int) {}
+    JG_HD inline void unit_end(bool) {}
     JG_HD inline void tick() {}
 };
 
@@ -173,6 +171,8 @@ JG_HD inline uint32_t sym_entry(int zpos, int value)
 /// ONE flat loop, one symbol per iteration for every lane: the data-unit boundary is handled with
 /// selects, not with a branch -- a branch there makes the compiler nest the loop, and a nested loop
 /// makes the 64 lanes of a wave wait for the longest data unit among them at every boundary.
+/// Coefficient slots are counted as 64 per closed unit plus the zig-zag index difference, which equals
+/// the reference's per-symbol count (decode_huffman.cu:302-394) on every valid stream.
 template <class Fetch, class Sink>
 JG_HD inline void decode_subsequence(
     LaneState& st,
@@ -183,45 +183,73 @@ JG_HD inline void decode_subsequence(
     const ScanParams& sp,
     Sink& sink)
 {
-    TableSel ts = select_tables(sp, st.c);
+#if defined(__HIP_DEVICE_COMPILE__)
+    typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
+#define JG_LOAD_CURSOR(off) (*reinterpret_cast<const u32x4*>(tabs + (off)))
+    u32x4 cur = JG_LOAD_CURSOR(sp.cursor_off + 16u * static_cast<uint32_t>(st.c));
+#define JG_CUR_TABS cur[0]
+#define JG_CUR_META cur[1]
+#define JG_CUR_SELF cur[2]
+#define JG_CUR_NEXT cur[3]
+#else
+#define JG_LOAD_CURSOR(off) (*reinterpret_cast<const CursorEntry*>(tabs + (off)))
+    CursorEntry cur = JG_LOAD_CURSOR(sp.cursor_off + 16u * static_cast<uint32_t>(st.c));
+#define JG_CUR_TABS cur.tabs
+#define JG_CUR_META cur.meta
+#define JG_CUR_SELF cur.self
+#define JG_CUR_NEXT cur.next
+#endif
+    int p       = st.p;
+    int z       = st.z;
+    int units   = 0;
+    uint32_t dc01 = st.dc01, dc23 = st.dc23;
     while (true) {
-        if (Sink::kWrite && sink.full()) break;
         const uint32_t peek = bw.peek(fetch);
-        const bool is_dc    = st.z == 0;
-        const uint8_t* tab  = tabs + (is_dc ? ts.dc : ts.ac);
-        const uint32_t idx  = is_dc ? peek >> (32 - kLutBitsDc) : peek >> (32 - kLutBitsAc);
+        const bool is_dc    = z == 0;
+        const uint8_t* tab  = tabs + (is_dc ? (JG_CUR_TABS & 0xFFFFu) : (JG_CUR_TABS >> 16));
+        const uint32_t idx  = peek >> (is_dc ? 32 - kLutBitsDc : 32 - kLutBitsAc);
         uint32_t e          = ld_u16(tab + 2 * idx);
-        if (e == 0) e = huff_long_code(tab + (is_dc ? (2 << kLutBitsDc) : (2 << kLutBitsAc)), peek, is_dc);
-        const int total   = e & 63;
-        const bool beyond = st.p + total > end_bit;
-        if (Sink::kWholeUnits ? (beyond && st.z == 0) : beyond) break;
+        if ((e & 31u) == 0) e = huff_second_level(tab, e, peek, is_dc);
+        const int total   = e & 31;
+        const bool beyond = p + total > end_bit;
+        if (Sink::kWholeUnits ? (is_dc && (beyond || sink.full())) : beyond) break;
         bw.skip(total);
-        st.p += total;
-        const int s    = (e >> 6) & 15;
-        const int run1 = (e >> 10) & 31;
-        const int adv  = (e & 0x8000u) ? 64 - st.z : run1; // DC entries have run1 == 1, no EOB flag
+        p += total;
+        const int adv = e >> 9;
         if (Sink::kWrite || is_dc) {
+            const int s = (e >> 5) & 15;
             const int v = extend_magnitude(bits_field(peek, total, s), s);
             if (is_dc) {
-                const uint32_t d = (static_cast<uint32_t>(v) & 0xFFFFu) << (16 * (ts.comp & 1));
-                st.dc01          = pk_add_u16(st.dc01, ts.comp < 2 ? d : 0u);
-                st.dc23          = pk_add_u16(st.dc23, ts.comp < 2 ? 0u : d);
-                sink.dc(ts.comp, v);
+                const int sh     = JG_CUR_META & 63;
+                const uint64_t d = static_cast<uint64_t>(static_cast<uint32_t>(v) & 0xFFFFu) << sh;
+                dc01             = pk_add_u16(dc01, static_cast<uint32_t>(d));
+                dc23             = pk_add_u16(dc23, static_cast<uint32_t>(d >> 32));
+                // the component's running sum is the absolute DC value, 16-bit wrap like the
+                // reference's int16 prefix sum (decode_dc.cu:129-155)
+                if (Sink::kWrite) sink.dc(static_cast<int>(((static_cast<uint64_t>(dc23) << 32) | dc01) >> sh));
             } else if (Sink::kWrite) {
-                if (s) sink.ac(adv - 1, st.z + adv - 1, v);
-                else sink.advance(adv);
+                if (s) sink.ac(z + adv - 1, v);
             }
         }
-        st.n += adv;
-        const int z1      = st.z + adv;
+        const int z1      = z + adv;
         const bool du_end = z1 >= 64;
-        const int c1      = st.c + 1 >= sp.du_per_mcu ? 0 : st.c + 1;
-        st.z              = du_end ? 0 : z1;
-        st.c              = du_end ? c1 : st.c;
-        if (Sink::kWrite && du_end) sink.unit_end();
+        z                 = du_end ? 0 : z1;
+        units += du_end ? 1 : 0;
+        if (Sink::kWrite) sink.unit_end(du_end);
+        cur = JG_LOAD_CURSOR(du_end ? JG_CUR_NEXT : JG_CUR_SELF);
         if (Sink::kWrite) sink.tick(); // once per iteration, whatever the symbol was
-        ts                = select_tables(sp, st.c); // a few scalar-operand ALU ops, no memory
     }
+    st.n += 64 * units + z - st.z;
+    st.p    = p;
+    st.z    = z;
+    st.c    = (JG_CUR_META >> 8) & 0xFF;
+    st.dc01 = dc01;
+    st.dc23 = dc23;
+#undef JG_LOAD_CURSOR
+#undef JG_CUR_TABS
+#undef JG_CUR_META
+#undef JG_CUR_SELF
+#undef JG_CUR_NEXT
 }
 
 } // namespace jg

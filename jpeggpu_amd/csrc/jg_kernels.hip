@@ -172,9 +172,11 @@ struct LdsFetch {
     int seg_words; // words in the segment (zero beyond, reference decode_huffman_reader.hpp:110-152)
     __device__ __forceinline__ uint32_t raw(int w) const
     {
-        // past the segment's end read the zero word at (k = 3, t = T): selecting the ADDRESS keeps
-        // the loaded value free of dependent ALU work, so the prefetch really runs ahead
-        const int local = w < seg_words ? min(base + w, T * W + 2) : T * W + 3;
+        // No clamp and no zero-beyond-the-segment select: a lane never commits a symbol that uses a
+        // bit past `end_bit` <= the segment's end, and whether a symbol does is decided by the bits
+        // before it (prefix code), so what lies behind the end cannot change any result here. The
+        // window reads at most word (end_bit / 32) + 3 <= T * W + 3, which the pad column holds.
+        const int local = base + w;
         return img[(local & (W - 1)) * SeqImage<W>::kStride + (local >> kLog2W)];
     }
     __device__ __forceinline__ uint32_t cook(uint32_t v, int) const { return v; } // swapped at fill time
@@ -542,12 +544,11 @@ struct StreamSink {
     uint32_t cur_end;   // region end
     uint32_t du_off;
     int du_index;
-    int pos;
-    int quota;
+    int du;       // next data unit this lane starts
+    int quota;    // first data unit past the segment
     int ticks;
-    int pred[kMaxComp];
     bool started; // false while the first symbols finish the predecessor's data unit
-    __device__ __forceinline__ bool full() const { return pos >= quota; }
+    __device__ __forceinline__ bool full() const { return du >= quota; }
     /// Branch-free append: a lane that is not emitting (still finishing its predecessor's unit, or
     /// past its region on a corrupt stream) writes the spare ring row and does not advance.
     __device__ __forceinline__ void push(uint32_t e, bool emit)
@@ -557,29 +558,17 @@ struct StreamSink {
         ring[slot * T]      = e;
         emitted += emit ? 1u : 0u;
     }
-    __device__ __forceinline__ void dc(int comp, int diff)
+    __device__ __forceinline__ void dc(int value)
     {
-        int v = 0;
-#pragma unroll
-        for (int k = 0; k < kMaxComp; ++k) {
-            pred[k] += comp == k ? diff : 0;
-            v = comp == k ? pred[k] : v;
-        }
         started  = true;
         du_off   = emitted;
-        du_index = pos >> 6;
-        push(sym_entry(0, v), true); // 16-bit wrap = the reference's int16 prefix sum (decode_dc.cu:129-155)
-        ++pos;
+        du_index = du++;
+        push(sym_entry(0, value), true);
     }
-    __device__ __forceinline__ void ac(int run, int zpos, int v)
+    __device__ __forceinline__ void ac(int zpos, int v) { push(sym_entry(zpos, v), started); }
+    __device__ __forceinline__ void unit_end(bool end)
     {
-        pos += run + 1;
-        push(sym_entry(zpos, v), started);
-    }
-    __device__ __forceinline__ void advance(int k) { pos += k; }
-    __device__ __forceinline__ void unit_end()
-    {
-        if (started) du_tab[du_index] = uint2_t{du_off, emitted - du_off};
+        if (end && started) du_tab[du_index] = uint2_t{du_off, emitted - du_off};
     }
     /// One whole 32-byte sector (8 entries) from the ring to memory; `flushed` is a multiple of 8.
     __device__ __forceinline__ void flush_sector()
@@ -632,8 +621,6 @@ __device__ __forceinline__ void block_excl_scan_256(uint32_t v, uint32_t* s_scan
 }
 
 __device__ __forceinline__ uint32_t pk_sub(uint32_t a, uint32_t b) { return pk_add(a, pk_add(~b, 0x00010001u)); }
-__device__ __forceinline__ int lo16(uint32_t v) { return static_cast<int16_t>(v & 0xFFFFu); }
-__device__ __forceinline__ int hi16(uint32_t v) { return static_cast<int16_t>(v >> 16); }
 
 /// Carve of the write kernel's dynamic LDS: scan scratch | write-combining rings | table pack.
 struct WriteLds {
@@ -710,6 +697,7 @@ __global__ __launch_bounds__(T) void huff_write(JS js)
     sink.du_tab  = J.du_tab;
     sink.ring    = s_ring + t;
     int nprefix  = 0;
+    uint32_t pred01 = 0, pred23 = 0; // DC predictors at the lane's first symbol: sums over the segment so far
     {
         block_excl_scan_256<false>(active ? static_cast<uint32_t>(J.st_n[sub]) : 0u, s_scan, s_wave);
         nprefix = static_cast<int>(s_scan[t] - s_scan[ts] + (carried ? s_carry[0] : 0u));
@@ -717,18 +705,15 @@ __global__ __launch_bounds__(T) void huff_write(JS js)
         const uint32_t p01 = pk_add(pk_sub(s_scan[t], s_scan[ts]), carried ? s_carry[1] : 0u);
         block_excl_scan_256<true>(active ? J.st_dc23[sub] : 0u, s_scan, s_wave);
         const uint32_t p23 = pk_add(pk_sub(s_scan[t], s_scan[ts]), carried ? s_carry[2] : 0u);
-        sink.pred[0] = lo16(p01);
-        sink.pred[1] = hi16(p01);
-        sink.pred[2] = lo16(p23);
-        sink.pred[3] = hi16(p23);
+        pred01 = p01;
+        pred23 = p23;
     }
     if (!active) return;
 
-    const int du_words  = sp.du_per_mcu * 64;
     const int seg_mcus0 = seg_i * sp.mcus_per_segment;
     const int seg_mcus1 = min(seg_mcus0 + sp.mcus_per_segment, sp.total_mcus); // Appendix B-5 clamp
-    sink.pos            = seg_mcus0 * du_words + nprefix;
-    sink.quota          = seg_mcus1 * du_words;
+    sink.du             = seg_mcus0 * sp.du_per_mcu + ((nprefix + 63) >> 6);
+    sink.quota          = seg_mcus1 * sp.du_per_mcu;
     sink.flushed        = static_cast<uint32_t>(sub) * J.sym_region; // region base, a multiple of 8
     sink.emitted        = sink.flushed;
     sink.cur_end        = sink.flushed + J.sym_region;
@@ -737,6 +722,8 @@ __global__ __launch_bounds__(T) void huff_write(JS js)
     sink.ticks          = 0;
 
     LaneState st{};
+    st.dc01 = pred01;
+    st.dc23 = pred23;
     if (rel > 0) {
         st.p         = J.st_p[sub - 1];
         const int cz = J.st_cz[sub - 1];

@@ -1,5 +1,6 @@
 // jg_reader.cpp -- see jg_reader.hpp. Status codes per defect follow src/reader.cpp of the reference.
 #include "jg_reader.hpp"
+#include "jg_huff_core.h"
 
 #include <algorithm>
 #include <cstring>
@@ -48,6 +49,39 @@ void build_huff_table(
             voff[l - 9] = num_codes[l - 1] ? static_cast<uint16_t>((first_idx - static_cast<int>(first_code)) & 0xFF) : 0;
         }
         code <<= 1;
+    }
+    // Second-level tables for the LB-bit prefixes that start a valid longer code. Their entries are
+    // what the long-code path returns for each completion, so the two paths cannot disagree.
+    uint32_t prefix_of[256];
+    int num_sub = 0;
+    idx         = 0;
+    code        = 0;
+    for (int l = 1; l <= 16; ++l) {
+        for (int i = 0; i < num_codes[l - 1] && idx < 256; ++i, ++idx, ++code) {
+            if (l <= lb) continue;
+            const uint32_t prefix = (code >> (l - lb)) & ((1u << lb) - 1);
+            if (lut[prefix] != 0 || num_sub == kMaxSubTables) continue; // shorter code / already has one / budget
+            prefix_of[num_sub++] = prefix;
+            lut[prefix]          = static_cast<uint16_t>(num_sub << 5);
+        }
+        code <<= 1;
+    }
+    if (num_sub == 0) return;
+    t.resize(lut_sz + kHuffAuxSize + static_cast<size_t>(num_sub) * kSubTableSize, 0);
+    const uint8_t* aux = t.data() + lut_sz;
+    uint16_t* sub      = reinterpret_cast<uint16_t*>(t.data() + lut_sz + kHuffAuxSize);
+    const int known    = lb + kSubBits;          // window bits a second-level index pins down
+    for (int k = 0; k < num_sub; ++k) {
+        for (uint32_t i2 = 0; i2 < (1u << kSubBits); ++i2) {
+            const uint32_t v    = known >= 16 ? ((prefix_of[k] << kSubBits) | i2) >> (known - 16)
+                                              : ((prefix_of[k] << kSubBits) | i2) << (16 - known);
+            const uint32_t free = known >= 16 ? 0u : (1u << (16 - known)) - 1u;
+            // the entry must not depend on the window bits the index does not cover
+            const uint32_t e0 = huff_long_code(aux, v << 16, is_dc);
+            const uint32_t e1 = huff_long_code(aux, (v | free) << 16, is_dc);
+            const int codelen = static_cast<int>(e0 & 31u) - static_cast<int>((e0 >> 5) & 15u);
+            sub[k * (1 << kSubBits) + i2] = static_cast<uint16_t>((e0 == e1 && codelen <= known) ? e0 : 0u);
+        }
     }
 }
 
@@ -326,6 +360,24 @@ jpeggpu_status Reader::read_sos(const Logger& log)
             scan.ac_off[a] = static_cast<uint16_t>(scan.table_pack.size());
             scan.table_pack.insert(scan.table_pack.end(), ac_tab_[sc.ac_id].begin(), ac_tab_[sc.ac_id].end());
         }
+    }
+    // cursor ring behind the tables (jg_defs.h): one entry per data unit of the MCU
+    scan.cursor_off = static_cast<uint32_t>(scan.table_pack.size());
+    {
+        std::vector<CursorEntry> ring;
+        for (int a = 0; a < ns; ++a) {
+            for (int k = 0; k < scan.comp[a].h * scan.comp[a].v; ++k) {
+                CursorEntry ce;
+                const uint32_t du = static_cast<uint32_t>(ring.size());
+                ce.tabs = scan.dc_off[a] | static_cast<uint32_t>(scan.ac_off[a]) << 16;
+                ce.meta = 16u * a | du << 8;
+                ce.self = scan.cursor_off + 16u * du;
+                ce.next = scan.cursor_off + 16u * (static_cast<int>(du) + 1 == scan.du_per_mcu ? 0u : du + 1u);
+                ring.push_back(ce);
+            }
+        }
+        const uint8_t* rb = reinterpret_cast<const uint8_t*>(ring.data());
+        scan.table_pack.insert(scan.table_pack.end(), rb, rb + ring.size() * sizeof(CursorEntry));
     }
     const int total_mcus  = scan.mcus_x * scan.mcus_y;
     scan.mcus_per_segment = s.restart_interval ? s.restart_interval : total_mcus;

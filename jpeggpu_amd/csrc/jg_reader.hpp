@@ -62,6 +62,7 @@ struct Scan {
     std::vector<uint8_t> table_pack; // tables in force at SOS that this scan's components select
     uint16_t dc_off[kMaxComp] = {};  // byte offset in table_pack per scan component
     uint16_t ac_off[kMaxComp] = {};
+    uint32_t cursor_off = 0;         // byte offset of the cursor ring in table_pack
     std::vector<Segment> segments;
     std::vector<DestuffChunk> chunks;
     std::vector<int> tail_parts; // subsequence ranges [parts[i], parts[i+1]) cut at segment starts

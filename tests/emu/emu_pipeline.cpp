@@ -36,28 +36,23 @@ struct HostSink {
     uint2_t* du_tab;
     uint32_t cur, cur_end, du_off;
     int du_index;
-    int pos, quota;
-    int pred[kMaxComp];
+    int du, quota; // next data unit to start, first data unit past the segment
     bool started;
-    bool full() const { return pos >= quota; }
-    void dc(int comp, int diff)
+    bool full() const { return du >= quota; }
+    void dc(int value)
     {
-        pred[comp] += diff;
         started  = true;
         du_off   = cur;
-        du_index = pos >> 6;
-        if (cur < cur_end) sym[cur++] = sym_entry(0, pred[comp]);
-        ++pos;
+        du_index = du++;
+        if (cur < cur_end) sym[cur++] = sym_entry(0, value);
     }
-    void ac(int run, int zpos, int v)
+    void ac(int zpos, int v)
     {
-        pos += run + 1;
         if (started && cur < cur_end) sym[cur++] = sym_entry(zpos, v);
     }
-    void advance(int k) { pos += k; }
-    void unit_end()
+    void unit_end(bool end)
     {
-        if (started) du_tab[du_index] = uint2_t{du_off, cur - du_off};
+        if (end && started) du_tab[du_index] = uint2_t{du_off, cur - du_off};
     }
     void tick() {}
 };
@@ -141,12 +136,7 @@ int emu_decode_scan(
     sp.total_mcus       = sc.mcus_x * sc.mcus_y;
     sp.subseq_words     = subseq_bytes / 4;
     sp.tab_bytes        = static_cast<uint32_t>(sc.table_pack.size());
-    int du              = 0;
-    for (int a = 0; a < sc.num_comp; ++a) {
-        sp.dc_offs |= static_cast<uint64_t>(sc.dc_off[a]) << (16 * a);
-        sp.ac_offs |= static_cast<uint64_t>(sc.ac_off[a]) << (16 * a);
-        for (int k = 0; k < sc.comp[a].h * sc.comp[a].v; ++k) sp.du_comp |= static_cast<uint32_t>(a) << (2 * du++);
-    }
+    sp.cursor_off       = sc.cursor_off;
     const uint8_t* tabs = sc.table_pack.data();
 
     const int S    = sc.num_subseq;
@@ -327,20 +317,13 @@ int emu_decode_scan(
             sink.du_off  = sink.cur;
             sink.du_index = 0;
             const int nprefix = ex[t].n - ex[ts].n + (carried ? carry.n : 0);
-            {
-                const auto sub16 = [](uint32_t a, uint32_t b) { return pk_add_u16(a, pk_add_u16(~b, 0x00010001u)); };
-                const uint32_t p01 = pk_add_u16(sub16(ex[t].dc01, ex[ts].dc01), carried ? carry.dc01 : 0u);
-                const uint32_t p23 = pk_add_u16(sub16(ex[t].dc23, ex[ts].dc23), carried ? carry.dc23 : 0u);
-                sink.pred[0] = static_cast<int16_t>(p01 & 0xFFFF);
-                sink.pred[1] = static_cast<int16_t>(p01 >> 16);
-                sink.pred[2] = static_cast<int16_t>(p23 & 0xFFFF);
-                sink.pred[3] = static_cast<int16_t>(p23 >> 16);
-            }
-            const int du_words = sp.du_per_mcu * 64;
+            const auto sub16 = [](uint32_t a, uint32_t b) { return pk_add_u16(a, pk_add_u16(~b, 0x00010001u)); };
             const int m0 = seg_i * sp.mcus_per_segment, m1 = std::min(m0 + sp.mcus_per_segment, sp.total_mcus);
-            sink.pos   = m0 * du_words + nprefix;
-            sink.quota = m1 * du_words;
+            sink.du    = m0 * sp.du_per_mcu + ((nprefix + 63) >> 6);
+            sink.quota = m1 * sp.du_per_mcu;
             LaneState ls{};
+            ls.dc01 = pk_add_u16(sub16(ex[t].dc01, ex[ts].dc01), carried ? carry.dc01 : 0u); // predictors so far
+            ls.dc23 = pk_add_u16(sub16(ex[t].dc23, ex[ts].dc23), carried ? carry.dc23 : 0u);
             if (rel > 0) {
                 ls.p = st[sub - 1].p;
                 ls.c = st[sub - 1].cz & 0xFF;
