@@ -276,17 +276,21 @@ def main():
         pinned = torch.empty(len(s0.data), dtype=torch.uint8).pin_memory()
         pinned.numpy()[:] = memoryview(s0.data)
         host_ptr, host_n = pinned.data_ptr(), pinned.numel()
-        lat = []
+        lat, lat_parse, lat_enqueue = [], [], []
         st = streams[0]
         for it in range(args.latency_iters + 3):
             t1 = time.perf_counter()
             s0.dec.parse_header(host_ptr, host_n)
             n = s0.dec.get_buffer_size()
+            t2 = time.perf_counter()
             s0.dec.transfer(s0.base, n, st.cuda_stream)
             s0.dec.decode(s0.ptrs, s0.pitches, s0.base, n, st.cuda_stream)
+            t3 = time.perf_counter()
             st.synchronize()
             if it >= 3:
                 lat.append((time.perf_counter() - t1) * 1e3)
+                lat_parse.append((t2 - t1) * 1e3)
+                lat_enqueue.append((t3 - t2) * 1e3)
         # device-only latency of one decode, nothing else running
         s0.dec.set_profiling(True)
         for _ in range(10):
@@ -353,6 +357,8 @@ def main():
             "latency_ms": {"protocol": "parse+size+transfer+decode+sync, 1 image, 1 stream, pinned input",
                            "subsequence_bytes": s0.layout.subsequence_bytes,
                            "p50": statistics.median(lat), "mean": statistics.fmean(lat), "max": max(lat),
+                           "p50_host_parse": statistics.median(lat_parse),
+                           "p50_host_enqueue": statistics.median(lat_enqueue),
                            "iters": len(lat), "images_per_s_single_stream": 1e3 / statistics.fmean(lat)},
         }
         if not args.no_cpu:

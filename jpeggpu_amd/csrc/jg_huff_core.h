@@ -148,9 +148,7 @@ struct NoSink {
     static constexpr bool kWrite      = false;
     static constexpr bool kWholeUnits = false;
     JG_HD inline bool full() const { return false; }
-    JG_HD inline void dc(int) {}
-    JG_HD inline void ac(int, int) {}
-    JG_HD inline void unit_end(bool) {}
+    JG_HD inline void symbol(bool, bool, uint32_t, bool) {}
     JG_HD inline void tick() {}
 };
 
@@ -215,27 +213,30 @@ JG_HD inline void decode_subsequence(
         if (Sink::kWholeUnits ? (is_dc && (beyond || sink.full())) : beyond) break;
         bw.skip(total);
         p += total;
-        const int adv = e >> 9;
-        if (Sink::kWrite || is_dc) {
-            const int s = (e >> 5) & 15;
-            const int v = extend_magnitude(bits_field(peek, total, s), s);
-            if (is_dc) {
-                const int sh     = JG_CUR_META & 63;
-                const uint64_t d = static_cast<uint64_t>(static_cast<uint32_t>(v) & 0xFFFFu) << sh;
-                dc01             = pk_add_u16(dc01, static_cast<uint32_t>(d));
-                dc23             = pk_add_u16(dc23, static_cast<uint32_t>(d >> 32));
-                // the component's running sum is the absolute DC value, 16-bit wrap like the
-                // reference's int16 prefix sum (decode_dc.cu:129-155)
-                if (Sink::kWrite) sink.dc(static_cast<int>(((static_cast<uint64_t>(dc23) << 32) | dc01) >> sh));
-            } else if (Sink::kWrite) {
-                if (s) sink.ac(z + adv - 1, v);
-            }
-        }
+        const int adv     = e >> 9;
         const int z1      = z + adv;
         const bool du_end = z1 >= 64;
-        z                 = du_end ? 0 : z1;
+        if (Sink::kWrite) {
+            // branch-free: every lane computes the magnitude, only DC symbols move the sums
+            const int s       = (e >> 5) & 15;
+            const int v       = extend_magnitude(bits_field(peek, total, s), s);
+            const int sh      = JG_CUR_META & 63;
+            const uint64_t d  = static_cast<uint64_t>(is_dc ? static_cast<uint32_t>(v) & 0xFFFFu : 0u) << sh;
+            dc01              = pk_add_u16(dc01, static_cast<uint32_t>(d));
+            dc23              = pk_add_u16(dc23, static_cast<uint32_t>(d >> 32));
+            // the component's running sum is the absolute DC value, 16-bit wrap like the reference's
+            // int16 prefix sum (decode_dc.cu:129-155); an AC coefficient sits at zig-zag index z1 - 1
+            const int absdc   = static_cast<int>(((static_cast<uint64_t>(dc23) << 32) | dc01) >> sh);
+            sink.symbol(is_dc, s != 0, sym_entry(z1 - 1, is_dc ? absdc : v), du_end);
+        } else if (is_dc) {
+            const int s      = (e >> 5) & 15;
+            const int v      = extend_magnitude(bits_field(peek, total, s), s);
+            const uint64_t d = static_cast<uint64_t>(static_cast<uint32_t>(v) & 0xFFFFu) << (JG_CUR_META & 63);
+            dc01             = pk_add_u16(dc01, static_cast<uint32_t>(d));
+            dc23             = pk_add_u16(dc23, static_cast<uint32_t>(d >> 32));
+        }
+        z = du_end ? 0 : z1;
         units += du_end ? 1 : 0;
-        if (Sink::kWrite) sink.unit_end(du_end);
         cur = JG_LOAD_CURSOR(du_end ? JG_CUR_NEXT : JG_CUR_SELF);
         if (Sink::kWrite) sink.tick(); // once per iteration, whatever the symbol was
     }

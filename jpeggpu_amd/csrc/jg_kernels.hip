@@ -186,9 +186,10 @@ struct LdsFetch {
 /// segment); the byte swap and the zero-beyond-the-end select happen in cook(), when the word is
 /// shifted into the window one refill later -- a select right behind the load would wait for it.
 struct GlobalFetch {
-    const uint32_t* words; // first word of the segment
+    const uint32_t* scan32; // the scan's destuffed buffer: the same for every lane (scalar base address)
+    int seg_word0;          // first word of the lane's segment
     int seg_words;
-    __device__ __forceinline__ uint32_t raw(int w) const { return words[min(w, seg_words - 1)]; }
+    __device__ __forceinline__ uint32_t raw(int w) const { return scan32[seg_word0 + min(w, seg_words - 1)]; }
     __device__ __forceinline__ uint32_t cook(uint32_t v, int w) const
     {
         return w < seg_words ? __builtin_bswap32(v) : 0u;
@@ -429,7 +430,7 @@ __global__ __launch_bounds__(TL) void huff_sync_tail(JS js)
                 const Segment seg = J.segments[J.seg_idx[j - 1]];
                 const int lim     = seg.subseq_offset + seg.subseq_count;
                 if (j < lim) {
-                    GlobalFetch fetch{scan32 + static_cast<size_t>(seg.subseq_offset) * W, seg.subseq_count * W};
+                    GlobalFetch fetch{scan32, seg.subseq_offset * W, seg.subseq_count * W};
                     LaneState st{};
                     st.p = p;
                     st.c = cz & 0xFF;
@@ -549,33 +550,28 @@ struct StreamSink {
     int ticks;
     bool started; // false while the first symbols finish the predecessor's data unit
     __device__ __forceinline__ bool full() const { return du >= quota; }
-    /// Branch-free append: a lane that is not emitting (still finishing its predecessor's unit, or
-    /// past its region on a corrupt stream) writes the spare ring row and does not advance.
-    __device__ __forceinline__ void push(uint32_t e, bool emit)
+    /// One call per decoded symbol, branch-free. `entry` is the stream entry of a DC symbol (absolute
+    /// value, index 0) or of an AC symbol; zero AC coefficients, symbols that finish the predecessor's
+    /// unit, and anything past the region on a corrupt stream go to the spare ring row.
+    __device__ __forceinline__ void symbol(bool is_dc, bool nonzero, uint32_t entry, bool unit_end)
     {
-        emit                = emit && emitted < cur_end;
+        du_off   = is_dc ? emitted : du_off;
+        du_index = is_dc ? du : du_index;
+        du += is_dc ? 1 : 0;
+        started             = started || is_dc;
+        const bool emit     = started && (is_dc || nonzero) && emitted < cur_end;
         const uint32_t slot = emit ? (emitted & (kStageEntries - 1)) : kStageEntries;
-        ring[slot * T]      = e;
+        ring[slot * T]      = entry;
         emitted += emit ? 1u : 0u;
-    }
-    __device__ __forceinline__ void dc(int value)
-    {
-        started  = true;
-        du_off   = emitted;
-        du_index = du++;
-        push(sym_entry(0, value), true);
-    }
-    __device__ __forceinline__ void ac(int zpos, int v) { push(sym_entry(zpos, v), started); }
-    __device__ __forceinline__ void unit_end(bool end)
-    {
-        if (end && started) du_tab[du_index] = uint2_t{du_off, emitted - du_off};
+        if (unit_end && started) du_tab[du_index] = uint2_t{du_off, emitted - du_off};
     }
     /// One whole 32-byte sector (8 entries) from the ring to memory; `flushed` is a multiple of 8.
     __device__ __forceinline__ void flush_sector()
     {
         uint32_t e[8];
+        const uint32_t* r = ring + (flushed & (kStageEntries - 1)) * T; // flushed % 8 == 0: no wrap inside
 #pragma unroll
-        for (int k = 0; k < 8; ++k) e[k] = ring[((flushed + k) & (kStageEntries - 1)) * T];
+        for (int k = 0; k < 8; ++k) e[k] = r[k * T];
         uint4* dst = reinterpret_cast<uint4*>(sym + flushed);
         dst[0]     = make_uint4(e[0], e[1], e[2], e[3]);
         dst[1]     = make_uint4(e[4], e[5], e[6], e[7]);
@@ -731,8 +727,7 @@ __global__ __launch_bounds__(T) void huff_write(JS js)
         st.z         = cz >> 8;
     }
     sink.started = st.z == 0;
-    GlobalFetch fetch{reinterpret_cast<const uint32_t*>(J.destuffed) + static_cast<size_t>(seg.subseq_offset) * W,
-                      seg.subseq_count * W};
+    GlobalFetch fetch{reinterpret_cast<const uint32_t*>(J.destuffed), seg.subseq_offset * W, seg.subseq_count * W};
     BitWindow<GlobalFetch> bw{};
     bw.seek(st.p, fetch);
     decode_subsequence(st, bw, fetch, (rel + 1) * (W * 32), s_tab, sp, sink);

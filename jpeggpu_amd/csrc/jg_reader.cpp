@@ -3,6 +3,13 @@
 #include "jg_huff_core.h"
 
 #include <algorithm>
+#if defined(__SSE2__)
+#include <immintrin.h>
+#define JG_HAVE_SSE2 1
+#else
+#define JG_HAVE_SSE2 0
+#endif
+#include <cstdlib>
 #include <cstring>
 
 namespace jg {
@@ -14,6 +21,61 @@ constexpr int kNatural[64] = JG_ORDER_NATURAL;
 
 inline int ceil_div(int a, int b) { return (a + b - 1) / b; }
 } // namespace
+
+#if JG_HAVE_SSE2
+/// Result of scanning entropy-coded bytes [from, lim): the first FF that is not followed by 00 (a
+/// marker or fill byte) if there is one, and the number of FF bytes before it (all stuffed).
+struct WindowScan {
+    const uint8_t* marker;
+    uint32_t ff;
+};
+
+/// 64-byte blocks aligned to `grid`; `lim - grid` is a multiple of 64 and byte `lim` is readable.
+#define JG_SCAN_WINDOW_BODY(MASKS)                                                                  \
+    const size_t fo    = static_cast<size_t>(from - grid);                                          \
+    const uint8_t* blk = grid + (fo & ~static_cast<size_t>(63));                                    \
+    uint64_t keep      = ~0ull << (fo & 63);                                                        \
+    uint32_t count     = 0;                                                                         \
+    for (; blk < lim; blk += 64, keep = ~0ull) {                                                    \
+        uint64_t ff, zr;                                                                            \
+        MASKS;                                                                                      \
+        ff &= keep;                                                                                 \
+        if (ff == 0) continue;                                                                      \
+        const uint64_t next_zero = (zr >> 1) | (static_cast<uint64_t>(blk[64] == 0) << 63);         \
+        const uint64_t mk        = ff & ~next_zero;                                                 \
+        if (mk) {                                                                                   \
+            const int k = __builtin_ctzll(mk);                                                      \
+            count += static_cast<uint32_t>(__builtin_popcountll(ff & ((1ull << k) - 1ull)));        \
+            return WindowScan{blk + k, count};                                                      \
+        }                                                                                           \
+        count += static_cast<uint32_t>(__builtin_popcountll(ff));                                   \
+    }                                                                                               \
+    return WindowScan{nullptr, count};
+
+WindowScan scan_window_sse2(const uint8_t* from, const uint8_t* lim, const uint8_t* grid)
+{
+    JG_SCAN_WINDOW_BODY(
+        ff = 0; zr = 0; for (int k = 0; k < 4; ++k) {
+            const __m128i a = _mm_loadu_si128(reinterpret_cast<const __m128i*>(blk + 16 * k));
+            ff |= static_cast<uint64_t>(static_cast<uint32_t>(_mm_movemask_epi8(_mm_cmpeq_epi8(a, _mm_set1_epi8(static_cast<char>(0xFF)))))) << (16 * k);
+            zr |= static_cast<uint64_t>(static_cast<uint32_t>(_mm_movemask_epi8(_mm_cmpeq_epi8(a, _mm_setzero_si128())))) << (16 * k);
+        })
+}
+
+__attribute__((target("avx2,popcnt"))) WindowScan scan_window_avx2(const uint8_t* from, const uint8_t* lim, const uint8_t* grid)
+{
+    JG_SCAN_WINDOW_BODY(
+        const __m256i a0 = _mm256_loadu_si256(reinterpret_cast<const __m256i*>(blk));
+        const __m256i a1 = _mm256_loadu_si256(reinterpret_cast<const __m256i*>(blk + 32));
+        const __m256i vf = _mm256_set1_epi8(static_cast<char>(0xFF));
+        const __m256i vz = _mm256_setzero_si256();
+        ff = static_cast<uint32_t>(_mm256_movemask_epi8(_mm256_cmpeq_epi8(a0, vf))) |
+             static_cast<uint64_t>(static_cast<uint32_t>(_mm256_movemask_epi8(_mm256_cmpeq_epi8(a1, vf)))) << 32;
+        zr = static_cast<uint32_t>(_mm256_movemask_epi8(_mm256_cmpeq_epi8(a0, vz))) |
+             static_cast<uint64_t>(static_cast<uint32_t>(_mm256_movemask_epi8(_mm256_cmpeq_epi8(a1, vz)))) << 32;)
+}
+#undef JG_SCAN_WINDOW_BODY
+#endif
 
 void build_huff_table(
     std::vector<uint8_t>& t, const uint8_t (&num_codes)[16], const uint8_t* huffval, int count, bool is_dc)
@@ -421,7 +483,41 @@ jpeggpu_status Reader::walk_scan(Scan& scan, const Logger& log)
         ff_in_chunk = 0;
     };
 
+    // Bulk part of the walk (scan_window above): whole destuff windows at a time; the per-byte code
+    // below runs at real markers and near the end of the buffer.
+    const uint8_t* const grid = base_ + xb;
+    const auto skip_data = [&](const uint8_t* from) -> const uint8_t* {
+#if JG_HAVE_SSE2
+        // JPEGGPU_HOST_SIMD = scalar | sse2 pins the path (tests cover all three); default: best available
+        const char* pin      = std::getenv("JPEGGPU_HOST_SIMD");
+        if (pin && std::strcmp(pin, "scalar") == 0) return from;
+        const bool have_avx2 = !(pin && std::strcmp(pin, "sse2") == 0) && __builtin_cpu_supports("avx2") &&
+                               __builtin_cpu_supports("popcnt");
+        // blocks [.., last_blk) can be scanned: the byte behind a block must be readable
+        const uint8_t* const last_blk = end_ - grid > 64 ? grid + ((static_cast<size_t>(end_ - grid) - 1) & ~static_cast<size_t>(63)) : grid;
+        while (true) {
+            const uint8_t* wend = grid + next_win;
+            if (from >= wend) {
+                emit(chunk_begin, next_win);
+                chunk_begin = next_win;
+                next_win += kDestuffWin;
+                continue;
+            }
+            const uint8_t* lim = wend < last_blk ? wend : last_blk;
+            if (from >= lim) return from;
+            const WindowScan r = have_avx2 ? scan_window_avx2(from, lim, grid) : scan_window_sse2(from, lim, grid);
+            ff_in_chunk += r.ff;
+            if (r.marker) return r.marker;
+            from = lim;
+            if (lim != wend) return from;
+        }
+#else
+        return from;
+#endif
+    };
+
     while (true) {
+        pos = skip_data(pos);
         const uint8_t* q =
             static_cast<const uint8_t*>(std::memchr(pos, 0xFF, static_cast<size_t>(end_ - pos)));
         if (q == nullptr || q + 1 >= end_) return JPEGGPU_INVALID_JPEG; // no end-of-image marker
@@ -497,7 +593,27 @@ jpeggpu_status Reader::walk_scan(Scan& scan, const Logger& log)
 
 jpeggpu_status Reader::parse(const uint8_t* data, size_t size, int subseq_bytes, const Logger& log)
 {
-    s             = Stream{};
+    {
+        // reset, keeping the capacity of the per-scan vectors: a decoder parses image after image
+        Scan keep[kMaxScans];
+        for (int i = 0; i < kMaxScans; ++i) {
+            keep[i].table_pack.swap(s.scans[i].table_pack);
+            keep[i].segments.swap(s.scans[i].segments);
+            keep[i].chunks.swap(s.scans[i].chunks);
+            keep[i].tail_parts.swap(s.scans[i].tail_parts);
+        }
+        s = Stream{};
+        for (int i = 0; i < kMaxScans; ++i) {
+            keep[i].table_pack.clear();
+            keep[i].segments.clear();
+            keep[i].chunks.clear();
+            keep[i].tail_parts.clear();
+            s.scans[i].table_pack.swap(keep[i].table_pack);
+            s.scans[i].segments.swap(keep[i].segments);
+            s.scans[i].chunks.swap(keep[i].chunks);
+            s.scans[i].tail_parts.swap(keep[i].tail_parts);
+        }
+    }
     std::memset(s.qtable, 0, sizeof(s.qtable));
     base_         = data;
     cur_          = data;

@@ -39,20 +39,16 @@ struct HostSink {
     int du, quota; // next data unit to start, first data unit past the segment
     bool started;
     bool full() const { return du >= quota; }
-    void dc(int value)
+    /// `entry` of a DC symbol (absolute value, index 0) or of an AC symbol (zero coefficients emit nothing)
+    void symbol(bool is_dc, bool nonzero, uint32_t entry, bool unit_end)
     {
-        started  = true;
-        du_off   = cur;
-        du_index = du++;
-        if (cur < cur_end) sym[cur++] = sym_entry(0, value);
-    }
-    void ac(int zpos, int v)
-    {
-        if (started && cur < cur_end) sym[cur++] = sym_entry(zpos, v);
-    }
-    void unit_end(bool end)
-    {
-        if (end && started) du_tab[du_index] = uint2_t{du_off, cur - du_off};
+        if (is_dc) {
+            started  = true;
+            du_off   = cur;
+            du_index = du++;
+        }
+        if ((is_dc || (started && nonzero)) && cur < cur_end) sym[cur++] = entry;
+        if (unit_end && started) du_tab[du_index] = uint2_t{du_off, cur - du_off};
     }
     void tick() {}
 };

@@ -34,3 +34,26 @@ def test_emulated_photo(photo_bytes):
         rc, r = emu.decode_scan(photo_bytes, 0, 128, cap)
         assert rc == 0 and np.array_equal(r.coef, tw.stream_coef)
         assert r.max_flow_iters >= 1
+
+
+@pytest.mark.parametrize("simd", ["auto", "sse2", "scalar"])
+def test_marker_walk_at_every_alignment(simd, monkeypatch):
+    """The host walk scans 64-byte blocks on the destuff-window grid (jg_reader.cpp, scan_window):
+    shift the entropy-coded bytes through every position of a block (a COM segment of growing length
+    in front of them) and across window edges, for streams rich in stuffed FF bytes, restart markers
+    and fill bytes; destuffed bytes, segment index and coefficients must not change."""
+    if simd != "auto":
+        monkeypatch.setenv("JPEGGPU_HOST_SIMD", simd)
+    m = cases.matrix()
+    for name in ("multi_seq_dri", "dri_fill", "q100_noisy", "dri_1"):
+        data = m[name]
+        tw = oracle.scan_stages(data, 0, 64)
+        assert data[:2] == b"\xff\xd8"
+        for shift in list(range(0, 66)) + [4096 - 20 + k for k in range(0, 40, 3)]:
+            com = b"\xff\xfe" + (2 + shift).to_bytes(2, "big") + bytes(shift)
+            shifted = data[:2] + com + data[2:]
+            rc, r = emu.decode_scan(shifted, 0, 64, 256)
+            assert rc == 0, (name, shift)
+            assert np.array_equal(r.destuffed, tw.destuffed), (name, shift, "destuffed bytes")
+            assert np.array_equal(r.seg_index, tw.seg_index), (name, shift, "segment index")
+            assert np.array_equal(r.coef, tw.stream_coef), (name, shift, "coefficients")
