@@ -149,7 +149,7 @@ void Decoder::make_plan()
         const size_t S = static_cast<size_t>(sc.num_subseq);
         sp.num_seq     = static_cast<int>((S + kSeqSubseq - 1) / kSeqSubseq);
         sp.destuffed   = o;
-        o += align_up(S * subseq_bytes + 256, 256);
+        o += align_up((S + kTileSubseq) / kTileSubseq * kTileSubseq * subseq_bytes + 256, 256); // whole tiles
         sp.seg_idx = o;
         o += align_up(S * 4, 256);
         sp.st_p = o;

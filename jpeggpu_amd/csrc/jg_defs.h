@@ -81,6 +81,18 @@ JG_HD inline uint32_t huff_entry(int codelen, uint32_t sym, bool is_dc)
     return (static_cast<uint32_t>(codelen) + s) | (s << 5) | ((eob ? 64u : r + 1u) << 9);
 }
 
+/// Layout of the destuffed buffer: TILES of kTileSubseq subsequences, word-major inside a tile -- word k
+/// of subsequence t is 32-bit word (t / 32) * 32 * W + k * 32 + t % 32 (W = words per subsequence). The
+/// lanes of a wave walk 64 different subsequences at about the same pace, so their 4-byte refills fall
+/// into a few shared 128-byte lines; with the plain layout every refill touched its own line
+/// (lane stride = 128 B) and the write pass fetched 25x the bitstream (rocprofv3 FETCH_SIZE).
+constexpr int kTileSubseq = 32;
+JG_HD inline uint32_t tiled_word(uint32_t linear_word, int log2_w)
+{
+    const uint32_t t = linear_word >> log2_w, k = linear_word & ((1u << log2_w) - 1u);
+    return ((t >> 5) << (5 + log2_w)) + (k << 5) + (t & 31u);
+}
+
 /// Entries of the symbol stream reserved per subsequence: an emitted entry (DC, or a non-zero AC
 /// coefficient with its magnitude bits) takes at least 2 bits of the stream on average over a data
 /// unit, plus up to one data unit of overrun (a lane finishes the unit it started).

@@ -121,20 +121,24 @@ __global__ __launch_bounds__(256) void destuff_kernel(JS js)
     }
     __syncthreads();
 
-    // write-out: 16-byte granules of the destination, aligned
-    uint8_t* const dbase = dst + (ck.dst_off - phase);
-    const uint32_t lo = phase, hi = phase + total; // valid LDS byte range
-    for (uint32_t g = t; g * 16 < hi; g += 256) {
-        const uint32_t b0 = g * 16;
-        if (b0 >= lo && b0 + 16 <= hi) {
-            *reinterpret_cast<uint4*>(dbase + b0) = *reinterpret_cast<const uint4*>(s_out + b0);
+    // write-out into the tiled layout (jg_defs.h): 4-byte words, byte stores at the two ragged ends
+    // (neighbouring chunks own the other bytes of those words)
+    const int log2w          = 31 - __clz(J.sp.subseq_words);
+    uint32_t* const dst32    = reinterpret_cast<uint32_t*>(dst);
+    const uint32_t word0     = (ck.dst_off - phase) >> 2; // linear word of s_out[0]
+    const uint32_t lo = phase, hi = phase + total;        // valid LDS byte range
+    for (uint32_t g = t; g * 4 < hi; g += 256) {
+        const uint32_t b0 = g * 4;
+        const uint32_t tw = tiled_word(word0 + g, log2w);
+        if (b0 >= lo && b0 + 4 <= hi) {
+            dst32[tw] = *reinterpret_cast<const uint32_t*>(s_out + b0);
         } else {
-            for (uint32_t b = b0 > lo ? b0 : lo; b < b0 + 16 && b < hi; ++b) dbase[b] = s_out[b];
+            for (uint32_t b = b0 > lo ? b0 : lo; b < b0 + 4 && b < hi; ++b) dst[tw * 4 + (b & 3)] = s_out[b];
         }
     }
     // zero the tail of the segment up to its subsequence-aligned end
     if (ck.pad_end) {
-        for (uint32_t b = ck.dst_off + total + t; b < ck.pad_end; b += 256) dst[b] = 0;
+        for (uint32_t b = ck.dst_off + total + t; b < ck.pad_end; b += 256) dst[tiled_word(b >> 2, log2w) * 4 + (b & 3)] = 0;
     }
     // subsequences that start inside this chunk's destination range belong to this segment
     if (total) {
@@ -185,37 +189,48 @@ struct LdsFetch {
 /// Words straight from the destuffed buffer. raw() only issues the load (address clamped into the
 /// segment); the byte swap and the zero-beyond-the-end select happen in cook(), when the word is
 /// shifted into the window one refill later -- a select right behind the load would wait for it.
+template <int W>
 struct GlobalFetch {
-    const uint32_t* scan32; // the scan's destuffed buffer: the same for every lane (scalar base address)
-    int seg_word0;          // first word of the lane's segment
+    static constexpr int kLog2W = W == 8 ? 3 : W == 16 ? 4 : 5;
+    const uint32_t* scan32; // the scan's destuffed buffer (tiled): the same for every lane (scalar base address)
+    int seg_word0;          // first (linear) word of the lane's segment
     int seg_words;
-    __device__ __forceinline__ uint32_t raw(int w) const { return scan32[seg_word0 + min(w, seg_words - 1)]; }
+    __device__ __forceinline__ uint32_t raw(int w) const
+    {
+        return scan32[tiled_word(static_cast<uint32_t>(seg_word0 + min(w, seg_words - 1)), kLog2W)];
+    }
     __device__ __forceinline__ uint32_t cook(uint32_t v, int w) const
     {
         return w < seg_words ? __builtin_bswap32(v) : 0u;
     }
 };
 
-/// Stage subsequences [img_first, img_first + T) (clipped to [0, num_subseq)) into LDS.
+/// Stage subsequences [img_first, img_first + T) (clipped to [0, num_subseq)) into LDS. The tiled global
+/// layout is word-major like the image, so 32 consecutive lanes copy 128 contiguous bytes.
 template <int W>
 __device__ __forceinline__ void load_image(
     uint32_t* img, const uint32_t* __restrict__ scan32, int img_first, int num_subseq)
 {
-    const int lo        = max(0, -img_first) * W;             // first valid local word
-    const int hi        = min(T, num_subseq - img_first) * W; // one past the last valid local word
-    const uint32_t* src = scan32 + static_cast<ptrdiff_t>(img_first) * W;
-    for (int i = lo + threadIdx.x; i < hi; i += T) {
-        img[(i % W) * SeqImage<W>::kStride + i / W] = __builtin_bswap32(src[i]);
+    constexpr int kLog2W = LdsFetch<W>::kLog2W;
+    const int lo = max(0, -img_first);             // first local subsequence that exists
+    const int hi = min(T, num_subseq - img_first); // one past the last
+    for (int i = threadIdx.x; i < T * W; i += T) {
+        const int k = i / T, t = i % T;            // T lanes share k: conflict-free LDS stores
+        if (t >= lo && t < hi)
+            img[k * SeqImage<W>::kStride + t] =
+                __builtin_bswap32(scan32[tiled_word(static_cast<uint32_t>((img_first + t) * W + k), kLog2W)]);
     }
     if (threadIdx.x < 3) {
-        // words T*W + 0..2 -> (k = 0..2, t = T); the destuffed buffer has 256 spare bytes at its end
+        // words T*W + 0..2 -> (k = 0..2, t = T)
         const bool more = img_first + T < num_subseq;
-        img[threadIdx.x * SeqImage<W>::kStride + T] = more ? __builtin_bswap32(src[T * W + threadIdx.x]) : 0u;
+        img[threadIdx.x * SeqImage<W>::kStride + T] =
+            more ? __builtin_bswap32(scan32[tiled_word(static_cast<uint32_t>((img_first + T) * W + threadIdx.x), kLog2W)]) : 0u;
     }
     if (threadIdx.x == 3) img[3 * SeqImage<W>::kStride + T] = 0u; // the zero word
     if (threadIdx.x == 4) {
         // word -1 -> (k = W-1, t = -1)
-        img[(W - 1) * SeqImage<W>::kStride - 1] = img_first > 0 ? __builtin_bswap32(src[-1]) : 0u;
+        img[(W - 1) * SeqImage<W>::kStride - 1] =
+            img_first > 0 ? __builtin_bswap32(scan32[tiled_word(static_cast<uint32_t>(img_first * W - 1), kLog2W)]) : 0u;
     }
 }
 
@@ -430,12 +445,12 @@ __global__ __launch_bounds__(TL) void huff_sync_tail(JS js)
                 const Segment seg = J.segments[J.seg_idx[j - 1]];
                 const int lim     = seg.subseq_offset + seg.subseq_count;
                 if (j < lim) {
-                    GlobalFetch fetch{scan32, seg.subseq_offset * W, seg.subseq_count * W};
+                    GlobalFetch<W> fetch{scan32, seg.subseq_offset * W, seg.subseq_count * W};
                     LaneState st{};
                     st.p = p;
                     st.c = cz & 0xFF;
                     st.z = cz >> 8;
-                    BitWindow<GlobalFetch> bw{};
+                    BitWindow<GlobalFetch<W>> bw{};
                     bw.seek(st.p, fetch);
                     decode_subsequence(st, bw, fetch, (j - seg.subseq_offset + 1) * (W * 32), s_tab, sp, sink);
                     p        = st.p;
@@ -727,8 +742,8 @@ __global__ __launch_bounds__(T) void huff_write(JS js)
         st.z         = cz >> 8;
     }
     sink.started = st.z == 0;
-    GlobalFetch fetch{reinterpret_cast<const uint32_t*>(J.destuffed), seg.subseq_offset * W, seg.subseq_count * W};
-    BitWindow<GlobalFetch> bw{};
+    GlobalFetch<W> fetch{reinterpret_cast<const uint32_t*>(J.destuffed), seg.subseq_offset * W, seg.subseq_count * W};
+    BitWindow<GlobalFetch<W>> bw{};
     bw.seek(st.p, fetch);
     decode_subsequence(st, bw, fetch, (rel + 1) * (W * 32), s_tab, sp, sink);
     sink.finish();
