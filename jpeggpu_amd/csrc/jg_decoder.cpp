@@ -292,6 +292,11 @@ jpeggpu_status build_jobs(
         ip.num_du      = sc.num_du;
         ip.du_per_mcu  = sc.du_per_mcu;
         ip.mcus_x      = sc.mcus_x;
+        {
+            const MagicDiv a = magic_div(static_cast<uint32_t>(sc.du_per_mcu)), b = magic_div(static_cast<uint32_t>(sc.mcus_x));
+            ip.du_per_mcu_mul = a.mul, ip.du_per_mcu_shift = a.shift;
+            ip.mcus_x_mul = b.mul, ip.mcus_x_shift = b.shift;
+        }
         int du         = 0;
         for (int a = 0; a < sc.num_comp; ++a) {
             const ScanComponent& c = sc.comp[a];

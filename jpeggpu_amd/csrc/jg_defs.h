@@ -149,9 +149,12 @@ static_assert(sizeof(CursorEntry) == 16, "read with one 16-byte load");
 /// Geometry for dequant + IDCT reading the stream-order coefficient buffer (replaces the reference's
 /// separate transpose pass, src/decode_transpose.cu:41-132, plus src/idct.cu:146-223).
 struct IdctParams {
-    int num_du;     // data units in the scan
+    int num_du;     // data units in the scan (< 2^31)
     int du_per_mcu;
     int mcus_x;
+    // n / d for n < 2^31 as (mulhi(n, mul) >> shift); mul == 0 stands for d == 1 (jg_defs.h, magic_div)
+    uint32_t du_per_mcu_mul, du_per_mcu_shift;
+    uint32_t mcus_x_mul, mcus_x_shift;
     uint8_t du_comp[kMaxDuPerMcu]; // scan-component index of each data unit in the MCU
     uint8_t du_dx[kMaxDuPerMcu];   // block column inside the MCU
     uint8_t du_dy[kMaxDuPerMcu];   // block row inside the MCU
@@ -163,6 +166,21 @@ struct IdctParams {
     int qidx[kMaxComp];            // quantisation table index
     uint8_t* plane[kMaxComp];
 };
+
+/// Division by a runtime constant: for 2 <= d and n < 2^31, with L = ceil(log2 d) and
+/// M = ceil(2^(31+L) / d) (< 2^32), floor(n / d) == (mulhi(n, M) >> (L - 1)): the error term
+/// n * (M * d - 2^(31+L)) / (d * 2^(31+L)) is below 1 / d.
+struct MagicDiv {
+    uint32_t mul, shift;
+};
+inline MagicDiv magic_div(uint32_t d)
+{
+    if (d <= 1) return MagicDiv{0u, 0u};
+    uint32_t l = 0;
+    while ((1u << l) < d) ++l;
+    const uint64_t m = ((1ull << (31 + l)) + d - 1) / d;
+    return MagicDiv{static_cast<uint32_t>(m), l - 1};
+}
 
 /// Everything the kernels need to know about one scan of one image: a launch covers one job (passed
 /// by value, the drop-in API) or an array of jobs, one per blockIdx.y (the batch API).

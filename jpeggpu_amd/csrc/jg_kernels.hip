@@ -753,7 +753,6 @@ __global__ __launch_bounds__(T) void huff_write(JS js)
 // dequantisation + inverse DCT
 // ------------------------------------------------------------------------------------------------
 
-__device__ __forceinline__ int unfixh(int x) { return static_cast<int16_t>((x + 0x8000) >> 16); }
 __device__ __forceinline__ int unfixo(int x) { return (x + 0x1000) >> 13; }
 
 /// 8-point fixed-point inverse DCT, the arithmetic of the reference's `idct_vector`
@@ -779,14 +778,32 @@ __device__ __forceinline__ void idct8(int (&v)[8])
     const int b2 = o2 * ocos_5_16 + o3 * osin_5_16;
     const int b3 = o2 * osin_5_16 - o3 * ocos_5_16;
 
-    v[0] = unfixh(a0 + b0);
-    v[1] = unfixh(a1 + b3);
-    v[2] = unfixh(a2 + b2);
-    v[3] = unfixh(a3 + b1);
-    v[4] = unfixh(a3 - b1);
-    v[5] = unfixh(a2 - b2);
-    v[6] = unfixh(a1 - b3);
-    v[7] = unfixh(a0 - b0);
+    // results rounded but NOT shifted: the int16 the reference stores (`unfixh`) is the high half
+    v[0] = a0 + b0 + 0x8000;
+    v[1] = a1 + b3 + 0x8000;
+    v[2] = a2 + b2 + 0x8000;
+    v[3] = a3 + b1 + 0x8000;
+    v[4] = a3 - b1 + 0x8000;
+    v[5] = a2 - b2 + 0x8000;
+    v[6] = a1 - b3 + 0x8000;
+    v[7] = a0 - b0 + 0x8000;
+}
+
+__device__ __forceinline__ uint32_t magic_quot(uint32_t n, uint32_t mul, uint32_t shift)
+{
+    return mul ? __umulhi(n, mul) >> shift : n;
+}
+
+/// Two finished samples from two row-pass results: (int16)(hi16 + 128) each, clamped to 0..255
+/// (reference src/idct.cu:218-220), as two bytes in the low half of the result.
+__device__ __forceinline__ uint32_t finish_pixels(int w0, int w1)
+{
+    typedef short s2 __attribute__((ext_vector_type(2)));
+    const uint32_t pair = __builtin_amdgcn_perm(static_cast<uint32_t>(w1), static_cast<uint32_t>(w0), 0x07060302u);
+    const s2 sum        = __builtin_bit_cast(s2, pair) + s2{128, 128}; // wraps like the reference's int16 store
+    uint32_t r;
+    asm("v_sat_pk_u8_i16 %0, %1" : "=v"(r) : "v"(__builtin_bit_cast(uint32_t, sum)));
+    return r & 0xFFFFu;
 }
 
 constexpr int kIdctDuPerBlock = 32; // 8 lanes per data unit, 256 lanes
@@ -818,8 +835,7 @@ template <class JS>
 __global__ __launch_bounds__(256) void idct_kernel(JS js)
 {
     __shared__ __attribute__((aligned(16))) int16_t s_blk[kIdctDuPerBlock][kIdctDuStride]; // [unit][col * 8 + row]
-    __shared__ uint8_t s_q[4 * 64];
-    __shared__ uint8_t s_nat[64];
+    __shared__ uint16_t s_zq[4 * 64]; // [quantisation table][zig-zag index]: transposed slot | q << 8
     __shared__ uint2 s_px[2][kIdctDuPerBlock][9]; // finished pixel rows, [buffer][unit][row] (+1: bank spread)
     // Geometry of the k-th data unit of an MCU, staged once: the job lives in global memory (batch
     // API), and indexing its small arrays per lane would be a chain of dependent L2 round trips.
@@ -835,6 +851,8 @@ __global__ __launch_bounds__(256) void idct_kernel(JS js)
     const int num_du     = ip.num_du;
     const int du_per_mcu = ip.du_per_mcu;
     const int mcus_x     = ip.mcus_x;
+    const uint32_t dpm_mul = ip.du_per_mcu_mul, dpm_shift = ip.du_per_mcu_shift;
+    const uint32_t mx_mul = ip.mcus_x_mul, mx_shift = ip.mcus_x_shift;
     if (du0 >= num_du) return;
     if (threadIdx.x < static_cast<unsigned>(du_per_mcu)) {
         const int k  = threadIdx.x;
@@ -856,13 +874,14 @@ __global__ __launch_bounds__(256) void idct_kernel(JS js)
     const int r  = t & 7;  // column (pass 1) or row (pass 2) handled by this lane
     const int dl = t >> 3; // data unit inside the group
 
-    s_q[t] = J.qtables[t];
-    if (t < 64) {
+    {
+        // natural index = row * 8 + col -> transposed slot col * 8 + row; unsigned q (Appendix B-3)
         constexpr uint8_t nat[64] = JG_ORDER_NATURAL;
-        s_nat[t]                  = nat[t];
+        const int n               = nat[t & 63];
+        s_zq[t] = static_cast<uint16_t>(((n & 7) * 8 + (n >> 3)) | J.qtables[(t & ~63) + n] << 8);
     }
     int16_t* blk = s_blk[dl];
-    __syncthreads(); // s_q, s_nat, s_desc are loaded
+    __syncthreads(); // s_zq, s_desc are loaded
 
     // table entries of all iterations (independent loads, one latency); a table entry that was never
     // written (corrupt stream) must not lead out of the buffer
@@ -892,13 +911,13 @@ __global__ __launch_bounds__(256) void idct_kernel(JS js)
         // at the end crosses waves (one barrier per iteration, buffers alternate).
         *reinterpret_cast<uint4*>(blk + r * 8) = make_uint4(0, 0, 0, 0);
 
-        const int k      = du % du_per_mcu; // < du_per_mcu even for lanes past the last unit
-        const uint8_t* q = s_q + s_desc[k].qoff;
+        // < du_per_mcu even for lanes past the last unit
+        const int k        = du - static_cast<int>(magic_quot(du, dpm_mul, dpm_shift)) * du_per_mcu;
+        const uint16_t* zq = s_zq + s_desc[k].qoff;
         const auto put = [&](uint32_t v) {
-            const int nat = s_nat[(v >> 16) & 63];
-            const int c   = static_cast<int16_t>(v & 0xFFFFu);
-            // natural index = row * 8 + col -> transposed slot col * 8 + row; unsigned q (Appendix B-3)
-            blk[(nat & 7) * 8 + (nat >> 3)] = static_cast<int16_t>(c * static_cast<int>(q[nat]));
+            const uint32_t e = zq[(v >> 16) & 63];
+            const int c      = static_cast<int16_t>(v & 0xFFFFu);
+            blk[e & 0xFFu]   = static_cast<int16_t>(c * static_cast<int>(e >> 8));
         };
         const uint32_t cnt = tcnt[it];
         if (r < cnt) put(e0);
@@ -910,27 +929,15 @@ __global__ __launch_bounds__(256) void idct_kernel(JS js)
         __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront"); // every column is read before rows overwrite the block
         idct8(v);
 #pragma unroll
-        for (int i = 0; i < 8; ++i) blk[i * 8 + r] = static_cast<int16_t>(v[i]); // now [row][col]
+        for (int i = 0; i < 8; ++i) blk[i * 8 + r] = static_cast<int16_t>(v[i] >> 16); // now [row][col]
         __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
         unpack8(*reinterpret_cast<const uint4*>(blk + r * 8), v); // row r
         __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront"); // row reads precede the next iteration's zeroing
         idct8(v);
 
         uint2 o;
-        {
-            uint32_t px[8];
-#pragma unroll
-            for (int i = 0; i < 8; ++i) {
-                int s = static_cast<int16_t>(v[i] + 128);
-                // hipcc (ROCm 7.2) otherwise folds shift + level shift + clamp of two pixels into
-                // v_ashr_pk_u8_i32 and ORs the other two bytes onto its result, whose upper half is
-                // not zero on gfx950: bytes 2 and 6 of every row came out with extra bits set
-                asm volatile("" : "+v"(s));
-                px[i] = static_cast<uint32_t>(min(max(s, 0), 255));
-            }
-            o.x = px[0] | px[1] << 8 | px[2] << 16 | px[3] << 24;
-            o.y = px[4] | px[5] << 8 | px[6] << 16 | px[7] << 24;
-        }
+        o.x = finish_pixels(v[0], v[1]) | finish_pixels(v[2], v[3]) << 16;
+        o.y = finish_pixels(v[4], v[5]) | finish_pixels(v[6], v[7]) << 16;
         // A lane holds row r of unit dl; storing that directly makes every wave store touch ~40 cache
         // lines (8 units x 8 rows). Re-map through LDS: lane -> (row t / 32, unit t % 32), so that
         // consecutive lanes write the neighbouring 8-byte segments of one image row.
@@ -942,9 +949,10 @@ __global__ __launch_bounds__(256) void idct_kernel(JS js)
             const int du2 = du0 + it * kIdctDuPerBlock + j;
             if (du2 < num_du) {
                 const uint2 w    = s_px[it & 1][j][r2];
-                const int mcu2   = du2 / du_per_mcu;
+                const int mcu2   = static_cast<int>(magic_quot(du2, dpm_mul, dpm_shift));
                 const UnitDesc d = s_desc[du2 - mcu2 * du_per_mcu];
-                const int my = mcu2 / mcus_x, mx = mcu2 - my * mcus_x;
+                const int my     = static_cast<int>(magic_quot(mcu2, mx_mul, mx_shift));
+                const int mx     = mcu2 - my * mcus_x;
                 const int x0 = (mx * d.h + d.dx) * 8;
                 const int y  = (my * d.v + d.dy) * 8 + r2;
                 if (y < d.size_y && x0 < d.size_x) {
