@@ -243,10 +243,13 @@ __device__ __forceinline__ void load_tables(uint8_t* s_tab, const uint8_t* __res
 }
 
 /// Carve of the dynamic LDS of the two sequence-wide Huffman kernels.
+#ifndef JG_INTRA_LDS_IMAGE
+#define JG_INTRA_LDS_IMAGE 0
+#endif
 template <int W>
 struct SeqLds {
     static constexpr uint32_t kImg   = 0;
-    static constexpr uint32_t kState = kImg + SeqImage<W>::kWords * 4;
+    static constexpr uint32_t kState = kImg + (JG_INTRA_LDS_IMAGE ? SeqImage<W>::kWords * 4 : 0);
     static constexpr uint32_t kTabs  = (kState + 6 * (T + 1) * 4 + 64 + 15) / 16 * 16; // 5 state arrays / scan scratch
     static_assert(kTabs % 16 == 0, "the table pack is read with 16-byte loads");
 };
@@ -288,21 +291,32 @@ __global__ __launch_bounds__(T) void huff_sync_intra(JS js)
     const int img_end   = min(T, sp.num_subseq - img_first); // lanes below this have a subsequence
 
     load_tables(s_tab, J.tables, sp.tab_bytes);
+#if JG_INTRA_LDS_IMAGE
     load_image<W>(s_img, reinterpret_cast<const uint32_t*>(J.destuffed), img_first, sp.num_subseq);
+#endif
     __syncthreads();
 
     const int sub     = img_first + t;
     const bool active = sub >= 0 && t < img_end;
     LaneState st{};
+#if JG_INTRA_LDS_IMAGE
     BitWindow<LdsFetch<W>> bw{};
     LdsFetch<W> fetch{s_img, 0, 0};
+#else
+    BitWindow<GlobalFetch<W>> bw{};
+    GlobalFetch<W> fetch{reinterpret_cast<const uint32_t*>(J.destuffed), 0, 0};
+#endif
     int end_bit = 0;
     int lim     = 0; // flows stay below this lane index: end of the segment or of the image
     NoSink sink;
     if (active) {
         const Segment seg = J.segments[J.seg_idx[sub]];
         const int rel     = sub - seg.subseq_offset;
+#if JG_INTRA_LDS_IMAGE
         fetch.base        = (seg.subseq_offset - img_first) * W;
+#else
+        fetch.seg_word0   = seg.subseq_offset * W;
+#endif
         fetch.seg_words   = seg.subseq_count * W;
         lim               = min(img_end, seg.subseq_offset + seg.subseq_count - img_first);
         st.p              = rel * (W * 32);
