@@ -85,7 +85,7 @@ def lib():
         import torch  # noqa: F401
     except ImportError:
         pass
-    path = _build.LIB_PATH
+    path = os.environ.get("JPEGGPU_LIB", _build.LIB_PATH)  # override: A/B runs of experimental builds
     if not os.path.exists(path):
         raise ImportError(
             "jpeggpu_amd: %s is missing -- run `python -c 'import __graft_entry__ as g; g.build()'`" % path)

@@ -152,43 +152,12 @@ __global__ __launch_bounds__(256) void destuff_kernel(JS js)
 // Huffman: bitstream access
 // ------------------------------------------------------------------------------------------------
 
-/// LDS image of the bitstream of T consecutive subsequences: word k of local subsequence t lives at
-/// k * (T + PAD) + t, PAD = 32 / W (W = words per subsequence, at most 32 here) so that both the
-/// coalesced fill (consecutive k) and the decode-time reads (consecutive t) are bank-conflict-free.
-template <int W>
-struct SeqImage {
-    static constexpr int kPad    = W >= 32 ? 1 : 32 / W;
-    static constexpr int kStride = T + kPad;
-    static constexpr int kWords  = W * kStride;
-};
-
-/// Words just outside the image live in its pad column, so one address formula serves every read:
-/// the word before it (local index -1; the write pass of a sequence's first subsequence starts up to
-/// 31 bits before its own first bit, reference decode_huffman_reader.hpp:279-292 carries those bits
-/// in `cache`) lands on (k = W-1, t = -1), and the three words after it (a symbol may be peeked across
-/// the end and the window prefetches one word ahead) on (k = 0..2, t = T).
-template <int W>
-struct LdsFetch {
-    static constexpr int kLog2W = W == 8 ? 3 : W == 16 ? 4 : 5;
-    static_assert((1 << kLog2W) == W, "subsequence words must be 8, 16 or 32");
-    const uint32_t* img;
-    int base;      // word offset of the segment's first word relative to the image's first word
-    int seg_words; // words in the segment (zero beyond, reference decode_huffman_reader.hpp:110-152)
-    __device__ __forceinline__ uint32_t raw(int w) const
-    {
-        // No clamp and no zero-beyond-the-segment select: a lane never commits a symbol that uses a
-        // bit past `end_bit` <= the segment's end, and whether a symbol does is decided by the bits
-        // before it (prefix code), so what lies behind the end cannot change any result here. The
-        // window reads at most word (end_bit / 32) + 3 <= T * W + 3, which the pad column holds.
-        const int local = base + w;
-        return img[(local & (W - 1)) * SeqImage<W>::kStride + (local >> kLog2W)];
-    }
-    __device__ __forceinline__ uint32_t cook(uint32_t v, int) const { return v; } // swapped at fill time
-};
-
-/// Words straight from the destuffed buffer. raw() only issues the load (address clamped into the
-/// segment); the byte swap and the zero-beyond-the-end select happen in cook(), when the word is
-/// shifted into the window one refill later -- a select right behind the load would wait for it.
+/// Words of the tiled destuffed buffer (jg_defs.h). raw() only issues the load (address clamped into
+/// the segment); the byte swap and the zero-beyond-the-end select (reference
+/// decode_huffman_reader.hpp:110-152) happen in cook(), when the word is shifted into the window one
+/// refill later -- a select right behind the load would wait for it. The lanes of a wave walk
+/// neighbouring subsequences at about the same pace, so their refills share 128-byte lines and hit L1;
+/// nothing is staged in LDS, which keeps eight workgroups of the sync kernel on a CU.
 template <int W>
 struct GlobalFetch {
     static constexpr int kLog2W = W == 8 ? 3 : W == 16 ? 4 : 5;
@@ -205,35 +174,6 @@ struct GlobalFetch {
     }
 };
 
-/// Stage subsequences [img_first, img_first + T) (clipped to [0, num_subseq)) into LDS. The tiled global
-/// layout is word-major like the image, so 32 consecutive lanes copy 128 contiguous bytes.
-template <int W>
-__device__ __forceinline__ void load_image(
-    uint32_t* img, const uint32_t* __restrict__ scan32, int img_first, int num_subseq)
-{
-    constexpr int kLog2W = LdsFetch<W>::kLog2W;
-    const int lo = max(0, -img_first);             // first local subsequence that exists
-    const int hi = min(T, num_subseq - img_first); // one past the last
-    for (int i = threadIdx.x; i < T * W; i += T) {
-        const int k = i / T, t = i % T;            // T lanes share k: conflict-free LDS stores
-        if (t >= lo && t < hi)
-            img[k * SeqImage<W>::kStride + t] =
-                __builtin_bswap32(scan32[tiled_word(static_cast<uint32_t>((img_first + t) * W + k), kLog2W)]);
-    }
-    if (threadIdx.x < 3) {
-        // words T*W + 0..2 -> (k = 0..2, t = T)
-        const bool more = img_first + T < num_subseq;
-        img[threadIdx.x * SeqImage<W>::kStride + T] =
-            more ? __builtin_bswap32(scan32[tiled_word(static_cast<uint32_t>((img_first + T) * W + threadIdx.x), kLog2W)]) : 0u;
-    }
-    if (threadIdx.x == 3) img[3 * SeqImage<W>::kStride + T] = 0u; // the zero word
-    if (threadIdx.x == 4) {
-        // word -1 -> (k = W-1, t = -1)
-        img[(W - 1) * SeqImage<W>::kStride - 1] =
-            img_first > 0 ? __builtin_bswap32(scan32[tiled_word(static_cast<uint32_t>(img_first * W - 1), kLog2W)]) : 0u;
-    }
-}
-
 /// Copy the scan's Huffman table pack (a multiple of 16 bytes) into LDS.
 __device__ __forceinline__ void load_tables(uint8_t* s_tab, const uint8_t* __restrict__ g_tab, uint32_t bytes)
 {
@@ -243,13 +183,8 @@ __device__ __forceinline__ void load_tables(uint8_t* s_tab, const uint8_t* __res
 }
 
 /// Carve of the dynamic LDS of the two sequence-wide Huffman kernels.
-#ifndef JG_INTRA_LDS_IMAGE
-#define JG_INTRA_LDS_IMAGE 0
-#endif
-template <int W>
 struct SeqLds {
-    static constexpr uint32_t kImg   = 0;
-    static constexpr uint32_t kState = kImg + (JG_INTRA_LDS_IMAGE ? SeqImage<W>::kWords * 4 : 0);
+    static constexpr uint32_t kState = 0;
     static constexpr uint32_t kTabs  = (kState + 6 * (T + 1) * 4 + 64 + 15) / 16 * 16; // 5 state arrays / scan scratch
     static_assert(kTabs % 16 == 0, "the table pack is read with 16-byte loads");
 };
@@ -272,14 +207,13 @@ template <int W, class JS>
 __global__ __launch_bounds__(T) void huff_sync_intra(JS js)
 {
     extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
-    uint32_t* s_img  = reinterpret_cast<uint32_t*>(smem + SeqLds<W>::kImg);
-    int* s_p         = reinterpret_cast<int*>(smem + SeqLds<W>::kState);
+    int* s_p         = reinterpret_cast<int*>(smem + SeqLds::kState);
     int* s_n         = s_p + T;
     int* s_cz        = s_n + T;
     uint32_t* s_dc01 = reinterpret_cast<uint32_t*>(s_cz + T);
     uint32_t* s_dc23 = s_dc01 + T;
     int* s_pend      = reinterpret_cast<int*>(s_dc23 + T);
-    uint8_t* s_tab   = smem + SeqLds<W>::kTabs;
+    uint8_t* s_tab   = smem + SeqLds::kTabs;
 
     const ScanJob& J = js.get();
     if (static_cast<int>(blockIdx.x) >= J.num_seq) return;
@@ -291,32 +225,20 @@ __global__ __launch_bounds__(T) void huff_sync_intra(JS js)
     const int img_end   = min(T, sp.num_subseq - img_first); // lanes below this have a subsequence
 
     load_tables(s_tab, J.tables, sp.tab_bytes);
-#if JG_INTRA_LDS_IMAGE
-    load_image<W>(s_img, reinterpret_cast<const uint32_t*>(J.destuffed), img_first, sp.num_subseq);
-#endif
     __syncthreads();
 
     const int sub     = img_first + t;
     const bool active = sub >= 0 && t < img_end;
     LaneState st{};
-#if JG_INTRA_LDS_IMAGE
-    BitWindow<LdsFetch<W>> bw{};
-    LdsFetch<W> fetch{s_img, 0, 0};
-#else
     BitWindow<GlobalFetch<W>> bw{};
     GlobalFetch<W> fetch{reinterpret_cast<const uint32_t*>(J.destuffed), 0, 0};
-#endif
     int end_bit = 0;
     int lim     = 0; // flows stay below this lane index: end of the segment or of the image
     NoSink sink;
     if (active) {
         const Segment seg = J.segments[J.seg_idx[sub]];
         const int rel     = sub - seg.subseq_offset;
-#if JG_INTRA_LDS_IMAGE
-        fetch.base        = (seg.subseq_offset - img_first) * W;
-#else
         fetch.seg_word0   = seg.subseq_offset * W;
-#endif
         fetch.seg_words   = seg.subseq_count * W;
         lim               = min(img_end, seg.subseq_offset + seg.subseq_count - img_first);
         st.p              = rel * (W * 32);
@@ -549,7 +471,11 @@ __global__ __launch_bounds__(T) void huff_seq_tails(JS js)
 // Huffman: write pass
 // ------------------------------------------------------------------------------------------------
 
-constexpr int kStageEntries = 16; // entries of a lane's write-combining ring (a power of two)
+#ifndef JG_RING_ENTRIES
+#define JG_RING_ENTRIES 16
+#endif
+constexpr int kStageEntries = JG_RING_ENTRIES;   // entries of a lane's write-combining ring (a power of two)
+constexpr int kFlushEntries = kStageEntries / 2; // entries per flush: 8 = one 32-byte sector
 
 /// Sink of the write pass: a compact symbol stream instead of a dense coefficient buffer. Every lane
 /// appends one 32-bit entry per non-zero coefficient (zig-zag position | value, DC already absolute)
@@ -594,21 +520,21 @@ struct StreamSink {
         emitted += emit ? 1u : 0u;
         if (unit_end && started) du_tab[du_index] = uint2_t{du_off, emitted - du_off};
     }
-    /// One whole 32-byte sector (8 entries) from the ring to memory; `flushed` is a multiple of 8.
+    /// kFlushEntries entries from the ring to memory; `flushed` is a multiple of kFlushEntries.
     __device__ __forceinline__ void flush_sector()
     {
-        uint32_t e[8];
-        const uint32_t* r = ring + (flushed & (kStageEntries - 1)) * T; // flushed % 8 == 0: no wrap inside
+        uint32_t e[kFlushEntries];
+        const uint32_t* r = ring + (flushed & (kStageEntries - 1)) * T; // no wrap inside a flush unit
 #pragma unroll
-        for (int k = 0; k < 8; ++k) e[k] = r[k * T];
+        for (int k = 0; k < kFlushEntries; ++k) e[k] = r[k * T];
         uint4* dst = reinterpret_cast<uint4*>(sym + flushed);
-        dst[0]     = make_uint4(e[0], e[1], e[2], e[3]);
-        dst[1]     = make_uint4(e[4], e[5], e[6], e[7]);
-        flushed += 8;
+#pragma unroll
+        for (int k = 0; k < kFlushEntries / 4; ++k) dst[k] = make_uint4(e[4 * k], e[4 * k + 1], e[4 * k + 2], e[4 * k + 3]);
+        flushed += kFlushEntries;
     }
     __device__ __forceinline__ void tick()
     {
-        if ((++ticks & 7) == 0 && emitted - flushed >= 8) flush_sector();
+        if ((++ticks & (kFlushEntries - 1)) == 0 && emitted - flushed >= kFlushEntries) flush_sector();
     }
     /// After the loop: everything that is left, rounded up to whole sectors (the entries behind the
     /// last valid one are never read: the data-unit table bounds every gather).
@@ -1023,7 +949,7 @@ hipError_t allow_lds(K kernel, size_t bytes)
 template <int W, class JS>
 hipError_t launch_huff(Stage stage, const JS& js, const JobExtent& e, int grid_y, hipStream_t stream)
 {
-    const size_t seq_lds = SeqLds<W>::kTabs + e.max_tab_bytes;
+    const size_t seq_lds = SeqLds::kTabs + e.max_tab_bytes;
     hipError_t err       = hipSuccess;
     switch (stage) {
     case kStageSyncIntra:
