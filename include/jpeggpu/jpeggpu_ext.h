@@ -11,6 +11,7 @@
  *                                      benchmark/benchmark_jpeggpu.hpp:96-102)
  *   jpeggpu_ext_decode_batch           one launch per stage for many images; the
  *                                      reference decodes one image per call sequence
+ *   jpeggpu_ext_planes_to_rgbi         chroma replication + YCbCr -> interleaved RGB8 (util/util.h:62-104)
  *   jpeggpu_ext_upsample_planes        nearest-neighbour chroma replication on the device, the integer
  *                                      part of the reference's host helper util/util.h:62-91
  */
@@ -121,6 +122,19 @@ enum jpeggpu_status jpeggpu_ext_upsample_planes(
     const struct jpeggpu_img_info* info,
     const struct jpeggpu_img* src,
     struct jpeggpu_img* dst,
+    int width,
+    int height,
+    jpeggpu_stream_t stream);
+
+/* Planes of a 1- or 3-component image -> interleaved RGB8 at the full image resolution: nearest-neighbour
+ * chroma replication + the JFIF YCbCr matrix in float, rounded and clamped -- the arithmetic of the
+ * reference's host helper conv_to_rgbi (util/util.h:62-104). dst[y * dst_pitch + 3 * x + {0,1,2}] = R,G,B.
+ * JPEGGPU_NOT_SUPPORTED for 2 or 4 components, as the helper. */
+enum jpeggpu_status jpeggpu_ext_planes_to_rgbi(
+    const struct jpeggpu_img_info* info,
+    const struct jpeggpu_img* src,
+    uint8_t* dst,
+    int dst_pitch,
     int width,
     int height,
     jpeggpu_stream_t stream);

@@ -115,6 +115,8 @@ def lib():
     L.jpeggpu_ext_batch_get_stage_ms.argtypes = [C.c_void_p, C.POINTER(C.c_float)]
     L.jpeggpu_ext_upsample_planes.argtypes = [
         C.POINTER(ImgInfo), C.POINTER(Img), C.POINTER(Img), C.c_int, C.c_int, C.c_void_p]
+    L.jpeggpu_ext_planes_to_rgbi.argtypes = [
+        C.POINTER(ImgInfo), C.POINTER(Img), C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_void_p]
     _lib = L
     return L
 

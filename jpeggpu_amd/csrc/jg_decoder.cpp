@@ -728,4 +728,29 @@ enum jpeggpu_status jpeggpu_ext_upsample_planes(
     return JPEGGPU_SUCCESS;
 }
 
+enum jpeggpu_status jpeggpu_ext_planes_to_rgbi(
+    const struct jpeggpu_img_info* info,
+    const struct jpeggpu_img* src,
+    uint8_t* dst,
+    int dst_pitch,
+    int width,
+    int height,
+    jpeggpu_stream_t stream)
+{
+    if (!info || !src || !dst || width <= 0 || height <= 0 || dst_pitch < 3 * width) return JPEGGPU_INVALID_ARGUMENT;
+    const int nc = info->num_components;
+    if (nc != 1 && nc != 3) return JPEGGPU_NOT_SUPPORTED; // as the reference's helper (util/util.h:42-45)
+    int sx_max = 0, sy_max = 0;
+    for (int c = 0; c < nc; ++c) {
+        if (info->subsampling.x[c] < 1 || info->subsampling.y[c] < 1) return JPEGGPU_INVALID_ARGUMENT;
+        if (!src->image[c] || src->pitch[c] < info->sizes_x[c]) return JPEGGPU_INVALID_ARGUMENT;
+        sx_max = info->subsampling.x[c] > sx_max ? info->subsampling.x[c] : sx_max;
+        sy_max = info->subsampling.y[c] > sy_max ? info->subsampling.y[c] : sy_max;
+    }
+    const hipError_t err = jg::launch_rgbi(
+        src->image, src->pitch, info->sizes_x, info->sizes_y, info->subsampling.x, info->subsampling.y,
+        sx_max, sy_max, nc, dst, dst_pitch, width, height, stream);
+    return err == hipSuccess ? JPEGGPU_SUCCESS : JPEGGPU_INTERNAL_ERROR;
+}
+
 } // extern "C"

@@ -933,6 +933,55 @@ __global__ __launch_bounds__(256) void upsample_kernel(
     }
 }
 
+/// Chroma replication + YCbCr -> RGB, interleaved 8-bit output; the arithmetic of the reference's host
+/// helper `conv_to_rgbi` (util/util.h:62-104): nearest-neighbour replication, the JFIF matrix in float,
+/// roundf, clamp. Each lane produces 4 consecutive pixels (12 bytes) of one row, so a wave writes 768
+/// contiguous bytes. With one component the sample is copied to R, G and B (util.h:47-58).
+struct RgbiParams {
+    const uint8_t* plane[3];
+    int pitch[3], w[3], h[3];
+    int num_x[3], num_y[3]; // sampling factors; the maxima are the denominators
+    int den_x, den_y;
+    int ncomp;
+};
+
+__global__ __launch_bounds__(256) void rgbi_kernel(RgbiParams p, uint8_t* __restrict__ dst, int dst_pitch, int width, int height)
+{
+    const int x0 = (blockIdx.x * blockDim.x + threadIdx.x) * 4;
+    const int y  = blockIdx.y;
+    if (x0 >= width || y >= height) return;
+    uint32_t out[12];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const int x = min(x0 + i, width - 1);
+        float v[3];
+#pragma unroll
+        for (int c = 0; c < 3; ++c) {
+            const int cc = c < p.ncomp ? c : 0;
+            const int sy = min(y * p.num_y[cc] / p.den_y, p.h[cc] - 1);
+            const int sx = min(x * p.num_x[cc] / p.den_x, p.w[cc] - 1);
+            v[c]         = static_cast<float>(p.plane[cc][static_cast<size_t>(sy) * p.pitch[cc] + sx]);
+        }
+        float r = v[0], g = v[0], b = v[0];
+        if (p.ncomp == 3) {
+            r = v[0] + 1.402f * (v[2] - 128.f);
+            g = v[0] - .344136f * (v[1] - 128.f) - .714136f * (v[2] - 128.f);
+            b = v[0] + 1.772f * (v[1] - 128.f);
+        }
+        out[3 * i + 0] = static_cast<uint32_t>(fmaxf(0.f, fminf(roundf(r), 255.f)));
+        out[3 * i + 1] = static_cast<uint32_t>(fmaxf(0.f, fminf(roundf(g), 255.f)));
+        out[3 * i + 2] = static_cast<uint32_t>(fmaxf(0.f, fminf(roundf(b), 255.f)));
+    }
+    uint8_t* drow = dst + static_cast<size_t>(y) * dst_pitch + static_cast<size_t>(x0) * 3;
+    if (x0 + 4 <= width && (reinterpret_cast<uintptr_t>(drow) & 3) == 0) {
+        uint32_t* d = reinterpret_cast<uint32_t*>(drow);
+#pragma unroll
+        for (int k = 0; k < 3; ++k) d[k] = out[4 * k] | out[4 * k + 1] << 8 | out[4 * k + 2] << 16 | out[4 * k + 3] << 24;
+    } else {
+        for (int i = 0; i < 12 && x0 + i / 3 < width; ++i) drow[i] = static_cast<uint8_t>(out[i]);
+    }
+}
+
 // ------------------------------------------------------------------------------------------------
 // launches
 // ------------------------------------------------------------------------------------------------
@@ -1038,6 +1087,29 @@ hipError_t launch_upsample(
     const dim3 grid((dst_w + 1023) / 1024, dst_h);
     upsample_kernel<<<grid, 256, 0, stream>>>(
         src, src_pitch, src_w, src_h, dst, dst_pitch, dst_w, dst_h, num_x, den_x, num_y, den_y);
+    return hipGetLastError();
+}
+
+hipError_t launch_rgbi(
+    const uint8_t* const* planes, const int* pitch, const int* w, const int* h, const int* num_x, const int* num_y,
+    int den_x, int den_y, int ncomp, uint8_t* dst, int dst_pitch, int width, int height, hipStream_t stream)
+{
+    if (width <= 0 || height <= 0) return hipSuccess;
+    RgbiParams p{};
+    for (int c = 0; c < 3; ++c) {
+        const int cc = c < ncomp ? c : 0;
+        p.plane[c] = planes[cc];
+        p.pitch[c] = pitch[cc];
+        p.w[c]     = w[cc];
+        p.h[c]     = h[cc];
+        p.num_x[c] = num_x[cc];
+        p.num_y[c] = num_y[cc];
+    }
+    p.den_x = den_x;
+    p.den_y = den_y;
+    p.ncomp = ncomp;
+    const dim3 grid((width + 1023) / 1024, height);
+    rgbi_kernel<<<grid, 256, 0, stream>>>(p, dst, dst_pitch, width, height);
     return hipGetLastError();
 }
 

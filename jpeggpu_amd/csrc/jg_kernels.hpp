@@ -48,6 +48,12 @@ hipError_t launch_upsample(
     uint8_t* dst, int dst_pitch, int dst_w, int dst_h,
     int num_x, int den_x, int num_y, int den_y, hipStream_t stream);
 
+/// Nearest-neighbour replication + YCbCr -> interleaved RGB8 (reference host helper util/util.h:62-104);
+/// `ncomp` 1 (grey copied to R, G, B) or 3.
+hipError_t launch_rgbi(
+    const uint8_t* const* planes, const int* pitch, const int* w, const int* h, const int* num_x, const int* num_y,
+    int den_x, int den_y, int ncomp, uint8_t* dst, int dst_pitch, int width, int height, hipStream_t stream);
+
 } // namespace jg
 
 #endif // JG_KERNELS_HPP_

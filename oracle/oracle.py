@@ -148,3 +148,31 @@ def scan_stages(data: bytes, scan_idx: int, subseq_bytes: int) -> Stages:
     if rc:
         raise OracleError(rc)
     return st
+
+
+def planes_to_rgbi(planes, sub_x, sub_y, width, height):
+    """CPU restatement of the reference's host helper conv_to_rgbi (util/util.h:62-104): nearest-neighbour
+    chroma replication, r = y + 1.402 (cr - 128), g = y - .344136 (cb - 128) - .714136 (cr - 128),
+    b = y + 1.772 (cb - 128) in float32, roundf (half away from zero), clamp to 0..255. `planes`: 1 or 3
+    uint8 arrays as decoded; returns uint8 [height, width, 3]. The C expression may or may not be
+    contracted into FMAs by the compiler, so a consumer compares within +-1."""
+    import numpy as np
+
+    n = len(planes)
+    sxm, sym = max(sub_x[:n]), max(sub_y[:n])
+    up = []
+    for c in range(n):
+        p = planes[c]
+        ys = np.minimum(np.arange(height) * sub_y[c] // sym, p.shape[0] - 1)
+        xs = np.minimum(np.arange(width) * sub_x[c] // sxm, p.shape[1] - 1)
+        up.append(p[ys][:, xs].astype(np.float32))
+    if n == 1:
+        return np.repeat(up[0].astype(np.uint8)[:, :, None], 3, axis=2)
+    y, cb, cr = up
+    f = np.float32
+    r = y + f(1.402) * (cr - f(128))
+    g = y - f(.344136) * (cb - f(128)) - f(.714136) * (cr - f(128))
+    b = y + f(1.772) * (cb - f(128))
+    out = np.stack([r, g, b], axis=2)
+    out = np.sign(out) * np.floor(np.abs(out) + f(0.5))  # roundf
+    return np.clip(out, 0, 255).astype(np.uint8)

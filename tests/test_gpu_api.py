@@ -141,6 +141,49 @@ def test_upsample_planes(torch_cuda):
             assert np.array_equal(outs[c].cpu().numpy()[:, :W], p[ys][:, xs]), (name, c)
 
 
+def test_planes_to_rgbi(torch_cuda):
+    """Additive colour kernel vs the oracle's restatement of the reference's host helper conv_to_rgbi
+    (util/util.h:62-104). Float arithmetic: the C expression may be contracted into FMAs, so the tolerance
+    is 1 LSB, and almost every sample must be exact."""
+    import ctypes as C
+
+    import jpeggpu_amd
+    from jpeggpu_amd.api import Img, lib
+    from oracle import oracle
+
+    torch = torch_cuda
+    for name in ("ss_2x2", "ss_1x1", "ss_2x1", "odd_partial_mcu", "odd_17x9", "gray", "q100_noisy"):
+        data = cases.matrix()[name]
+        planes, info = jpeggpu_amd.decode_to_planes(data)
+        n = info.num_components
+        sxm, sym = max(info.subsampling.x[:n]), max(info.subsampling.y[:n])
+        W = info.sizes_x[[i for i in range(n) if info.subsampling.x[i] == sxm][0]]
+        H = info.sizes_y[[i for i in range(n) if info.subsampling.y[i] == sym][0]]
+        src = Img()
+        for c in range(n):
+            src.image[c], src.pitch[c] = planes[c].data_ptr(), planes[c].stride(0)
+        pitch = 3 * W + 5  # unaligned rows on purpose
+        out = torch.full((H, pitch), 0x5A, dtype=torch.uint8, device="cuda:0")
+        rc = lib().jpeggpu_ext_planes_to_rgbi(C.byref(info), C.byref(src), out.data_ptr(), pitch, W, H, None)
+        assert rc == 0, name
+        torch.cuda.synchronize()
+        got = out.cpu().numpy()
+        assert (got[:, 3 * W:] == 0x5A).all(), (name, "wrote past the row")
+        got = got[:, :3 * W].reshape(H, W, 3).astype(np.int32)
+        ref = oracle.planes_to_rgbi([p.cpu().numpy() for p in planes], list(info.subsampling.x), list(info.subsampling.y), W, H)
+        diff = np.abs(got - ref.astype(np.int32))
+        assert diff.max() <= 1, (name, int(diff.max()))
+        assert (diff == 0).mean() > 0.999, (name, float((diff == 0).mean()))
+    # 4 components: not supported, as the reference's helper
+    data = cases.matrix()["four_comp_444"]
+    planes, info = jpeggpu_amd.decode_to_planes(data)
+    src = Img()
+    for c in range(4):
+        src.image[c], src.pitch[c] = planes[c].data_ptr(), planes[c].stride(0)
+    out = torch.zeros((8, 64), dtype=torch.uint8, device="cuda:0")
+    assert lib().jpeggpu_ext_planes_to_rgbi(C.byref(info), C.byref(src), out.data_ptr(), 64, 8, 8, None) == int(jpeggpu_amd.Status.NOT_SUPPORTED)
+
+
 def test_batch_decode_equals_single(torch_cuda):
     """jpeggpu_ext_decode_batch (one launch per stage, grid.y = scan) against the oracle, for a batch of
     images of different geometry, scan count and table sets, decoded twice through the same handle."""
