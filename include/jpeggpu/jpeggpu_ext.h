@@ -11,6 +11,7 @@
  *                                      benchmark/benchmark_jpeggpu.hpp:96-102)
  *   jpeggpu_ext_decode_batch           one launch per stage for many images; the
  *                                      reference decodes one image per call sequence
+ *   jpeggpu_ext_parse_headers          parse_header of many images on a pool of host threads
  *   jpeggpu_ext_planes_to_rgbi         chroma replication + YCbCr -> interleaved RGB8 (util/util.h:62-104)
  *   jpeggpu_ext_upsample_planes        nearest-neighbour chroma replication on the device, the integer
  *                                      part of the reference's host helper util/util.h:62-91
@@ -62,7 +63,7 @@ struct jpeggpu_ext_layout {
     size_t transferred_bytes;  /* entropy-coded byte range copied by jpeggpu_decoder_transfer */
     size_t blob_bytes;         /* table blob copied by jpeggpu_decoder_transfer */
     size_t off_bytes;          /* stuffed bytes inside d_tmp */
-    size_t off_qtables;        /* uint8[4][64], natural order */
+    size_t off_qtables;        /* uint16[4][64], natural order */
     struct jpeggpu_ext_scan_layout scans[JPEGGPU_MAX_COMP];
 };
 
@@ -125,6 +126,20 @@ enum jpeggpu_status jpeggpu_ext_upsample_planes(
     int width,
     int height,
     jpeggpu_stream_t stream);
+
+/* jpeggpu_decoder_parse_header for many images on `num_threads` host threads (the calling thread is one
+ * of them). A 12 MP scan costs ~0.2 ms of one core to walk (reference src/reader.cpp:447-489 does the
+ * same walk inside its timed loop), so a serving loop at 14 k images/s needs about three cores of it.
+ * Every decoder must appear once. statuses[i] receives the result of item i; the return value is the
+ * first failure, or JPEGGPU_SUCCESS. */
+struct jpeggpu_ext_parse_item {
+    jpeggpu_decoder_t decoder;
+    struct jpeggpu_img_info* img_info;
+    const uint8_t* data;
+    size_t size;
+};
+enum jpeggpu_status jpeggpu_ext_parse_headers(
+    const struct jpeggpu_ext_parse_item* items, int num_items, int num_threads, enum jpeggpu_status* statuses);
 
 /* Planes of a 1- or 3-component image -> interleaved RGB8 at the full image resolution: nearest-neighbour
  * chroma replication + the JFIF YCbCr matrix in float, rounded and clamped -- the arithmetic of the

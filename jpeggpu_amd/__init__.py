@@ -12,5 +12,6 @@ from .api import (  # noqa: F401
     Status,
     decode_to_planes,
     lib,
+    parse_headers,
     status_string,
 )

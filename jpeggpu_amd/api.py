@@ -60,6 +60,10 @@ class ExtLayout(C.Structure):
     ]
 
 
+class ParseItem(C.Structure):
+    _fields_ = [("decoder", C.c_void_p), ("img_info", C.POINTER(ImgInfo)), ("data", C.c_void_p), ("size", C.c_size_t)]
+
+
 class BatchItem(C.Structure):
     _fields_ = [("decoder", C.c_void_p), ("img", C.POINTER(Img)), ("d_tmp", C.c_void_p), ("tmp_size", C.c_size_t)]
 
@@ -115,6 +119,7 @@ def lib():
     L.jpeggpu_ext_batch_get_stage_ms.argtypes = [C.c_void_p, C.POINTER(C.c_float)]
     L.jpeggpu_ext_upsample_planes.argtypes = [
         C.POINTER(ImgInfo), C.POINTER(Img), C.POINTER(Img), C.c_int, C.c_int, C.c_void_p]
+    L.jpeggpu_ext_parse_headers.argtypes = [C.POINTER(ParseItem), C.c_int, C.c_int, C.POINTER(C.c_int)]
     L.jpeggpu_ext_planes_to_rgbi.argtypes = [
         C.POINTER(ImgInfo), C.POINTER(Img), C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_void_p]
     _lib = L
@@ -281,3 +286,22 @@ def decode_to_planes(data: bytes, device="cuda:0", subseq_bytes=None, return_tmp
         return planes, info
     finally:
         dec.cleanup()
+
+
+def parse_headers(decoders, buffers, num_threads=4):
+    """jpeggpu_ext_parse_headers: parse `buffers[i]` (bytes or numpy uint8; kept alive by the decoder object)
+    into `decoders[i]` on a pool of host threads. Returns the list of ImgInfo; raises on the first failure."""
+    n = len(decoders)
+    items = (ParseItem * n)()
+    infos = [ImgInfo() for _ in range(n)]
+    for i, (d, b) in enumerate(zip(decoders, buffers)):
+        d._keep = b
+        if isinstance(b, (bytes, bytearray)):
+            ptr, size = C.cast(C.c_char_p(bytes(b)) if isinstance(b, bytearray) else C.c_char_p(b), C.c_void_p).value, len(b)
+        else:
+            ptr = b.ctypes.data if hasattr(b, "ctypes") else b.data_ptr()
+            size = b.nbytes if hasattr(b, "nbytes") else b.numel()
+        items[i].decoder, items[i].img_info, items[i].data, items[i].size = d._h.value, C.pointer(infos[i]), ptr, size
+    st = (C.c_int * n)()
+    _check(lib().jpeggpu_ext_parse_headers(items, n, num_threads, st), "jpeggpu_ext_parse_headers")
+    return infos

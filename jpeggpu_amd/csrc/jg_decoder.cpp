@@ -17,7 +17,9 @@
 #include <hip/hip_runtime.h>
 
 #include <cstdlib>
+#include <atomic>
 #include <cstring>
+#include <thread>
 #include <new>
 #include <vector>
 
@@ -321,7 +323,7 @@ jpeggpu_status build_jobs(
         job.chunks     = reinterpret_cast<const DestuffChunk*>(blob + pl.blob_chunks);
         job.segments   = reinterpret_cast<const Segment*>(blob + pl.blob_segments);
         job.tables     = blob + pl.blob_tables;
-        job.qtables    = blob + plan.blob_qtables;
+        job.qtables    = reinterpret_cast<const uint16_t*>(blob + plan.blob_qtables);
         job.destuffed  = base + pl.destuffed;
         job.seg_idx    = reinterpret_cast<int*>(base + pl.seg_idx);
         job.st_p       = reinterpret_cast<int*>(base + pl.st_p);
@@ -751,6 +753,37 @@ enum jpeggpu_status jpeggpu_ext_planes_to_rgbi(
         src->image, src->pitch, info->sizes_x, info->sizes_y, info->subsampling.x, info->subsampling.y,
         sx_max, sy_max, nc, dst, dst_pitch, width, height, stream);
     return err == hipSuccess ? JPEGGPU_SUCCESS : JPEGGPU_INTERNAL_ERROR;
+}
+
+enum jpeggpu_status jpeggpu_ext_parse_headers(
+    const struct jpeggpu_ext_parse_item* items, int num_items, int num_threads, enum jpeggpu_status* statuses)
+{
+    if (!items || num_items < 0 || !statuses) return JPEGGPU_INVALID_ARGUMENT;
+    for (int i = 0; i < num_items; ++i) {
+        statuses[i] = JPEGGPU_INVALID_ARGUMENT;
+        for (int j = 0; j < i; ++j) // one decoder must not be used concurrently
+            if (items[i].decoder && items[i].decoder == items[j].decoder) return JPEGGPU_INVALID_ARGUMENT;
+    }
+    if (num_threads < 1) num_threads = 1;
+    if (num_threads > num_items) num_threads = num_items;
+    std::atomic<int> next{0};
+    const auto work = [&]() {
+        for (int i = next.fetch_add(1); i < num_items; i = next.fetch_add(1)) {
+            const jpeggpu_ext_parse_item& it = items[i];
+            statuses[i] = jpeggpu_decoder_parse_header(it.decoder, it.img_info, it.data, it.size);
+        }
+    };
+    std::vector<std::thread> pool;
+    try {
+        for (int t = 1; t < num_threads; ++t) pool.emplace_back(work);
+    } catch (...) {
+        // fewer threads than asked for: the calling thread picks up the rest
+    }
+    work();
+    for (std::thread& t : pool) t.join();
+    for (int i = 0; i < num_items; ++i)
+        if (statuses[i] != JPEGGPU_SUCCESS) return statuses[i];
+    return JPEGGPU_SUCCESS;
 }
 
 } // extern "C"

@@ -190,7 +190,7 @@ struct ScanJob {
     const DestuffChunk* chunks;
     const Segment* segments;
     const uint8_t* tables;       // Huffman table pack of the scan
-    const uint8_t* qtables;      // uint8[4][64], natural order
+    const uint16_t* qtables;     // uint16[4][64], natural order
     uint8_t* destuffed;
     int* seg_idx;                // subsequence -> segment
     int* st_p;                   // sync state, structure of arrays (reference `subsequence_info`,

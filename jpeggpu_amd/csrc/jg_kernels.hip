@@ -775,7 +775,7 @@ template <class JS>
 __global__ __launch_bounds__(256) void idct_kernel(JS js)
 {
     __shared__ __attribute__((aligned(16))) int16_t s_blk[kIdctDuPerBlock][kIdctDuStride]; // [unit][col * 8 + row]
-    __shared__ uint16_t s_zq[4 * 64]; // [quantisation table][zig-zag index]: transposed slot | q << 8
+    __shared__ uint32_t s_zq[4 * 64]; // [quantisation table][zig-zag index]: transposed slot | q << 8 (q up to 16 bits)
     __shared__ uint2 s_px[2][kIdctDuPerBlock][9]; // finished pixel rows, [buffer][unit][row] (+1: bank spread)
     // Geometry of the k-th data unit of an MCU, staged once: the job lives in global memory (batch
     // API), and indexing its small arrays per lane would be a chain of dependent L2 round trips.
@@ -818,7 +818,7 @@ __global__ __launch_bounds__(256) void idct_kernel(JS js)
         // natural index = row * 8 + col -> transposed slot col * 8 + row; unsigned q (Appendix B-3)
         constexpr uint8_t nat[64] = JG_ORDER_NATURAL;
         const int n               = nat[t & 63];
-        s_zq[t] = static_cast<uint16_t>(((n & 7) * 8 + (n >> 3)) | J.qtables[(t & ~63) + n] << 8);
+        s_zq[t] = static_cast<uint32_t>((n & 7) * 8 + (n >> 3)) | static_cast<uint32_t>(J.qtables[(t & ~63) + n]) << 8;
     }
     int16_t* blk = s_blk[dl];
     __syncthreads(); // s_zq, s_desc are loaded
@@ -853,7 +853,7 @@ __global__ __launch_bounds__(256) void idct_kernel(JS js)
 
         // < du_per_mcu even for lanes past the last unit
         const int k        = du - static_cast<int>(magic_quot(du, dpm_mul, dpm_shift)) * du_per_mcu;
-        const uint16_t* zq = s_zq + s_desc[k].qoff;
+        const uint32_t* zq = s_zq + s_desc[k].qoff;
         const auto put = [&](uint32_t v) {
             const uint32_t e = zq[(v >> 16) & 63];
             const int c      = static_cast<int16_t>(v & 0xFFFFu);

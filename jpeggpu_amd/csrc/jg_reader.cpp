@@ -281,21 +281,20 @@ jpeggpu_status Reader::read_dqt(const Logger& log)
             log.log("\tinvalid precision or id value\n");
             return JPEGGPU_INVALID_JPEG;
         }
-        if (precision != 0) {
-            log.log("\t16-bit quantization table is not supported\n");
-            return JPEGGPU_NOT_SUPPORTED;
-        }
-        if (rem < 64) return JPEGGPU_INVALID_JPEG;
+        // 16-bit entries (Pq = 1): the reference returns NOT_SUPPORTED (src/reader.cpp:517-520); libjpeg
+        // writes such tables at low quality without -baseline, so they are read
+        const int bytes = precision ? 128 : 64;
+        if (rem < bytes) return JPEGGPU_INVALID_JPEG;
         // A table that a component of an earlier scan dequantises with must not be replaced: all
         // scans are dequantised together at the end (reference src/reader.cpp:524-541 intends this).
         bool in_use = false;
         for (int c = 0; c < s.num_comp; ++c) in_use |= comp_in_scan_[c] && s.comp[c].qidx == id;
         for (int j = 0; j < 64; ++j) {
-            const uint8_t q = u8();
+            const uint16_t q = precision ? u16() : u8();
             if (!in_use) s.qtable[id][kNatural[j]] = q;
         }
         qt_defined_[id] = true;
-        rem -= 64;
+        rem -= bytes;
     }
     return JPEGGPU_SUCCESS;
 }

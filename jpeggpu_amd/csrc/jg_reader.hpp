@@ -76,7 +76,7 @@ struct Stream {
     int restart_interval = 0;
     int num_scans = 0;
     Scan scans[kMaxScans];
-    uint8_t qtable[4][64]; // natural order, 8-bit (reference src/defs.hpp:87-89)
+    uint16_t qtable[4][64]; // natural order (reference src/defs.hpp:87-89 keeps 8 bits; 16-bit entries are read too)
     // Transferred byte range of the file: [xfer_begin, xfer_end). Buffer offset = file offset - xfer_begin.
     size_t xfer_begin = 0;
     size_t xfer_end   = 0;

@@ -94,7 +94,7 @@ typedef struct {
 typedef struct {
     int width, height, ncomp, hmax, vmax, restart_interval, nscans;
     int id[4], hs[4], vs[4], qidx[4], size_x[4], size_y[4];
-    uint8_t qtab[4][64];
+    uint16_t qtab[4][64];
     int qdef[4];
     jo_scan scan[4];
 } jo_stream;
@@ -203,15 +203,16 @@ static int parse_stream(const uint8_t* data, size_t size, jo_stream* s)
                 int info = rd_u8(&r), prec = info >> 4, id = info & 15, in_use = 0;
                 --rem;
                 if (prec > 1 || id > 3) return JO_INVALID_JPEG;
-                if (prec) return JO_NOT_SUPPORTED;
-                if (rem < 64) return JO_INVALID_JPEG;
+                /* 16-bit entries (Pq = 1): the reference stops here (reader.cpp:517-520); libjpeg writes
+                   them at low quality, so they are read */
+                if (rem < (prec ? 128 : 64)) return JO_INVALID_JPEG;
                 for (int c = 0; c < s->ncomp; ++c) in_use |= in_scan[c] && s->qidx[c] == id;
                 for (int j = 0; j < 64; ++j) {
-                    int q = rd_u8(&r);
-                    if (!in_use) s->qtab[id][kNatural[j]] = (uint8_t)q;
+                    int q = prec ? rd_u16(&r) : rd_u8(&r);
+                    if (!in_use) s->qtab[id][kNatural[j]] = (uint16_t)q;
                 }
                 s->qdef[id] = 1;
-                rem -= 64;
+                rem -= prec ? 128 : 64;
             }
         } else if (m == 0xDD) { /* DRI :551-574 */
             int rsti;
@@ -536,11 +537,11 @@ static void idct_vector(int* v0, int* v1, int* v2, int* v3, int* v4, int* v5, in
     *v7 = unfixh(tmp20 - tmp50);
 }
 
-void jo_idct_block(const int16_t coef[64], const uint8_t q[64], uint8_t out[64], int flags)
+void jo_idct_block(const int16_t coef[64], const uint16_t q[64], uint8_t out[64], int flags)
 {
     int16_t blk[64];
     for (int i = 0; i < 64; ++i) { /* idct.cu:176-180: int16 = int16 * (int8 | uint8) */
-        int qv = (flags & JO_QUIRK_SIGNED_Q) ? (int)(int8_t)q[i] : (int)q[i];
+        int qv = (flags & JO_QUIRK_SIGNED_Q) ? (int)(int8_t)(uint8_t)q[i] : (int)q[i];
         blk[i] = (int16_t)(coef[i] * qv);
     }
     for (int x = 0; x < 8; ++x) { /* column pass, idct.cu:97-120 */

@@ -30,7 +30,7 @@ typedef struct {
     int blocks_w[4], blocks_h[4]; /* coefficient array size in blocks (rounded to the scan's MCU) */
     int16_t* coef[4];             /* [blocks_h][blocks_w][64], natural order, quantised, DC absolute */
     uint8_t* plane[4];            /* [plane_h][plane_w] */
-    uint8_t qtab[4][64];          /* natural order */
+    uint16_t qtab[4][64];         /* natural order; 8- or 16-bit entries in the file */
     /* per scan: coefficients in stream order (data unit after data unit as coded) */
     int16_t* stream_coef[4];
     int stream_du[4];
@@ -43,7 +43,7 @@ int jo_decode(const uint8_t* data, size_t size, jo_image* img, int flags);
 void jo_free(jo_image* img);
 
 /* dequant + IDCT + level shift + clamp of one data unit (natural order in, raster out) */
-void jo_idct_block(const int16_t coef[64], const uint8_t q[64], uint8_t out[64], int flags);
+void jo_idct_block(const int16_t coef[64], const uint16_t q[64], uint8_t out[64], int flags);
 
 typedef struct {
     int num_subseq, num_segments, num_du;

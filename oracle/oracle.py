@@ -23,7 +23,7 @@ class _JoImage(C.Structure):
         ("blocks_w", C.c_int * 4), ("blocks_h", C.c_int * 4),
         ("coef", C.POINTER(C.c_int16) * 4),
         ("plane", C.POINTER(C.c_uint8) * 4),
-        ("qtab", (C.c_uint8 * 64) * 4),
+        ("qtab", (C.c_uint16 * 64) * 4),
         ("stream_coef", C.POINTER(C.c_int16) * 4),
         ("stream_du", C.c_int * 4),
         ("scan_ncomp", C.c_int * 4),
@@ -104,7 +104,7 @@ def decode(data: bytes, flags: int = 0) -> Decoded:
 
 def idct_block(coef, q, flags: int = 0):
     coef = np.ascontiguousarray(coef, dtype=np.int16).reshape(64)
-    q = np.ascontiguousarray(q, dtype=np.uint8).reshape(64)
+    q = np.ascontiguousarray(q, dtype=np.uint16).reshape(64)
     out = np.zeros(64, dtype=np.uint8)
     lib().jo_idct_block(coef.ctypes.data, q.ctypes.data, out.ctypes.data, flags)
     return out.reshape(8, 8)

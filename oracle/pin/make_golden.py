@@ -113,6 +113,7 @@ def main():
         "syn_4comp_opt": e(264, 200, ((2, 1), (1, 1), (1, 1), (2, 1)), optimize=True, seed=105),
         "syn_4x1": e(200, 152, ((4, 1), (1, 1), (1, 1)), seed=106),
         "syn_q100": e(160, 128, S420, quality=100, noise=40, seed=107),
+        "syn_q16_tables": e(200, 152, S420, restart_interval=5, quality=3, noise=30, seed=108, qmax=65535),  # Pq = 1
     }
     cases.update(pil_cases())
     store, report = {}, {}

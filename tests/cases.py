@@ -40,6 +40,7 @@ def matrix():
         # entropy extremes
         "q100_noisy": e(160, 128, S420, quality=100, noise=40, seed=23),   # long codes, long blocks
         "q5_flat": e(640, 480, S420, quality=5, noise=0, seed=24),         # almost all EOB
+        "q16_tables": e(328, 248, S420, restart_interval=7, quality=3, noise=30, seed=31, qmax=65535),  # 16-bit DQT (Pq = 1)
         # more than one sequence without restart markers (inter-sequence flows), ~150 KB of scan
         "multi_seq_nodri": e(1024, 768, S420, quality=92, noise=12, seed=25),
         "multi_seq_dri": e(1024, 768, S420, quality=92, noise=12, restart_interval=64, seed=26),

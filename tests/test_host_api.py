@@ -174,6 +174,50 @@ def test_decoder_reuse_and_subsequence_knob(L):
     dec.cleanup()
 
 
+def test_parallel_parse_equals_serial(L):
+    """jpeggpu_ext_parse_headers on a thread pool: same geometry, sizes and layouts as one-by-one parsing,
+    per-item statuses for bad inputs, duplicate decoders rejected."""
+    import ctypes as C
+
+    import jpeggpu_amd
+    from jpeggpu_amd.api import ParseItem
+
+    m = cases.matrix()
+    names = list(m.keys())
+    bufs = [m[k] for k in names] * 2
+    serial = []
+    for b in bufs:
+        d = jpeggpu_amd.Decoder()
+        info = d.parse_header(b)
+        serial.append((info.num_components, list(info.sizes_x), list(info.sizes_y), d.get_buffer_size(),
+                       d.layout().scans[0].num_subsequences, d.layout().scans[0].num_segments))
+        d.cleanup()
+    for threads in (1, 3, 8):
+        decs = [jpeggpu_amd.Decoder() for _ in bufs]
+        infos = jpeggpu_amd.parse_headers(decs, bufs, num_threads=threads)
+        got = [(i.num_components, list(i.sizes_x), list(i.sizes_y), d.get_buffer_size(),
+                d.layout().scans[0].num_subsequences, d.layout().scans[0].num_segments) for i, d in zip(infos, decs)]
+        assert got == serial, threads
+        for d in decs:
+            d.cleanup()
+    # one truncated file among good ones: its own status, the others still parsed
+    decs = [jpeggpu_amd.Decoder() for _ in range(3)]
+    datas = [m["ss_2x2"], m["ss_2x2"][:200], m["gray"]]
+    items = (ParseItem * 3)()
+    infos = [jpeggpu_amd.ImgInfo() for _ in range(3)]
+    for i in range(3):
+        items[i].decoder, items[i].img_info = decs[i]._h.value, C.pointer(infos[i])
+        items[i].data, items[i].size = C.cast(C.c_char_p(datas[i]), C.c_void_p).value, len(datas[i])
+    st = (C.c_int * 3)()
+    rc = L.jpeggpu_ext_parse_headers(items, 3, 2, st)
+    assert list(st) == [0, rc, 0] and rc != 0
+    assert infos[0].num_components == 3 and infos[2].num_components == 1
+    items[2].decoder = decs[0]._h.value  # the same decoder twice
+    assert L.jpeggpu_ext_parse_headers(items, 3, 2, st) == int(jpeggpu_amd.Status.INVALID_ARGUMENT)
+    for d in decs:
+        d.cleanup()
+
+
 def test_fails_loudly_without_a_device(L):
     """No CPU fallback: without a HIP device transfer/decode return an error, never fake planes."""
     import torch

@@ -28,6 +28,8 @@ typedef struct {
     int noise;            /* amplitude of the white-noise term, 0..64 */
     int fill_bytes;       /* number of FF fill bytes inserted before every RSTn / EOI marker */
     uint64_t seed;
+    int qmax;             /* largest quantiser value; 0 = 127. Above 255 the tables are written with 16-bit
+                             entries (Pq = 1), as libjpeg does at low quality without -baseline */
 } js_params;
 
 static const uint8_t kZigzag[64] = {
@@ -324,8 +326,9 @@ size_t js_encode(const js_params* p, uint8_t* out, size_t cap)
         int scale = q < 50 ? 5000 / q : 200 - 2 * q;
         for (int i = 0; i < 64; ++i) {
             int a = (kLumaQ[i] * scale + 50) / 100, b = (kChromaQ[i] * scale + 50) / 100;
-            qt[0][i] = (uint16_t)(a < 1 ? 1 : a > 127 ? 127 : a);
-            qt[1][i] = (uint16_t)(b < 1 ? 1 : b > 127 ? 127 : b);
+            const int qmax = p->qmax <= 0 ? 127 : p->qmax > 65535 ? 65535 : p->qmax;
+            qt[0][i] = (uint16_t)(a < 1 ? 1 : a > qmax ? qmax : a);
+            qt[1][i] = (uint16_t)(b < 1 ? 1 : b > qmax ? qmax : b);
         }
     }
     const int single = nc == 1;
@@ -402,11 +405,19 @@ size_t js_encode(const js_params* p, uint8_t* out, size_t cap)
 
     /* headers */
     put_marker(&w, 0xD8);
-    put_marker(&w, 0xDB);
-    put_u16(&w, 2 + 2 * 65);
-    for (int t = 0; t < 2; ++t) {
-        put_byte_raw(&w, t);
-        for (int k = 0; k < 64; ++k) put_byte_raw(&w, qt[t][kZigzag[k]]);
+    {
+        int wide = 0;
+        for (int t = 0; t < 2; ++t)
+            for (int k = 0; k < 64; ++k) wide |= qt[t][k] > 255;
+        put_marker(&w, 0xDB);
+        put_u16(&w, 2 + 2 * (1 + (wide ? 128 : 64)));
+        for (int t = 0; t < 2; ++t) {
+            put_byte_raw(&w, (wide ? 0x10 : 0) | t);
+            for (int k = 0; k < 64; ++k) {
+                if (wide) put_byte_raw(&w, qt[t][kZigzag[k]] >> 8);
+                put_byte_raw(&w, qt[t][kZigzag[k]] & 0xFF);
+            }
+        }
     }
     put_marker(&w, 0xC0);
     put_u16(&w, 8 + 3 * nc);

@@ -11,7 +11,7 @@ class _Params(C.Structure):
     _fields_ = [("width", C.c_int), ("height", C.c_int), ("ncomp", C.c_int),
                 ("hs", C.c_int * 4), ("vs", C.c_int * 4),
                 ("interleaved", C.c_int), ("restart_interval", C.c_int), ("quality", C.c_int),
-                ("optimize", C.c_int), ("noise", C.c_int), ("fill_bytes", C.c_int), ("seed", C.c_uint64)]
+                ("optimize", C.c_int), ("noise", C.c_int), ("fill_bytes", C.c_int), ("seed", C.c_uint64), ("qmax", C.c_int)]
 
 
 def build(force=False):
@@ -25,7 +25,7 @@ _lib = None
 
 
 def encode(width, height, sampling=((2, 2), (1, 1), (1, 1)), interleaved=True, restart_interval=0,
-           quality=75, optimize=False, noise=6, fill_bytes=0, seed=0) -> bytes:
+           quality=75, optimize=False, noise=6, fill_bytes=0, seed=0, qmax=0) -> bytes:
     """sampling: one (h, v) pair per component (1..4 components)."""
     global _lib
     if _lib is None:
@@ -38,7 +38,7 @@ def encode(width, height, sampling=((2, 2), (1, 1), (1, 1)), interleaved=True, r
     for c, (h, v) in enumerate(sampling):
         p.hs[c], p.vs[c] = h, v
     p.interleaved, p.restart_interval, p.quality = int(interleaved), restart_interval, quality
-    p.optimize, p.noise, p.fill_bytes, p.seed = int(optimize), noise, fill_bytes, seed
+    p.optimize, p.noise, p.fill_bytes, p.seed, p.qmax = int(optimize), noise, fill_bytes, seed, qmax
     cap = 1024 + width * height * len(sampling) * 3
     buf = C.create_string_buffer(cap)
     n = _lib.js_encode(C.byref(p), buf, cap)
