@@ -17,6 +17,7 @@
 #include <hip/hip_runtime.h>
 
 #include <cstdlib>
+#include <algorithm>
 #include <atomic>
 #include <cstring>
 #include <thread>
@@ -335,6 +336,9 @@ jpeggpu_status build_jobs(
         job.flow_list  = reinterpret_cast<int*>(base + pl.flow_list);
         job.tail_parts = reinterpret_cast<const int*>(blob + pl.blob_parts);
         job.num_tail_parts = static_cast<int>(sc.tail_parts.size()) - 1;
+        job.max_tail_part  = 0;
+        for (size_t k = 0; k + 1 < sc.tail_parts.size(); ++k)
+            job.max_tail_part = std::max(job.max_tail_part, sc.tail_parts[k + 1] - sc.tail_parts[k]);
         job.tails_n    = reinterpret_cast<int*>(base + pl.tails_n);
         job.tails_dc01 = reinterpret_cast<uint32_t*>(base + pl.tails_dc01);
         job.tails_dc23 = reinterpret_cast<uint32_t*>(base + pl.tails_dc23);

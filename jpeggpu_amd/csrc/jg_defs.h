@@ -22,7 +22,7 @@ constexpr int kMaxDuPerMcu  = 10; // T.81 B.2.3
 constexpr int kSeqLanes    = 256; // lanes per workgroup of the Huffman kernels (reference decode_huffman.cu:777)
 constexpr int kSeqOverlap  = 16;  // lanes of the sync kernel that re-decode the tail of the previous sequence
 constexpr int kSeqSubseq   = kSeqLanes - kSeqOverlap; // subsequences owned by one workgroup ("sequence")
-constexpr int kTailPartSubseq = 2048; // target subsequences per workgroup of huff_sync_tail (cut at segment starts)
+constexpr int kTailPartSubseq = 512; // target subsequences per workgroup of huff_sync_tail (cut at segment starts)
 constexpr int kDestuffWin   = 4096; // stuffed bytes handled by one destuff workgroup (256 lanes x 16 B)
 
 /// Zig-zag index -> raster index inside a data unit (T.81 figure A.6; reference src/defs.hpp:94-102).
@@ -202,6 +202,7 @@ struct ScanJob {
     int* flow_list;              // [num_subseq] scratch of huff_sync_tail
     const int* tail_parts;       // [num_tail_parts + 1] subsequence ranges of huff_sync_tail's workgroups
     int num_tail_parts;
+    int max_tail_part;           // subsequences in the largest part
     int* tails_n;                // per-sequence aggregates used to place the write pass
     uint32_t* tails_dc01;
     uint32_t* tails_dc23;

@@ -294,10 +294,16 @@ __global__ __launch_bounds__(T) void huff_sync_intra(JS js)
 // Huffman: inter-sequence synchronisation
 // ------------------------------------------------------------------------------------------------
 
-constexpr int TL = 1024; // lanes of the tail kernel
+/// Lanes of the tail kernel. A part cut from a scan with restart markers holds ~500 subsequences and a
+/// few dozen flows: 256 lanes, so that the idle waves of the ~500 us this latency-bound kernel lives do not
+/// hold the wave slots other streams' kernels need (16-wave workgroups held 3/4 of them: -8 % throughput
+/// with overlapping streams). A scan without restart markers is one part with thousands of flows: 1024
+/// lanes, or its ordered groups of flows would run one after the other.
+constexpr int kTailLanesSmall = 256, kTailLanesLarge = 1024, kTailLargeFrom = 1024;
 
 /// Inclusive block-wide position of the set flags among TL lanes; returns the block total.
-__device__ __forceinline__ int block_rank_1024(bool flag, int* s_wave, int& rank)
+template <int TL>
+__device__ __forceinline__ int block_rank(bool flag, int* s_wave, int& rank)
 {
     const unsigned long long m = __ballot(flag);
     const int before           = __popcll(m & ((1ull << lane_id()) - 1ull));
@@ -332,7 +338,7 @@ __device__ __forceinline__ int block_rank_1024(bool flag, int* s_wave, int& rank
 /// ahead; only the Huffman tables and the repacking buffer need LDS. With the overlap lanes of
 /// huff_sync_intra a boundary flow normally confirms the stored state in its first iteration; this
 /// kernel is what makes the result exact.
-template <int W, class JS>
+template <int W, int TL, class JS>
 __global__ __launch_bounds__(TL) void huff_sync_tail(JS js)
 {
     extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
@@ -357,7 +363,7 @@ __global__ __launch_bounds__(TL) void huff_sync_tail(JS js)
         const int sub = base + tid;
         const bool f  = sub < hi && sub + 1 < sp.num_subseq && (J.pending[sub] != 0 || (sub + 1) % SEQ == 0);
         int rank;
-        const int total = block_rank_1024(f, s_wave, rank);
+        const int total = block_rank<TL>(f, s_wave, rank);
         if (f) J.flow_list[lo + count + rank] = sub;
         count += total;
     }
@@ -403,7 +409,7 @@ __global__ __launch_bounds__(TL) void huff_sync_tail(JS js)
             // re-pack the survivors into the lowest lanes (also the barrier + workgroup-scope fence
             // that makes this iteration's state stores visible to the next one)
             int rank;
-            const int total = block_rank_1024(flowing, s_wave, rank);
+            const int total = block_rank<TL>(flowing, s_wave, rank);
             if (total == 0) break;
             if (flowing) {
                 s_j[rank]  = j;
@@ -1007,7 +1013,15 @@ hipError_t launch_huff(Stage stage, const JS& js, const JobExtent& e, int grid_y
         break;
     case kStageSyncInter:
         if (e.max_tail_parts > 0)
-            huff_sync_tail<W, JS><<<dim3(e.max_tail_parts, grid_y), TL, 3 * TL * 4 + e.max_tab_bytes, stream>>>(js);
+        {
+            if (e.max_tail_part >= kTailLargeFrom) {
+                constexpr int TL = kTailLanesLarge;
+                huff_sync_tail<W, TL, JS><<<dim3(e.max_tail_parts, grid_y), TL, 3 * TL * 4 + e.max_tab_bytes, stream>>>(js);
+            } else {
+                constexpr int TL = kTailLanesSmall;
+                huff_sync_tail<W, TL, JS><<<dim3(e.max_tail_parts, grid_y), TL, 3 * TL * 4 + e.max_tab_bytes, stream>>>(js);
+            }
+        }
         break;
     case kStageWrite:
         huff_write<W, JS><<<dim3(e.max_seq, grid_y), T, WriteLds::kTabs + e.max_tab_bytes, stream>>>(js);
@@ -1062,6 +1076,7 @@ void extend(JobExtent& e, const ScanJob& job)
     e.max_tab_bytes   = job.sp.tab_bytes > e.max_tab_bytes ? job.sp.tab_bytes : e.max_tab_bytes;
     e.subseq_words    = job.sp.subseq_words;
     e.max_tail_parts  = job.num_tail_parts > e.max_tail_parts ? job.num_tail_parts : e.max_tail_parts;
+    e.max_tail_part   = job.max_tail_part > e.max_tail_part ? job.max_tail_part : e.max_tail_part;
 }
 
 hipError_t launch_stage(Stage stage, const ScanJob& job, hipStream_t stream)

@@ -28,6 +28,7 @@ struct JobExtent {
     int max_chunks      = 0;
     int max_seq         = 0;
     int max_tail_parts  = 0;
+    int max_tail_part   = 0; // subsequences in the largest tail part of any job
     int max_idct_blocks = 0;
     int subseq_words    = 0; // identical for every job of a launch
     uint32_t max_tab_bytes = 0;
