@@ -110,8 +110,9 @@ enum jpeggpu_status jpeggpu_ext_decode_batch(
     size_t scratch_size,
     jpeggpu_stream_t stream);
 enum jpeggpu_status jpeggpu_ext_batch_destroy(jpeggpu_batch_t batch);
-/* Lock-step flow iterations inside the per-sequence sync kernel before unfinished flows are handed to
- * the low-footprint, re-packing tail kernel (default 1; the drop-in decode keeps all flows in the sequence kernel). */
+/* Lock-step flow iterations inside the per-sequence sync kernel (>= 1: the first one is what gives every
+ * subsequence its coefficient count and DC sums) before unfinished flows are handed to the low-footprint,
+ * re-packing tail kernel (default 1; the drop-in decode keeps all flows in the sequence kernel). */
 enum jpeggpu_status jpeggpu_ext_batch_set_sync_iterations(jpeggpu_batch_t batch, int iterations);
 /* Stage timing of batched decodes; same contract as jpeggpu_ext_set_profiling / _get_stage_ms. */
 enum jpeggpu_status jpeggpu_ext_batch_set_profiling(jpeggpu_batch_t batch, int enable);

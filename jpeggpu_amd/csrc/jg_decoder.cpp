@@ -673,7 +673,7 @@ enum jpeggpu_status jpeggpu_ext_decode_batch(
 
 enum jpeggpu_status jpeggpu_ext_batch_set_sync_iterations(jpeggpu_batch_t batch, int iterations)
 {
-    if (!batch || iterations < 0) return JPEGGPU_INVALID_ARGUMENT;
+    if (!batch || iterations < 1) return JPEGGPU_INVALID_ARGUMENT; // the first flow iteration supplies n and the DC sums
     batch->sync_iters = iterations;
     return JPEGGPU_SUCCESS;
 }

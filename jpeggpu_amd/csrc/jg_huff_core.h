@@ -143,13 +143,20 @@ JG_HD inline uint32_t bits_field(uint32_t peek, int total_len, int s)
 #endif
 }
 
-/// Sink used by the synchronisation passes: nothing is stored.
+/// Sink of the flow passes: nothing is stored; n and the DC sums of the subsequence are accumulated.
 struct NoSink {
     static constexpr bool kWrite      = false;
     static constexpr bool kWholeUnits = false;
+    static constexpr bool kSums       = true;
     JG_HD inline bool full() const { return false; }
     JG_HD inline void symbol(bool, bool, uint32_t, bool) {}
     JG_HD inline void tick() {}
+};
+
+/// Sink of the speculative pass: only the exit state (p, c, z) is wanted -- every subsequence is decoded
+/// again from a real predecessor state (or its segment's start) by a flow, which supplies n and the sums.
+struct SpecSink : NoSink {
+    static constexpr bool kSums = false;
 };
 
 /// One entry of the symbol stream the write pass emits: a non-zero coefficient (or the absolute DC)
@@ -160,7 +167,8 @@ JG_HD inline uint32_t sym_entry(int zpos, int value)
 }
 
 /// Decode from `st` up to bit `end_bit` of the segment, committing symbols that end at or before it.
-/// `st.n`, `st.dc01`, `st.dc23` accumulate. `tabs` is the scan's table pack (LDS on the device).
+/// `st.n`, `st.dc01`, `st.dc23` accumulate (not with SpecSink). `tabs` is the scan's table pack (LDS on
+/// the device).
 ///
 /// With Sink::kWholeUnits (write pass) a lane owns whole data units: those whose DC symbol its
 /// subsequence commits. It keeps decoding past `end_bit` until the unit it started is complete, and
@@ -228,7 +236,7 @@ JG_HD inline void decode_subsequence(
             // int16 prefix sum (decode_dc.cu:129-155); an AC coefficient sits at zig-zag index z1 - 1
             const int absdc   = static_cast<int>(((static_cast<uint64_t>(dc23) << 32) | dc01) >> sh);
             sink.symbol(is_dc, s != 0, sym_entry(z1 - 1, is_dc ? absdc : v), du_end);
-        } else if (is_dc) {
+        } else if (Sink::kSums && is_dc) {
             const int s      = (e >> 5) & 15;
             const int v      = extend_magnitude(bits_field(peek, total, s), s);
             const uint64_t d = static_cast<uint64_t>(static_cast<uint32_t>(v) & 0xFFFFu) << (JG_CUR_META & 63);
@@ -236,11 +244,11 @@ JG_HD inline void decode_subsequence(
             dc23             = pk_add_u16(dc23, static_cast<uint32_t>(d >> 32));
         }
         z = du_end ? 0 : z1;
-        units += du_end ? 1 : 0;
+        if (Sink::kWrite || Sink::kSums) units += du_end ? 1 : 0;
         cur = JG_LOAD_CURSOR(du_end ? JG_CUR_NEXT : JG_CUR_SELF);
         if (Sink::kWrite) sink.tick(); // once per iteration, whatever the symbol was
     }
-    st.n += 64 * units + z - st.z;
+    if (Sink::kWrite || Sink::kSums) st.n += 64 * units + z - st.z;
     st.p    = p;
     st.z    = z;
     st.c    = (JG_CUR_META >> 8) & 0xFF;

@@ -32,6 +32,7 @@ struct HostFetch {
 struct HostSink {
     static constexpr bool kWrite      = true;
     static constexpr bool kWholeUnits = true;
+    static constexpr bool kSums       = true;
     uint32_t* sym;
     uint2_t* du_tab;
     uint32_t cur, cur_end, du_off;
@@ -152,36 +153,56 @@ int emu_decode_scan(
     };
 
     std::vector<uint8_t> pend(S, 0);
+    if (max_intra_iters < 1) return JPEGGPU_INVALID_ARGUMENT; // the first flow iteration supplies n and the DC sums
 
-    // ---- intra-sequence (huff_sync_intra) ----
+    // ---- speculative pass of every subsequence (first half of huff_sync_intra): exit state only ----
+    for (int sub = 0; sub < S; ++sub) {
+        const Segment seg = sc.segments[segi[sub]];
+        const int rel     = sub - seg.subseq_offset;
+        HostFetch f{dst.data() + static_cast<size_t>(seg.subseq_offset) * subseq_bytes, seg.subseq_count * W};
+        LaneState ls{};
+        ls.p = rel * bits;
+        BitWindow<HostFetch> bw;
+        bw.seek(ls.p, f);
+        SpecSink spec_sink;
+        decode_subsequence(ls, bw, f, (rel + 1) * bits, tabs, sp, spec_sink);
+        st[sub].p  = ls.p;
+        st[sub].cz = ls.c | (ls.z << 8);
+    }
+    const std::vector<St> spec = st;
+
+    // ---- flow passes inside a sequence (second half of huff_sync_intra) ----
+    // Emulation lane t first decodes subsequence first + t (the device's lane index is one lower: there a
+    // lane holds the predecessor): from the predecessor's speculative exit state, or from the segment's
+    // start state when the subsequence opens a segment.
     const int num_seq = (S + T - 1) / T;
     for (int b = 0; b < num_seq; ++b) {
         const int first = b * T, nsub = std::min(T, S - first);
         std::vector<Lane> ln(nsub);
         for (int t = 0; t < nsub; ++t) {
-            const int sub      = first + t;
-            const Segment seg  = sc.segments[segi[sub]];
-            const int rel      = sub - seg.subseq_offset;
+            const int j        = first + t;
+            const Segment seg  = sc.segments[segi[j]];
+            const int rel      = j - seg.subseq_offset;
             Lane& L            = ln[t];
             L.f                = HostFetch{dst.data() + static_cast<size_t>(seg.subseq_offset) * subseq_bytes, seg.subseq_count * W};
             L.lim              = std::min(nsub, seg.subseq_offset + seg.subseq_count - first);
             L.s                = LaneState{};
-            L.s.p              = rel * bits;
-            L.end_bit          = (rel + 1) * bits;
+            if (rel > 0) {
+                L.s.p = spec[j - 1].p;
+                L.s.c = spec[j - 1].cz & 0xFF;
+                L.s.z = spec[j - 1].cz >> 8;
+            }
+            L.end_bit = rel * bits;
             L.bw.seek(L.s.p, L.f);
-            decode_subsequence(L.s, L.bw, L.f, L.end_bit, tabs, sp, nosink);
-            St& o = st[sub];
-            o.p = L.s.p; o.n = L.s.n; o.cz = L.s.c | (L.s.z << 8);
-            o.dc01 = L.s.dc01; o.dc23 = L.s.dc23;
             L.flowing = true;
         }
         int iter = 0;
         for (; iter < max_intra_iters; ++iter) {
             bool any = false;
-            for (int t = 0; t < nsub; ++t) if (ln[t].flowing && t + 1 + iter < ln[t].lim && iter < 512) ++g_active_hist[iter];
-            for (int t = 0; t < nsub; ++t) { // entry j of iteration `iter` is touched by lane t only
+            for (int t = 0; t < nsub; ++t) if (ln[t].flowing && t + iter < ln[t].lim && iter < 512) ++g_active_hist[iter];
+            for (int t = 0; t < nsub; ++t) { // entry t + iter of iteration `iter` is touched by lane t only
                 Lane& L     = ln[t];
-                const int j = t + 1 + iter;
+                const int j = t + iter;
                 if (L.flowing && j < L.lim) {
                     L.s.n = 0;
                     L.s.dc01 = L.s.dc23 = 0;
@@ -202,7 +223,7 @@ int emu_decode_scan(
         }
         if (iter == max_intra_iters) { // flows cut short continue in the tail pass from the entry they reached
             for (int t = 0; t < nsub; ++t)
-                if (ln[t].flowing && t + 1 + iter < ln[t].lim) pend[first + t + iter] = 1;
+                if (ln[t].flowing && t + iter < ln[t].lim) pend[first + t + iter - 1] = 1;
         }
     }
 

@@ -63,7 +63,7 @@ int main(int argc, char** argv)
         }
         if (kind == 3 && d.size() > 64) d.resize(d.size() - rnd() % (d.size() / 2)); // truncation
         static const int sizes[3] = {32, 64, 128};
-        static const int caps[4]  = {256, 1, 3, 0};
+        static const int caps[4]  = {256, 1, 3, 2};
         const int sb = sizes[rnd() % 3], cap = caps[rnd() % 4];
         for (int scan = 0; scan < 4; ++scan) {
             int ns = 0, nd = 0, iters = 0;

@@ -207,7 +207,7 @@ def test_batch_decode_equals_single(torch_cuda):
     batch = jpeggpu_amd.Batch(total_scans)
     scratch = torch.empty(batch.scratch_size, dtype=torch.uint8, device="cuda:0")
     batch.set_items(entries)
-    for rep, iters in enumerate([3, 0, 1, 256]):  # cap of the sequence kernel's lock-step loop; 0: every flow in the tail kernel
+    for rep, iters in enumerate([3, 1, 2, 256]):  # cap of the sequence kernel's lock-step loop (>= 1)
         batch.set_sync_iterations(iters)
         for _, _, planes in keep:
             for p in planes:
