@@ -27,6 +27,75 @@ constexpr int T   = kSeqLanes;   // lanes per workgroup in the Huffman kernels
 constexpr int SEQ = kSeqSubseq;  // subsequences a workgroup owns
 constexpr int OV  = kSeqOverlap; // lanes that re-decode the tail of the previous sequence
 
+/// Pointers read out of a job that lives in memory are generic to the compiler, and generic (flat) loads
+/// and stores count against lgkmcnt as well as vmcnt: every wait for an LDS table read would also wait for
+/// the bitstream word prefetched one refill ahead. The kernels therefore work on a view of the job whose
+/// pointers are qualified as global memory (kernel arguments passed by value are inferred global anyway).
+#define JG_GLOBAL __attribute__((address_space(1)))
+template <class T>
+__device__ __forceinline__ JG_GLOBAL T* as_global(T* p)
+{
+    return (JG_GLOBAL T*)p;
+}
+
+/// Class types do not copy through address-space-qualified pointers: move them as vectors of dwords.
+template <class T>
+__device__ __forceinline__ T ld_global(JG_GLOBAL const T* p)
+{
+    static_assert(sizeof(T) % 4 == 0 && alignof(T) >= 4, "dword-sized objects only");
+    typedef uint32_t V __attribute__((ext_vector_type(sizeof(T) / 4)));
+    const V v = *reinterpret_cast<JG_GLOBAL const V*>(p);
+    return __builtin_bit_cast(T, v);
+}
+template <class T>
+__device__ __forceinline__ void st_global(JG_GLOBAL T* p, const T& value)
+{
+    static_assert(sizeof(T) % 4 == 0 && alignof(T) >= 4, "dword-sized objects only");
+    typedef uint32_t V __attribute__((ext_vector_type(sizeof(T) / 4)));
+    *reinterpret_cast<JG_GLOBAL V*>(p) = __builtin_bit_cast(V, value);
+}
+
+struct JobView {
+    JG_GLOBAL const uint8_t* bytes;
+    JG_GLOBAL const DestuffChunk* chunks;
+    JG_GLOBAL const Segment* segments;
+    JG_GLOBAL const uint8_t* tables;
+    JG_GLOBAL const uint16_t* qtables;
+    JG_GLOBAL uint8_t* destuffed;
+    JG_GLOBAL int* seg_idx;
+    JG_GLOBAL int* st_p;
+    JG_GLOBAL int* st_n;
+    JG_GLOBAL int* st_cz;
+    JG_GLOBAL uint32_t* st_dc01;
+    JG_GLOBAL uint32_t* st_dc23;
+    JG_GLOBAL uint8_t* pending;
+    JG_GLOBAL int* flow_list;
+    JG_GLOBAL const int* tail_parts;
+    int num_tail_parts;
+    JG_GLOBAL int* tails_n;
+    JG_GLOBAL uint32_t* tails_dc01;
+    JG_GLOBAL uint32_t* tails_dc23;
+    JG_GLOBAL uint32_t* sym;
+    JG_GLOBAL uint2_t* du_tab;
+    uint32_t sym_region;
+    uint64_t sym_entries;
+    int num_chunks;
+    int num_seq;
+    const ScanParams& sp;
+    const IdctParams& ip;
+    __device__ __forceinline__ explicit JobView(const ScanJob& j)
+        : bytes(as_global(j.bytes)), chunks(as_global(j.chunks)), segments(as_global(j.segments)),
+          tables(as_global(j.tables)), qtables(as_global(j.qtables)), destuffed(as_global(j.destuffed)),
+          seg_idx(as_global(j.seg_idx)), st_p(as_global(j.st_p)), st_n(as_global(j.st_n)), st_cz(as_global(j.st_cz)),
+          st_dc01(as_global(j.st_dc01)), st_dc23(as_global(j.st_dc23)), pending(as_global(j.pending)),
+          flow_list(as_global(j.flow_list)), tail_parts(as_global(j.tail_parts)), num_tail_parts(j.num_tail_parts),
+          tails_n(as_global(j.tails_n)), tails_dc01(as_global(j.tails_dc01)), tails_dc23(as_global(j.tails_dc23)),
+          sym(as_global(j.sym)), du_tab(as_global(j.du_tab)), sym_region(j.sym_region), sym_entries(j.sym_entries),
+          num_chunks(j.num_chunks), num_seq(j.num_seq), sp(j.sp), ip(j.ip)
+    {
+    }
+};
+
 struct JobByValue {
     // One image: ~14 dependent flow iterations decide the time, the speculative pass is one of them.
     static constexpr bool kSpeculateStateOnly = false;
@@ -68,17 +137,17 @@ __global__ __launch_bounds__(256) void destuff_kernel(JS js)
     __shared__ __attribute__((aligned(16))) uint8_t s_out[kDestuffWin + 32];
     __shared__ uint32_t s_wave[4];
 
-    const ScanJob& J = js.get();
+    const JobView J(js.get());
     if (static_cast<int>(blockIdx.x) >= J.num_chunks) return;
-    const uint8_t* __restrict__ src = J.bytes;
-    uint8_t* __restrict__ dst       = J.destuffed;
-    const DestuffChunk ck           = J.chunks[blockIdx.x];
+    JG_GLOBAL const uint8_t* __restrict__ src = J.bytes;
+    JG_GLOBAL uint8_t* __restrict__ dst       = J.destuffed;
+    const DestuffChunk ck           = ld_global(J.chunks + blockIdx.x);
     const int t                     = threadIdx.x;
     const uint32_t gpos             = ck.win_off + t * 16;
 
     uint32_t w[4];
     {
-        const uint4 v = *reinterpret_cast<const uint4*>(src + gpos);
+        const uint4 v = ld_global(reinterpret_cast<JG_GLOBAL const uint4*>(src + gpos));
         w[0] = v.x; w[1] = v.y; w[2] = v.z; w[3] = v.w;
     }
     uint32_t prev = __shfl_up(w[3] >> 24, 1);
@@ -129,7 +198,7 @@ __global__ __launch_bounds__(256) void destuff_kernel(JS js)
     // write-out into the tiled layout (jg_defs.h): 4-byte words, byte stores at the two ragged ends
     // (neighbouring chunks own the other bytes of those words)
     const int log2w          = 31 - __clz(J.sp.subseq_words);
-    uint32_t* const dst32    = reinterpret_cast<uint32_t*>(dst);
+    JG_GLOBAL uint32_t* const dst32 = reinterpret_cast<JG_GLOBAL uint32_t*>(dst);
     const uint32_t word0     = (ck.dst_off - phase) >> 2; // linear word of s_out[0]
     const uint32_t lo = phase, hi = phase + total;        // valid LDS byte range
     for (uint32_t g = t; g * 4 < hi; g += 256) {
@@ -166,7 +235,7 @@ __global__ __launch_bounds__(256) void destuff_kernel(JS js)
 template <int W>
 struct GlobalFetch {
     static constexpr int kLog2W = W == 8 ? 3 : W == 16 ? 4 : 5;
-    const uint32_t* scan32; // the scan's destuffed buffer (tiled): the same for every lane (scalar base address)
+    JG_GLOBAL const uint32_t* scan32; // the scan's destuffed buffer (tiled): the same for every lane (scalar base address)
     int seg_word0;          // first (linear) word of the lane's segment
     int seg_words;
     __device__ __forceinline__ uint32_t raw(int w) const
@@ -180,11 +249,11 @@ struct GlobalFetch {
 };
 
 /// Copy the scan's Huffman table pack (a multiple of 16 bytes) into LDS.
-__device__ __forceinline__ void load_tables(uint8_t* s_tab, const uint8_t* __restrict__ g_tab, uint32_t bytes)
+__device__ __forceinline__ void load_tables(uint8_t* s_tab, JG_GLOBAL const uint8_t* __restrict__ g_tab, uint32_t bytes)
 {
     uint4* d       = reinterpret_cast<uint4*>(s_tab);
-    const uint4* s = reinterpret_cast<const uint4*>(g_tab);
-    for (uint32_t i = threadIdx.x; i < bytes / 16; i += blockDim.x) d[i] = s[i];
+    JG_GLOBAL const uint4* s = reinterpret_cast<JG_GLOBAL const uint4*>(g_tab);
+    for (uint32_t i = threadIdx.x; i < bytes / 16; i += blockDim.x) d[i] = ld_global(s + i);
 }
 
 /// Carve of the dynamic LDS of the two sequence-wide Huffman kernels.
@@ -222,7 +291,7 @@ __global__ __launch_bounds__(T) void huff_sync_intra(JS js)
     int* s_pend      = reinterpret_cast<int*>(s_dc23 + T);
     uint8_t* s_tab   = smem + SeqLds::kTabs;
 
-    const ScanJob& J = js.get();
+    const JobView J(js.get());
     if (static_cast<int>(blockIdx.x) >= J.num_seq) return;
     const ScanParams sp = J.sp;
     const int t         = threadIdx.x;
@@ -239,12 +308,12 @@ __global__ __launch_bounds__(T) void huff_sync_intra(JS js)
     const bool active   = sub >= 0 && t < img_end;
     LaneState st{};
     BitWindow<GlobalFetch<W>> bw{};
-    GlobalFetch<W> fetch{reinterpret_cast<const uint32_t*>(J.destuffed), 0, 1};
+    GlobalFetch<W> fetch{reinterpret_cast<JG_GLOBAL const uint32_t*>(J.destuffed), 0, 1};
     Segment seg{0, 0};
     int rel = 0;
     if (active) {
         // speculative pass: the own subsequence from the guessed state (c, z) = (0, 0), exit state only
-        seg             = J.segments[J.seg_idx[sub]];
+        seg             = ld_global(J.segments + J.seg_idx[sub]);
         rel             = sub - seg.subseq_offset;
         fetch.seg_word0 = seg.subseq_offset * W;
         fetch.seg_words = seg.subseq_count * W;
@@ -275,7 +344,7 @@ __global__ __launch_bounds__(T) void huff_sync_intra(JS js)
     if (flowing) {
         const int sub_j = img_first + t + 1;
         if (JS::kSpeculateStateOnly && (!active || rel + 1 == seg.subseq_count)) { // j opens the next segment
-            seg             = J.segments[J.seg_idx[sub_j]];
+            seg             = ld_global(J.segments + J.seg_idx[sub_j]);
             rel             = -1;
             fetch.seg_word0 = seg.subseq_offset * W;
             fetch.seg_words = seg.subseq_count * W;
@@ -380,10 +449,10 @@ __global__ __launch_bounds__(TL) void huff_sync_tail(JS js)
     int* s_cz      = s_pz + TL;                    // its c | z << 8
     uint8_t* s_tab = reinterpret_cast<uint8_t*>(s_cz + TL);
 
-    const ScanJob& J = js.get();
+    const JobView J(js.get());
     if (static_cast<int>(blockIdx.x) >= J.num_tail_parts) return;
     const ScanParams sp    = J.sp;
-    const uint32_t* scan32 = reinterpret_cast<const uint32_t*>(J.destuffed);
+    JG_GLOBAL const uint32_t* scan32 = reinterpret_cast<JG_GLOBAL const uint32_t*>(J.destuffed);
     const int lo           = J.tail_parts[blockIdx.x];
     const int hi           = J.tail_parts[blockIdx.x + 1];
     const int tid          = threadIdx.x;
@@ -416,7 +485,7 @@ __global__ __launch_bounds__(TL) void huff_sync_tail(JS js)
         while (true) {
             bool flowing = false;
             if (live) {
-                const Segment seg = J.segments[J.seg_idx[j - 1]];
+                const Segment seg = ld_global(J.segments + J.seg_idx[j - 1]);
                 const int lim     = seg.subseq_offset + seg.subseq_count;
                 if (j < lim) {
                     GlobalFetch<W> fetch{scan32, seg.subseq_offset * W, seg.subseq_count * W};
@@ -486,7 +555,7 @@ template <class JS>
 __global__ __launch_bounds__(T) void huff_seq_tails(JS js)
 {
     __shared__ uint32_t s_red[4];
-    const ScanJob& J = js.get();
+    const JobView J(js.get());
     if (static_cast<int>(blockIdx.x) >= J.num_seq) return;
     const int t         = threadIdx.x;
     const int first_sub = blockIdx.x * SEQ;
@@ -531,8 +600,8 @@ struct StreamSink {
     static constexpr bool kWrite      = true;
     static constexpr bool kWholeUnits = true;
     static constexpr bool kSums       = true;
-    uint32_t* sym;
-    uint2_t* du_tab;
+    JG_GLOBAL uint32_t* sym;
+    JG_GLOBAL uint2_t* du_tab;
     uint32_t* ring;     // &s_ring[lane]; slot k at ring[k * T]
     uint32_t flushed;   // entries of this lane already in memory (region base + multiples of 8)
     uint32_t emitted;   // entries produced so far (region base + count)
@@ -557,7 +626,7 @@ struct StreamSink {
         const uint32_t slot = emit ? (emitted & (kStageEntries - 1)) : kStageEntries;
         ring[slot * T]      = entry;
         emitted += emit ? 1u : 0u;
-        if (unit_end && started) du_tab[du_index] = uint2_t{du_off, emitted - du_off};
+        if (unit_end && started) st_global(du_tab + du_index, uint2_t{du_off, emitted - du_off});
     }
     /// kFlushEntries entries from the ring to memory; `flushed` is a multiple of kFlushEntries.
     __device__ __forceinline__ void flush_sector()
@@ -566,9 +635,9 @@ struct StreamSink {
         const uint32_t* r = ring + (flushed & (kStageEntries - 1)) * T; // no wrap inside a flush unit
 #pragma unroll
         for (int k = 0; k < kFlushEntries; ++k) e[k] = r[k * T];
-        uint4* dst = reinterpret_cast<uint4*>(sym + flushed);
+        JG_GLOBAL uint4* dst = reinterpret_cast<JG_GLOBAL uint4*>(sym + flushed);
 #pragma unroll
-        for (int k = 0; k < kFlushEntries / 4; ++k) dst[k] = make_uint4(e[4 * k], e[4 * k + 1], e[4 * k + 2], e[4 * k + 3]);
+        for (int k = 0; k < kFlushEntries / 4; ++k) st_global(dst + k, make_uint4(e[4 * k], e[4 * k + 1], e[4 * k + 2], e[4 * k + 3]));
         flushed += kFlushEntries;
     }
     __device__ __forceinline__ void tick()
@@ -637,7 +706,7 @@ __global__ __launch_bounds__(T) void huff_write(JS js)
     uint32_t* s_ring  = reinterpret_cast<uint32_t*>(smem + WriteLds::kRing);
     uint8_t* s_tab    = smem + WriteLds::kTabs;
 
-    const ScanJob& J = js.get();
+    const JobView J(js.get());
     if (static_cast<int>(blockIdx.x) >= J.num_seq) return;
     const ScanParams sp = J.sp;
     const int t         = threadIdx.x;
@@ -648,7 +717,7 @@ __global__ __launch_bounds__(T) void huff_write(JS js)
 
     // carry-in of the segment that is open at the sequence's first subsequence
     {
-        const Segment seg0 = J.segments[J.seg_idx[first_sub]];
+        const Segment seg0 = ld_global(J.segments + J.seg_idx[first_sub]);
         const int a        = seg0.subseq_offset / SEQ; // sequence holding the segment's start
         uint32_t cn = 0, c01 = 0, c23 = 0;
         if (seg0.subseq_offset < first_sub) {
@@ -676,7 +745,7 @@ __global__ __launch_bounds__(T) void huff_write(JS js)
     bool carried = false; // segment started before this sequence
     if (active) {
         seg_i   = J.seg_idx[sub];
-        seg     = J.segments[seg_i];
+        seg     = ld_global(J.segments + seg_i);
         rel     = sub - seg.subseq_offset;
         carried = seg.subseq_offset < first_sub;
         ts      = carried ? 0 : seg.subseq_offset - first_sub;
@@ -721,7 +790,7 @@ __global__ __launch_bounds__(T) void huff_write(JS js)
         st.z         = cz >> 8;
     }
     sink.started = st.z == 0;
-    GlobalFetch<W> fetch{reinterpret_cast<const uint32_t*>(J.destuffed), seg.subseq_offset * W, seg.subseq_count * W};
+    GlobalFetch<W> fetch{reinterpret_cast<JG_GLOBAL const uint32_t*>(J.destuffed), seg.subseq_offset * W, seg.subseq_count * W};
     BitWindow<GlobalFetch<W>> bw{};
     bw.seek(st.p, fetch);
     decode_subsequence(st, bw, fetch, (rel + 1) * (W * 32), s_tab, sp, sink);
@@ -819,12 +888,12 @@ __global__ __launch_bounds__(256) void idct_kernel(JS js)
     // Geometry of the k-th data unit of an MCU, staged once: the job lives in global memory (batch
     // API), and indexing its small arrays per lane would be a chain of dependent L2 round trips.
     struct UnitDesc {
-        uint8_t* plane;
+        JG_GLOBAL uint8_t* plane;
         int pitch, size_x, size_y, h, v, dx, dy, qoff;
     };
     __shared__ UnitDesc s_desc[kMaxDuPerMcu];
 
-    const ScanJob& J     = js.get();
+    const JobView J(js.get());
     const IdctParams& ip = J.ip;
     const int du0        = blockIdx.x * kIdctDuPerWg;
     const int num_du     = ip.num_du;
@@ -837,7 +906,7 @@ __global__ __launch_bounds__(256) void idct_kernel(JS js)
         const int k  = threadIdx.x;
         const int sc = ip.du_comp[k];
         UnitDesc d;
-        d.plane  = ip.plane[sc];
+        d.plane  = as_global(ip.plane[sc]);
         d.pitch  = ip.pitch[sc];
         d.size_x = ip.size_x[sc];
         d.size_y = ip.size_y[sc];
@@ -870,7 +939,7 @@ __global__ __launch_bounds__(256) void idct_kernel(JS js)
     for (int it = 0; it < kIdctIters; ++it) {
         const int du = du0 + it * kIdctDuPerBlock + dl;
         uint2_t e{0u, 0u};
-        if (du < num_du) e = J.du_tab[du];
+        if (du < num_du) e = ld_global(J.du_tab + du);
         tcnt[it] = e.y < 64u ? e.y : 64u;
         toff[it] = static_cast<uint32_t>(e.x < limit ? e.x : limit);
     }
@@ -935,9 +1004,9 @@ __global__ __launch_bounds__(256) void idct_kernel(JS js)
                 const int x0 = (mx * d.h + d.dx) * 8;
                 const int y  = (my * d.v + d.dy) * 8 + r2;
                 if (y < d.size_y && x0 < d.size_x) {
-                    uint8_t* row = d.plane + static_cast<size_t>(y) * d.pitch + x0;
+                    JG_GLOBAL uint8_t* row = d.plane + static_cast<size_t>(y) * d.pitch + x0;
                     if (x0 + 8 <= d.size_x && (reinterpret_cast<uintptr_t>(row) & 7) == 0) {
-                        *reinterpret_cast<uint2*>(row) = w;
+                        st_global(reinterpret_cast<JG_GLOBAL uint2*>(row), w);
                     } else {
 #pragma unroll
                         for (int i = 0; i < 8; ++i) {
