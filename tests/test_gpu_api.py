@@ -277,6 +277,25 @@ def test_corrupt_entropy_data_is_memory_safe(torch_cuda):
             assert np.array_equal(planes[c].cpu().numpy(), ref.planes[c]), name
 
 
+def test_extreme_geometry(torch_cuda):
+    """The largest dimensions a JPEG frame header can carry, in both orientations, with partial MCUs at the
+    far edge, restart intervals that do not divide the MCU count, and a 1-pixel-wide column: planes
+    bit-exact vs the oracle."""
+    import jpeggpu_amd
+    from oracle import oracle
+    from tools import jpegsynth
+
+    S420, S444 = ((2, 2), (1, 1), (1, 1)), ((1, 1),) * 3
+    for w, h, ss, kw in ((65535, 17, S420, dict(restart_interval=1000)), (17, 65535, S420, dict(restart_interval=7)),
+                         (1, 4099, S444, {}), (40000, 9, ((4, 1), (1, 1), (1, 1)), dict(optimize=True))):
+        data = jpegsynth.encode(w, h, ss, seed=w + h, noise=10, **kw)
+        ref = oracle.decode(data)
+        planes, info = jpeggpu_amd.decode_to_planes(data)
+        assert (info.sizes_x[0], info.sizes_y[0]) == (w, h)
+        for c in range(ref.ncomp):
+            assert np.array_equal(planes[c].cpu().numpy(), ref.planes[c]), (w, h, c)
+
+
 @pytest.mark.parametrize("cfg", [2, 4, 5])
 def test_baseline_configs_full_size(torch_cuda, cfg):
     """BASELINE.json configs 2, 4 (39 MP, three non-interleaved scans) and 5 (4 components, 4+4
