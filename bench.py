@@ -49,6 +49,9 @@ def parse_args():
                     help="subsequence size of the single-image latency probe (64 B: shorter serial chain)")
     ap.add_argument("--cpu-seconds", type=float, default=12.0, help="budget of the CPU baseline sample")
     ap.add_argument("--no-cpu", action="store_true")
+    ap.add_argument("--e2e-rounds", type=int, default=6,
+                    help="rounds of the PCIe-inclusive measurement (parse + transfer + decode from pinned host memory); 0 = skip")
+    ap.add_argument("--host-threads", type=int, default=6, help="threads of jpeggpu_ext_parse_headers in that measurement")
     return ap.parse_args()
 
 
@@ -156,6 +159,43 @@ def cpu_baseline(args, data):
     except Exception:  # Pillow is optional on the box
         pass
     return out
+
+
+def pcie_inclusive(args, torch, jp, slots, groups, nstreams):
+    """End to end from pinned host memory, never `value`: per group of the batch, parse the headers on a pool
+    of host threads (jpeggpu_ext_parse_headers), enqueue the two H2D copies of every image and one batched
+    decode on the group's stream, and go on to the next group while that runs. Images/s over `--e2e-rounds`
+    rounds of the whole batch."""
+    pinned = []
+    for s in slots:
+        t = torch.empty(len(s.data), dtype=torch.uint8).pin_memory()
+        t.numpy()[:] = memoryview(s.data)
+        pinned.append(t)
+    per_group = [list(range(g, len(slots), nstreams)) for g in range(nstreams)]
+    copied = [torch.cuda.Event() for _ in groups]
+
+    def one_round():
+        for g, (bt, scratch, st, _) in enumerate(groups):
+            copied[g].synchronize()  # the group's previous copies have executed: its decoders' pinned tables are free again
+            idx = per_group[g]
+            jp.parse_headers([slots[i].dec for i in idx], [pinned[i] for i in idx], num_threads=args.host_threads)
+            for i in idx:
+                slots[i].dec.transfer(slots[i].base, slots[i].tmp_size, st.cuda_stream)
+            copied[g].record(st)
+            bt.decode(scratch.data_ptr(), st.cuda_stream)
+
+    one_round()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(args.e2e_rounds):
+        one_round()
+    torch.cuda.synchronize()
+    dt = time.perf_counter() - t0
+    nbytes = sum(len(s.data) for s in slots)
+    return {"value": args.e2e_rounds * len(slots) / dt, "unit": "images/s", "host_threads": args.host_threads,
+            "rounds": args.e2e_rounds, "h2d_GBs": args.e2e_rounds * sum(s.layout.transferred_bytes for s in slots) / dt / 1e9,
+            "file_bytes_per_image": nbytes // len(slots),
+            "protocol": "pinned host JPEGs -> parse_headers (thread pool) -> transfer -> decode_batch, %d groups in flight" % nstreams}
 
 
 def main():
@@ -361,6 +401,8 @@ def main():
                            "p50_host_enqueue": statistics.median(lat_enqueue),
                            "iters": len(lat), "images_per_s_single_stream": 1e3 / statistics.fmean(lat)},
         }
+        if args.mode == "batch" and args.e2e_rounds > 0:
+            out["pcie_inclusive"] = pcie_inclusive(args, torch, jp, slots, groups, nstreams)
         if not args.no_cpu:
             out["cpu_baseline"] = cpu_baseline(args, slots[0].data)
     if rank == 0:
