@@ -943,16 +943,23 @@ __global__ __launch_bounds__(256) void idct_kernel(JS js)
         tcnt[it] = e.y < 64u ? e.y : 64u;
         toff[it] = static_cast<uint32_t>(e.x < limit ? e.x : limit);
     }
-    uint32_t n0 = r < tcnt[0] ? J.sym[toff[0] + r] : 0u;
-    uint32_t n1 = r + 8 < tcnt[0] ? J.sym[toff[0] + r + 8] : 0u;
+#ifndef JG_IDCT_PREFETCH
+#define JG_IDCT_PREFETCH 4
+#endif
+    constexpr int kAhead = JG_IDCT_PREFETCH; // entries per lane fetched one iteration ahead (8 lanes: kAhead * 8 per unit)
+    uint32_t nx[kAhead];
+#pragma unroll
+    for (int k = 0; k < kAhead; ++k) nx[k] = r + 8 * k < tcnt[0] ? J.sym[toff[0] + r + 8 * k] : 0u;
 
 #pragma unroll
     for (int it = 0; it < kIdctIters; ++it) {
         const int du  = du0 + it * kIdctDuPerBlock + dl;
-        const uint32_t e0 = n0, e1 = n1;
+        uint32_t ex[kAhead];
+#pragma unroll
+        for (int k = 0; k < kAhead; ++k) ex[k] = nx[k];
         if (it + 1 < kIdctIters) { // next iteration's first entries are in flight while this one computes
-            n0 = r < tcnt[it + 1] ? J.sym[toff[it + 1] + r] : 0u;
-            n1 = r + 8 < tcnt[it + 1] ? J.sym[toff[it + 1] + r + 8] : 0u;
+#pragma unroll
+            for (int k = 0; k < kAhead; ++k) nx[k] = r + 8 * k < tcnt[it + 1] ? J.sym[toff[it + 1] + r + 8 * k] : 0u;
         }
         // The 8 lanes of a data unit sit in one wave and LDS executes a wave's instructions in order,
         // so the phases below need no workgroup barrier among themselves; only the pixel re-mapping
@@ -968,9 +975,10 @@ __global__ __launch_bounds__(256) void idct_kernel(JS js)
             blk[e & 0xFFu]   = static_cast<int16_t>(c * static_cast<int>(e >> 8));
         };
         const uint32_t cnt = tcnt[it];
-        if (r < cnt) put(e0);
-        if (r + 8 < cnt) put(e1);
-        for (uint32_t i = r + 16; i < cnt; i += 8) put(J.sym[toff[it] + i]); // dense units only
+#pragma unroll
+        for (int k = 0; k < kAhead; ++k)
+            if (r + 8 * k < cnt) put(ex[k]);
+        for (uint32_t i = r + 8 * kAhead; i < cnt; i += 8) put(J.sym[toff[it] + i]); // dense units only
         __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
         int v[8];
         unpack8(*reinterpret_cast<const uint4*>(blk + r * 8), v); // column r
