@@ -232,7 +232,12 @@ __global__ __launch_bounds__(256) void destuff_kernel(JS js)
 /// refill later -- a select right behind the load would wait for it. The lanes of a wave walk
 /// neighbouring subsequences at about the same pace, so their refills share 128-byte lines and hit L1;
 /// nothing is staged in LDS, which keeps eight workgroups of the sync kernel on a CU.
-template <int W>
+/// kExact = false (state-only passes): no clamp into the segment and no zeros behind its end. A lane never
+/// commits a symbol that uses a bit past `end_bit` <= the segment's end, and whether a symbol does is
+/// decided by the bits before it (prefix code), so what lies behind the end cannot change p, c, z, n or the
+/// DC sums. The window reads at most word (end_bit / 32) + 3, i.e. the first words of the following
+/// subsequence slot, which the buffer always has (jg_decoder.cpp rounds it up to whole tiles past S).
+template <int W, bool kExact = true>
 struct GlobalFetch {
     static constexpr int kLog2W = W == 8 ? 3 : W == 16 ? 4 : 5;
     JG_GLOBAL const uint32_t* scan32; // the scan's destuffed buffer (tiled): the same for every lane (scalar base address)
@@ -240,11 +245,12 @@ struct GlobalFetch {
     int seg_words;
     __device__ __forceinline__ uint32_t raw(int w) const
     {
-        return scan32[tiled_word(static_cast<uint32_t>(seg_word0 + min(w, seg_words - 1)), kLog2W)];
+        const int lw = seg_word0 + (kExact ? min(w, seg_words - 1) : w);
+        return scan32[tiled_word(static_cast<uint32_t>(lw), kLog2W)];
     }
     __device__ __forceinline__ uint32_t cook(uint32_t v, int w) const
     {
-        return w < seg_words ? __builtin_bswap32(v) : 0u;
+        return !kExact || w < seg_words ? __builtin_bswap32(v) : 0u;
     }
 };
 
@@ -307,8 +313,8 @@ __global__ __launch_bounds__(T) void huff_sync_intra(JS js)
     const int sub       = img_first + t;
     const bool active   = sub >= 0 && t < img_end;
     LaneState st{};
-    BitWindow<GlobalFetch<W>> bw{};
-    GlobalFetch<W> fetch{reinterpret_cast<JG_GLOBAL const uint32_t*>(J.destuffed), 0, 1};
+    BitWindow<GlobalFetch<W, false>> bw{};
+    GlobalFetch<W, false> fetch{reinterpret_cast<JG_GLOBAL const uint32_t*>(J.destuffed), 0, 1};
     Segment seg{0, 0};
     int rel = 0;
     if (active) {
@@ -488,12 +494,12 @@ __global__ __launch_bounds__(TL) void huff_sync_tail(JS js)
                 const Segment seg = ld_global(J.segments + J.seg_idx[j - 1]);
                 const int lim     = seg.subseq_offset + seg.subseq_count;
                 if (j < lim) {
-                    GlobalFetch<W> fetch{scan32, seg.subseq_offset * W, seg.subseq_count * W};
+                    GlobalFetch<W, false> fetch{scan32, seg.subseq_offset * W, seg.subseq_count * W};
                     LaneState st{};
                     st.p = p;
                     st.c = cz & 0xFF;
                     st.z = cz >> 8;
-                    BitWindow<GlobalFetch<W>> bw{};
+                    BitWindow<GlobalFetch<W, false>> bw{};
                     bw.seek(st.p, fetch);
                     decode_subsequence(st, bw, fetch, (j - seg.subseq_offset + 1) * (W * 32), s_tab, sp, sink);
                     p        = st.p;
