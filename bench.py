@@ -43,6 +43,8 @@ def parse_args():
     ap.add_argument("--unique", type=int, default=2, help="distinct synthetic images per rank (seeded)")
     ap.add_argument("--workload", default="cfg2", choices=["cfg2", "photo"])
     ap.add_argument("--subseq-bytes", type=int, default=0, help="0 = library default")
+    ap.add_argument("--sync-iters", type=int, default=0,
+                    help="flow iterations inside the sequence kernel in batch mode (0 = library default, 1)")
     ap.add_argument("--gather", action="store_true", help="RCCL gather of the decoded planes to rank 0 each step")
     ap.add_argument("--latency-iters", type=int, default=50)
     ap.add_argument("--latency-subseq-bytes", type=int, default=64,
@@ -260,6 +262,8 @@ def main():
             bt = jp.Batch(nscans)
             scratch = torch.empty(bt.scratch_size, dtype=torch.uint8, device=device)
             bt.set_items([(s.dec, s.ptrs, s.pitches, s.base, s.tmp_size) for s in mine])
+            if args.sync_iters > 0:
+                bt.set_sync_iterations(args.sync_iters)
             groups.append((bt, scratch, streams[g], len(mine)))
         groups[0][0].set_profiling(True)
     else:
