@@ -11,9 +11,9 @@
 //
 // Everything is integer / bit-serial: no MFMA. Every kernel takes a job source: one ScanJob by
 // value (drop-in API) or an array indexed by blockIdx.y (batch API: one launch per stage for many
-// images, which is what fills 256 CUs). The bitstream slice of a workgroup is staged through LDS with
-// coalesced 4-byte global loads into a padded [word][subsequence] layout so that the 64 lanes of a
-// wave, each walking its own subsequence, hit 64 different banks.
+// images, which is what fills 256 CUs). The destuffed bitstream is kept in tiles of 32 subsequences,
+// word-major (jg_defs.h), so that the 64 lanes of a wave, each walking its own subsequence, share cache
+// lines; nothing but the Huffman tables and a small write-combining ring lives in LDS.
 #include "jg_huff_core.h"
 #include "jg_kernels.hpp"
 
@@ -732,7 +732,7 @@ struct WriteLds {
 /// tails); it gives the index of every data unit the lane starts, and the same look-back gives the
 /// DC predictors. Lanes SEQ..T-1 have no subsequence here (the sequence is SEQ long); they only help
 /// with the scans. The bitstream is read straight from the destuffed buffer, one refill ahead (as in
-/// huff_sync_tail): every word is used once, and without a 33 KB image five workgroups fit on a CU.
+/// huff_sync_tail); LDS holds the ring and the tables: five workgroups per CU.
 template <int W, class JS>
 __global__ __launch_bounds__(T) void huff_write(JS js)
 {
