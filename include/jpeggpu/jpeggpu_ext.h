@@ -25,7 +25,7 @@
 extern "C" {
 #endif
 
-/* 32, 64 or 128. Takes effect at the next jpeggpu_decoder_parse_header. Default 128 (the reference's
+/* 32, 64, 128 or 256. Takes effect at the next jpeggpu_decoder_parse_header. Default 128 (the reference's
  * value) unless the environment variable JPEGGPU_SUBSEQ_BYTES overrides it at startup. */
 enum jpeggpu_status jpeggpu_ext_set_subsequence_bytes(jpeggpu_decoder_t decoder, int subseq_bytes);
 

@@ -239,7 +239,8 @@ __global__ __launch_bounds__(256) void destuff_kernel(JS js)
 /// subsequence slot, which the buffer always has (jg_decoder.cpp rounds it up to whole tiles past S).
 template <int W, bool kExact = true>
 struct GlobalFetch {
-    static constexpr int kLog2W = W == 8 ? 3 : W == 16 ? 4 : 5;
+    static constexpr int kLog2W = W == 8 ? 3 : W == 16 ? 4 : W == 32 ? 5 : 6;
+    static_assert((1 << kLog2W) == W, "subsequence words must be 8, 16, 32 or 64");
     JG_GLOBAL const uint32_t* scan32; // the scan's destuffed buffer (tiled): the same for every lane (scalar base address)
     int seg_word0;          // first (linear) word of the lane's segment
     int seg_words;
@@ -1208,6 +1209,7 @@ hipError_t launch_any(Stage stage, const JS& js, const JobExtent& e, int grid_y,
         case 8: return launch_huff<8, JS>(stage, js, e, grid_y, stream);
         case 16: return launch_huff<16, JS>(stage, js, e, grid_y, stream);
         case 32: return launch_huff<32, JS>(stage, js, e, grid_y, stream);
+        case 64: return launch_huff<64, JS>(stage, js, e, grid_y, stream);
         }
         return hipErrorInvalidValue;
     default: return hipErrorInvalidValue;
@@ -1216,7 +1218,7 @@ hipError_t launch_any(Stage stage, const JS& js, const JobExtent& e, int grid_y,
 
 } // namespace
 
-bool subseq_bytes_supported(int b) { return b == 32 || b == 64 || b == 128; }
+bool subseq_bytes_supported(int b) { return b == 32 || b == 64 || b == 128 || b == 256; }
 
 void extend(JobExtent& e, const ScanJob& job)
 {

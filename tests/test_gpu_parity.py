@@ -27,7 +27,7 @@ def _decode_gpu(data, subseq_bytes=None):
     return [p.cpu().numpy() for p in planes], info
 
 
-@pytest.mark.parametrize("subseq_bytes", [128, 64, 32])
+@pytest.mark.parametrize("subseq_bytes", [256, 128, 64, 32])
 def test_matrix_planes_bit_exact(gpu_lib, torch_cuda, inputs, subseq_bytes):
     from oracle import oracle
 
