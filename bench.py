@@ -43,6 +43,8 @@ def parse_args():
     ap.add_argument("--unique", type=int, default=2, help="distinct synthetic images per rank (seeded)")
     ap.add_argument("--workload", default="cfg2", choices=["cfg2", "photo"])
     ap.add_argument("--subseq-bytes", type=int, default=0, help="0 = library default")
+    ap.add_argument("--overlap", type=int, default=1,
+                    help="jpeggpu_ext_batch_set_overlap: concurrent parts per batch call (for --streams 1)")
     ap.add_argument("--sync-iters", type=int, default=0,
                     help="flow iterations inside the sequence kernel in batch mode (0 = library default, 1)")
     ap.add_argument("--gather", action="store_true", help="RCCL gather of the decoded planes to rank 0 each step")
@@ -264,6 +266,7 @@ def main():
             bt.set_items([(s.dec, s.ptrs, s.pitches, s.base, s.tmp_size) for s in mine])
             if args.sync_iters > 0:
                 bt.set_sync_iterations(args.sync_iters)
+            bt.set_overlap(args.overlap)
             groups.append((bt, scratch, streams[g], len(mine)))
         groups[0][0].set_profiling(True)
     else:

@@ -114,6 +114,12 @@ enum jpeggpu_status jpeggpu_ext_batch_destroy(jpeggpu_batch_t batch);
  * subsequence its coefficient count and DC sums) before unfinished flows are handed to the low-footprint,
  * re-packing tail kernel (default 1; the drop-in decode keeps all flows in the sequence kernel). */
 enum jpeggpu_status jpeggpu_ext_batch_set_sync_iterations(jpeggpu_batch_t batch, int iterations);
+/* For a caller that uses ONE stream: split every batch into `parts` (1..4, default 1) that run concurrently,
+ * part 0 on the caller's stream and the others on internal streams forked from and joined back into it with
+ * events, so that one part's latency-bound synchronisation tail overlaps another part's decode (+15 % with
+ * 2-3 parts). A caller that already keeps several streams busy gains nothing. Stage timing then reports
+ * part 0. */
+enum jpeggpu_status jpeggpu_ext_batch_set_overlap(jpeggpu_batch_t batch, int parts);
 /* Stage timing of batched decodes; same contract as jpeggpu_ext_set_profiling / _get_stage_ms. */
 enum jpeggpu_status jpeggpu_ext_batch_set_profiling(jpeggpu_batch_t batch, int enable);
 enum jpeggpu_status jpeggpu_ext_batch_get_stage_ms(jpeggpu_batch_t batch, float* ms /* [JPEGGPU_EXT_NUM_STAGES] */);

@@ -116,6 +116,7 @@ def lib():
     L.jpeggpu_ext_batch_destroy.argtypes = [C.c_void_p]
     L.jpeggpu_ext_batch_set_profiling.argtypes = [C.c_void_p, C.c_int]
     L.jpeggpu_ext_batch_set_sync_iterations.argtypes = [C.c_void_p, C.c_int]
+    L.jpeggpu_ext_batch_set_overlap.argtypes = [C.c_void_p, C.c_int]
     L.jpeggpu_ext_batch_get_stage_ms.argtypes = [C.c_void_p, C.POINTER(C.c_float)]
     L.jpeggpu_ext_upsample_planes.argtypes = [
         C.POINTER(ImgInfo), C.POINTER(Img), C.POINTER(Img), C.c_int, C.c_int, C.c_void_p]
@@ -240,6 +241,9 @@ class Batch:
     def decode(self, d_scratch: int, stream: int = 0):
         _check(lib().jpeggpu_ext_decode_batch(self._h, self._items, len(self._items), d_scratch, self.scratch_size, stream),
                "jpeggpu_ext_decode_batch")
+
+    def set_overlap(self, parts: int):
+        _check(lib().jpeggpu_ext_batch_set_overlap(self._h, parts), "jpeggpu_ext_batch_set_overlap")
 
     def set_sync_iterations(self, n: int):
         _check(lib().jpeggpu_ext_batch_set_sync_iterations(self._h, n), "jpeggpu_ext_batch_set_sync_iterations")

@@ -572,6 +572,13 @@ struct jpeggpu_batch {
     bool in_use[kRing]          = {};
     int next                    = 0;
     int sync_iters              = 1; // throughput: speculate + verify in the sequence kernel, the rest in the tail kernel
+    // A caller with ONE stream leaves the GPU idle while the latency-bound tail kernel runs (a fifth of a
+    // batch's time). With overlap > 1 the jobs are split into that many parts, part 0 on the caller's
+    // stream and the others on internal streams forked from and joined back into it with events.
+    static constexpr int kMaxOverlap = 4;
+    int overlap                 = 1;
+    hipStream_t aux[kMaxOverlap - 1] = {};
+    hipEvent_t joined[kMaxOverlap - 1] = {};
     std::vector<jg::ScanJob> jobs;
     // optional stage timing, same contract as the decoder's
     bool profiling = false;
@@ -604,6 +611,13 @@ enum jpeggpu_status jpeggpu_ext_batch_create(jpeggpu_batch_t* batch, int max_sca
 enum jpeggpu_status jpeggpu_ext_batch_destroy(jpeggpu_batch_t batch)
 {
     if (!batch) return JPEGGPU_INVALID_ARGUMENT;
+    for (int w = 0; w < jpeggpu_batch::kMaxOverlap - 1; ++w) {
+        if (batch->aux[w]) {
+            (void)hipStreamSynchronize(batch->aux[w]);
+            (void)hipStreamDestroy(batch->aux[w]);
+        }
+        if (batch->joined[w]) (void)hipEventDestroy(batch->joined[w]);
+    }
     for (int r = 0; r < jpeggpu_batch::kRing; ++r) {
         if (batch->staging[r]) (void)hipHostFree(batch->staging[r]);
         if (batch->copied[r]) (void)hipEventDestroy(batch->copied[r]);
@@ -661,13 +675,49 @@ enum jpeggpu_status jpeggpu_ext_decode_batch(
         }
         (void)hipEventRecord((*ev)[0], stream);
     }
-    for (int stage = 0; stage < jg::kNumStages; ++stage) {
-        if (jg::launch_stage_batch(static_cast<jg::Stage>(stage), d_jobs, n, extent, stream) != hipSuccess) {
-            (void)hipGetLastError();
-            return JPEGGPU_INTERNAL_ERROR;
+    // parts of the job array: contiguous, at least 8 jobs each
+    int ways = batch->overlap;
+    while (ways > 1 && n / ways < 8) --ways;
+    int begin[jpeggpu_batch::kMaxOverlap + 1];
+    jg::JobExtent part_extent[jpeggpu_batch::kMaxOverlap];
+    hipStream_t part_stream[jpeggpu_batch::kMaxOverlap];
+    for (int w = 0; w <= ways; ++w) begin[w] = static_cast<int>(static_cast<long long>(n) * w / ways);
+    part_stream[0] = stream;
+    for (int w = 1; w < ways; ++w) {
+        if (!batch->aux[w - 1]) {
+            if (hipStreamCreateWithFlags(&batch->aux[w - 1], hipStreamNonBlocking) != hipSuccess ||
+                hipEventCreateWithFlags(&batch->joined[w - 1], hipEventDisableTiming) != hipSuccess)
+                return JPEGGPU_INTERNAL_ERROR;
         }
-        if (ev) (void)hipEventRecord((*ev)[stage + 1], stream);
+        part_stream[w] = batch->aux[w - 1];
+        if (hipStreamWaitEvent(part_stream[w], batch->copied[r], 0) != hipSuccess) return JPEGGPU_INTERNAL_ERROR; // fork
     }
+    for (int w = 0; w < ways; ++w) {
+        part_extent[w] = jg::JobExtent{};
+        for (int j = begin[w]; j < begin[w + 1]; ++j) jg::extend(part_extent[w], batch->jobs[j]);
+    }
+    for (int stage = 0; stage < jg::kNumStages; ++stage) {
+        for (int w = 0; w < ways; ++w) {
+            if (jg::launch_stage_batch(static_cast<jg::Stage>(stage), d_jobs + begin[w], begin[w + 1] - begin[w], part_extent[w],
+                                       part_stream[w]) != hipSuccess) {
+                (void)hipGetLastError();
+                return JPEGGPU_INTERNAL_ERROR;
+            }
+        }
+        if (ev) (void)hipEventRecord((*ev)[stage + 1], stream); // stage times are those of part 0
+    }
+    for (int w = 1; w < ways; ++w) { // join: the caller's stream completes when every part has
+        if (hipEventRecord(batch->joined[w - 1], part_stream[w]) != hipSuccess ||
+            hipStreamWaitEvent(stream, batch->joined[w - 1], 0) != hipSuccess)
+            return JPEGGPU_INTERNAL_ERROR;
+    }
+    return JPEGGPU_SUCCESS;
+}
+
+enum jpeggpu_status jpeggpu_ext_batch_set_overlap(jpeggpu_batch_t batch, int parts)
+{
+    if (!batch || parts < 1 || parts > jpeggpu_batch::kMaxOverlap) return JPEGGPU_INVALID_ARGUMENT;
+    batch->overlap = parts;
     return JPEGGPU_SUCCESS;
 }
 

@@ -193,6 +193,7 @@ def test_batch_decode_equals_single(torch_cuda):
     torch = torch_cuda
     m = cases.matrix()
     names = ["multi_seq_dri", "ni_420_dri", "four_comp_opt", "gray", "multi_seq_nodri", "odd_1x1px", "cfg4_small", "dri_1"]
+    names = names * 3 + list(m.keys())[:12]  # > 32 scans: enough for four concurrent parts (set_overlap)
     keep, entries, refs = [], [], []
     total_scans = 0
     for name in names:
@@ -209,6 +210,7 @@ def test_batch_decode_equals_single(torch_cuda):
     batch.set_items(entries)
     for rep, iters in enumerate([3, 1, 2, 256]):  # cap of the sequence kernel's lock-step loop (>= 1)
         batch.set_sync_iterations(iters)
+        batch.set_overlap(1 + rep)  # 1..4 concurrent parts on internal streams
         for _, _, planes in keep:
             for p in planes:
                 p.fill_(0xCD)
