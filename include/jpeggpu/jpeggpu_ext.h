@@ -50,9 +50,12 @@ struct jpeggpu_ext_scan_layout {
     size_t off_state_dc01;     /* uint32[num_subsequences]: wrapping 16-bit DC-difference sums of scan
                                   components 0 (low half) and 1 (high half) */
     size_t off_state_dc23;     /* same for scan components 2 and 3 */
-    size_t off_symbols;        /* uint32[num_subsequences * symbol_region_entries]: zig-zag position << 16 |
-                                  16-bit coefficient, one region per subsequence */
-    size_t off_du_table;       /* {uint32 first entry, uint32 count}[num_data_units], stream order */
+    size_t off_symbols;        /* uint32 entries: zig-zag position << 16 | 16-bit coefficient. Logically one region of
+                                  symbol_region_entries per subsequence; physically the regions of 64 consecutive
+                                  subsequences are interleaved in sectors of 8 entries: sector j of subsequence s
+                                  starts at entry ((s / 64) * (symbol_region_entries / 8) + j) * 512 + (s % 64) * 8 */
+    size_t off_du_table;       /* {uint32 physical index of the first entry, uint32 count}[num_data_units], stream
+                                  order; entry k of a unit: w = (first & 7) + k -> (first & ~7) + (w >> 3) * 512 + (w & 7) */
     int symbol_region_entries;
 };
 

@@ -102,6 +102,34 @@ struct uint2_t {
     uint32_t x, y;
 };
 
+/// Placement of the symbol stream in memory. Logically every subsequence has a region of
+/// sym_region_entries() entries; physically the regions of 64 consecutive subsequences are interleaved
+/// sector by sector (a sector = 8 entries = 32 bytes, the unit a lane flushes): sector j of subsequence s sits
+/// at entry ((s / 64) * R + j) * 512 + (s % 64) * 8, R = sectors per region. The 64 lanes of a wave flush
+/// together, so the four sectors of a 128-byte line come from four neighbouring lanes at the same time;
+/// with plain regions (2.3 KB apart) a line got its sectors from ONE lane over ~32 iterations and was
+/// evicted from L2 partially written in between (as for the bitstream: tiled_word above).
+constexpr uint32_t kSymTileSubseq = 64;
+constexpr uint32_t kSymSectorStride = kSymTileSubseq * 8; // entries between consecutive sectors of one region
+JG_HD inline uint32_t sym_region_base(uint32_t sub, uint32_t region_entries)
+{
+    return (sub / kSymTileSubseq) * (region_entries / 8u) * kSymSectorStride + (sub % kSymTileSubseq) * 8u;
+}
+/// Physical index of logical entry `e` of the region that starts at physical `base`.
+JG_HD inline uint32_t sym_at(uint32_t base, uint32_t e) { return base + (e >> 3) * kSymSectorStride + (e & 7u); }
+/// Physical index of the k-th entry after the entry at physical index `first` (same region).
+JG_HD inline uint32_t sym_advance(uint32_t first, uint32_t k)
+{
+    const uint32_t w = (first & 7u) + k;
+    return (first & ~7u) + (w >> 3) * kSymSectorStride + (w & 7u);
+}
+/// Entries of the whole stream buffer, with room for a 64-entry gather starting at any clamped index.
+JG_HD inline uint64_t sym_buffer_entries(uint32_t num_subseq, uint32_t region_entries)
+{
+    const uint64_t tiles = (static_cast<uint64_t>(num_subseq) + kSymTileSubseq - 1) / kSymTileSubseq;
+    return tiles * (region_entries / 8u) * kSymSectorStride + 16u * kSymSectorStride;
+}
+
 /// One restart segment of a scan inside the destuffed buffer (reference src/reader.hpp:38-43).
 struct Segment {
     int subseq_offset; // subsequences before this segment
@@ -206,10 +234,10 @@ struct ScanJob {
     int* tails_n;                // per-sequence aggregates used to place the write pass
     uint32_t* tails_dc01;
     uint32_t* tails_dc23;
-    uint32_t* sym;               // symbol stream: one region of `sym_region` entries per subsequence
-    uint2_t* du_tab;             // per data unit (stream order): {first entry, number of entries}
+    uint32_t* sym;               // symbol stream: one region of `sym_region` entries per subsequence, interleaved (above)
+    uint2_t* du_tab;             // per data unit (stream order): {physical index of the first entry, number of entries}
     uint32_t sym_region;         // entries per subsequence region
-    uint64_t sym_entries;        // total entries (num_subseq * sym_region)
+    uint64_t sym_entries;        // entries of the buffer (sym_buffer_entries)
     int num_chunks;
     int num_seq;
     ScanParams sp;

@@ -610,9 +610,10 @@ struct StreamSink {
     JG_GLOBAL uint32_t* sym;
     JG_GLOBAL uint2_t* du_tab;
     uint32_t* ring;     // &s_ring[lane]; slot k at ring[k * T]
-    uint32_t flushed;   // entries of this lane already in memory (region base + multiples of 8)
-    uint32_t emitted;   // entries produced so far (region base + count)
-    uint32_t cur_end;   // region end
+    uint32_t base;      // physical index of the region's first entry (jg_defs.h, sym_region_base)
+    uint32_t flushed;   // entries of this lane already in memory (a multiple of 8), region-relative like the next three
+    uint32_t emitted;   // entries produced so far
+    uint32_t cur_end;   // entries a region holds
     uint32_t du_off;
     int du_index;
     int du;       // next data unit this lane starts
@@ -656,7 +657,7 @@ struct StreamSink {
 #pragma unroll
         for (int k = 0; k < 4; ++k) {
             const uint32_t cnt = (pend_cnts >> (8 * k)) & 0xFFu;
-            if (k < pend_n) st_global(du_tab + pend_du + k, uint2_t{off, cnt});
+            if (k < pend_n) st_global(du_tab + pend_du + k, uint2_t{sym_at(base, off), cnt});
             off += cnt;
         }
         pend_n    = 0;
@@ -669,7 +670,8 @@ struct StreamSink {
         const uint32_t* r = ring + (flushed & (kStageEntries - 1)) * T; // no wrap inside a flush unit
 #pragma unroll
         for (int k = 0; k < kFlushEntries; ++k) e[k] = r[k * T];
-        JG_GLOBAL uint4* dst = reinterpret_cast<JG_GLOBAL uint4*>(sym + flushed);
+        static_assert(kFlushEntries == 8, "a flush is one sector of the interleaved stream");
+        JG_GLOBAL uint4* dst = reinterpret_cast<JG_GLOBAL uint4*>(sym + sym_at(base, flushed));
 #pragma unroll
         for (int k = 0; k < kFlushEntries / 4; ++k) st_global(dst + k, make_uint4(e[4 * k], e[4 * k + 1], e[4 * k + 2], e[4 * k + 3]));
         flushed += kFlushEntries;
@@ -811,10 +813,11 @@ __global__ __launch_bounds__(T) void huff_write(JS js)
     const int seg_mcus1 = min(seg_mcus0 + sp.mcus_per_segment, sp.total_mcus); // Appendix B-5 clamp
     sink.du             = seg_mcus0 * sp.du_per_mcu + ((nprefix + 63) >> 6);
     sink.quota          = seg_mcus1 * sp.du_per_mcu;
-    sink.flushed        = static_cast<uint32_t>(sub) * J.sym_region; // region base, a multiple of 8
-    sink.emitted        = sink.flushed;
-    sink.cur_end        = sink.flushed + J.sym_region;
-    sink.du_off         = sink.flushed;
+    sink.base           = sym_region_base(static_cast<uint32_t>(sub), J.sym_region);
+    sink.flushed        = 0;
+    sink.emitted        = 0;
+    sink.cur_end        = J.sym_region;
+    sink.du_off         = 0;
     sink.du_index       = 0;
     sink.ticks          = 0;
     sink.pend_off       = 0;
@@ -976,7 +979,7 @@ __global__ __launch_bounds__(256) void idct_kernel(JS js)
     // table entries of all iterations (independent loads, one latency); a table entry that was never
     // written (corrupt stream) must not lead out of the buffer
     uint32_t toff[kIdctIters], tcnt[kIdctIters];
-    const uint64_t limit = J.sym_entries - 64;
+    const uint64_t limit = J.sym_entries - 10 * kSymSectorStride; // a 64-entry gather from here stays inside
 #pragma unroll
     for (int it = 0; it < kIdctIters; ++it) {
         const int du = du0 + it * kIdctDuPerBlock + dl;
@@ -990,8 +993,12 @@ __global__ __launch_bounds__(256) void idct_kernel(JS js)
 #endif
     constexpr int kAhead = JG_IDCT_PREFETCH; // entries per lane fetched one iteration ahead (8 lanes: kAhead * 8 per unit)
     uint32_t nx[kAhead];
+    {
+        // entries r, r + 8, r + 16, ...: eight entries further is the same slot of the next sector
+        const uint32_t p0 = sym_advance(toff[0], r);
 #pragma unroll
-    for (int k = 0; k < kAhead; ++k) nx[k] = r + 8 * k < tcnt[0] ? J.sym[toff[0] + r + 8 * k] : 0u;
+        for (int k = 0; k < kAhead; ++k) nx[k] = r + 8 * k < tcnt[0] ? J.sym[p0 + k * kSymSectorStride] : 0u;
+    }
 
 #pragma unroll
     for (int it = 0; it < kIdctIters; ++it) {
@@ -1000,8 +1007,9 @@ __global__ __launch_bounds__(256) void idct_kernel(JS js)
 #pragma unroll
         for (int k = 0; k < kAhead; ++k) ex[k] = nx[k];
         if (it + 1 < kIdctIters) { // next iteration's first entries are in flight while this one computes
+            const uint32_t p0 = sym_advance(toff[it + 1], r);
 #pragma unroll
-            for (int k = 0; k < kAhead; ++k) nx[k] = r + 8 * k < tcnt[it + 1] ? J.sym[toff[it + 1] + r + 8 * k] : 0u;
+            for (int k = 0; k < kAhead; ++k) nx[k] = r + 8 * k < tcnt[it + 1] ? J.sym[p0 + k * kSymSectorStride] : 0u;
         }
         // The 8 lanes of a data unit sit in one wave and LDS executes a wave's instructions in order,
         // so the phases below need no workgroup barrier among themselves; only the pixel re-mapping
@@ -1020,7 +1028,7 @@ __global__ __launch_bounds__(256) void idct_kernel(JS js)
 #pragma unroll
         for (int k = 0; k < kAhead; ++k)
             if (r + 8 * k < cnt) put(ex[k]);
-        for (uint32_t i = r + 8 * kAhead; i < cnt; i += 8) put(J.sym[toff[it] + i]); // dense units only
+        for (uint32_t i = r + 8 * kAhead; i < cnt; i += 8) put(J.sym[sym_advance(toff[it], i)]); // dense units only
         __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
         int v[8];
         unpack8(*reinterpret_cast<const uint4*>(blk + r * 8), v); // column r
