@@ -615,15 +615,15 @@ struct StreamSink {
     uint32_t emitted;   // entries produced so far
     uint32_t cur_end;   // entries a region holds
     uint32_t du_off;
-    int du_index;
     int du;       // next data unit this lane starts
     int quota;    // first data unit past the segment
     int ticks;
     // Data-unit records wait here until the next common flush point: a lane's units are consecutive in the
-    // table and contiguous in its region, so first index + first offset + packed counts describe up to four.
-    uint32_t pend_off;
+    // table and contiguous in its region, so the table index and the offset of the first waiting one, plus
+    // packed entry counts, describe up to four.
+    uint32_t rec_off;   // region-relative offset of the first unit whose record has not been stored
+    int rec_du;         // its index in the data-unit table
     uint32_t pend_cnts;
-    int pend_du;
     int pend_n;
     bool started; // false while the first symbols finish the predecessor's data unit
     __device__ __forceinline__ bool full() const { return du >= quota; }
@@ -632,8 +632,7 @@ struct StreamSink {
     /// unit, and anything past the region on a corrupt stream go to the spare ring row.
     __device__ __forceinline__ void symbol(bool is_dc, bool nonzero, uint32_t entry, bool unit_end)
     {
-        du_off   = is_dc ? emitted : du_off;
-        du_index = is_dc ? du : du_index;
+        du_off = is_dc ? emitted : du_off;
         du += is_dc ? 1 : 0;
         started             = started || is_dc;
         const bool emit     = started && (is_dc || nonzero) && emitted < cur_end;
@@ -645,21 +644,18 @@ struct StreamSink {
         // and leaves with the next common flush. A unit takes at least two symbols, so at most four finish
         // between two flush points.
         const bool done = unit_end && started;
-        const bool head = done && pend_n == 0;
-        pend_off        = head ? du_off : pend_off;
-        pend_du         = head ? du_index : pend_du;
         pend_cnts |= done ? (emitted - du_off) << (8 * pend_n) : 0u;
         pend_n += done ? 1 : 0;
     }
     __device__ __forceinline__ void flush_units()
     {
-        uint32_t off = pend_off;
 #pragma unroll
         for (int k = 0; k < 4; ++k) {
             const uint32_t cnt = (pend_cnts >> (8 * k)) & 0xFFu;
-            if (k < pend_n) st_global(du_tab + pend_du + k, uint2_t{sym_at(base, off), cnt});
-            off += cnt;
+            if (k < pend_n) st_global(du_tab + rec_du + k, uint2_t{sym_at(base, rec_off), cnt});
+            rec_off += cnt; // zero beyond pend_n
         }
+        rec_du += pend_n;
         pend_n    = 0;
         pend_cnts = 0;
     }
@@ -818,11 +814,10 @@ __global__ __launch_bounds__(T) void huff_write(JS js)
     sink.emitted        = 0;
     sink.cur_end        = J.sym_region;
     sink.du_off         = 0;
-    sink.du_index       = 0;
     sink.ticks          = 0;
-    sink.pend_off       = 0;
+    sink.rec_off        = 0;
+    sink.rec_du         = sink.du; // the first unit this lane starts
     sink.pend_cnts      = 0;
-    sink.pend_du        = 0;
     sink.pend_n         = 0;
 
     LaneState st{};
