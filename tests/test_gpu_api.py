@@ -279,6 +279,17 @@ def test_corrupt_entropy_data_is_memory_safe(torch_cuda):
             assert np.array_equal(planes[c].cpu().numpy(), ref.planes[c]), name
 
 
+def test_random_soak_short(torch_cuda, monkeypatch):
+    """A few seconds of tools/soak_gpu.py: random geometry / sampling / restart interval / quality / tables,
+    all subsequence sizes, random sync iterations and overlap parts, batch and drop-in calls, bit-exact."""
+    import sys
+
+    from tools import soak_gpu
+
+    monkeypatch.setattr(sys, "argv", ["soak_gpu.py", "8", "20261004"])
+    soak_gpu.main()
+
+
 def test_extreme_geometry(torch_cuda):
     """The largest dimensions a JPEG frame header can carry, in both orientations, with partial MCUs at the
     far edge, restart intervals that do not divide the MCU count, and a 1-pixel-wide column: planes

@@ -1,0 +1,83 @@
+#!/usr/bin/env python3
+"""Randomised soak of the GPU path against the oracle: many synthetic images of random geometry, sampling,
+restart interval, quality, table kind and scan structure, decoded through the batch API (random subsequence
+size, sync iterations and overlap parts) and through the drop-in call; every plane must be bit-exact.
+  python tools/soak_gpu.py [seconds] [seed]"""
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+
+
+def main():
+    import torch
+
+    import jpeggpu_amd as jp
+    from oracle import oracle
+    from tools import jpegsynth
+
+    budget = float(sys.argv[1]) if len(sys.argv) > 1 else 60.0
+    rng = np.random.default_rng(int(sys.argv[2]) if len(sys.argv) > 2 else 1)
+    samplings = [((1, 1),) * 3, ((2, 2), (1, 1), (1, 1)), ((2, 1), (1, 1), (1, 1)), ((1, 2), (1, 1), (1, 1)),
+                 ((4, 1), (1, 1), (1, 1)), ((1, 1),), ((2, 1), (1, 1), (1, 1), (2, 1)), ((2, 2), (1, 1))]
+    t0, rounds, images = time.time(), 0, 0
+    while time.time() - t0 < budget:
+        sb = int(rng.choice([32, 64, 128, 256]))
+        items, refs, keep = [], [], []
+        total_scans = 0
+        for _ in range(int(rng.integers(4, 24))):
+            ss = samplings[int(rng.integers(len(samplings)))]
+            w, h = int(rng.integers(1, 900)), int(rng.integers(1, 700))
+            if rng.random() < 0.1:
+                w, h = int(rng.integers(1500, 4100)), int(rng.integers(1000, 3100))
+            mcus = ((w + 8 * max(s[0] for s in ss) - 1) // (8 * max(s[0] for s in ss)))
+            dri = int(rng.choice([0, 0, 1, 2, 7, mcus, mcus * 3 + 1, 100]))
+            data = jpegsynth.encode(w, h, ss, interleaved=bool(rng.random() < 0.8) or len(ss) == 1,
+                                    restart_interval=dri, quality=int(rng.choice([3, 30, 60, 85, 95, 100])),
+                                    optimize=bool(rng.random() < 0.5), noise=int(rng.integers(0, 40)),
+                                    fill_bytes=int(rng.choice([0, 0, 0, 1, 3])), seed=int(rng.integers(1 << 30)),
+                                    qmax=int(rng.choice([0, 0, 255, 65535])))
+            ref = oracle.decode(data)
+            dec = jp.Decoder(sb)
+            info = dec.parse_header(data)
+            n = dec.get_buffer_size()
+            tmp = torch.empty(n + 256, dtype=torch.uint8, device="cuda:0")
+            base = (tmp.data_ptr() + 255) // 256 * 256
+            planes = [torch.full((info.sizes_y[c], info.sizes_x[c]), 0xCD, dtype=torch.uint8, device="cuda:0")
+                      for c in range(info.num_components)]
+            dec.transfer(base, n, 0)
+            total_scans += dec.layout().num_scans
+            items.append((dec, [p.data_ptr() for p in planes], [p.stride(0) for p in planes], base, n))
+            keep.append((dec, tmp, planes, data))
+            refs.append(ref)
+        batch = jp.Batch(total_scans)
+        scratch = torch.empty(batch.scratch_size, dtype=torch.uint8, device="cuda:0")
+        batch.set_items(items)
+        batch.set_sync_iterations(int(rng.choice([1, 1, 2, 5, 256])))
+        batch.set_overlap(int(rng.integers(1, 5)))
+        batch.decode(scratch.data_ptr(), 0)
+        torch.cuda.synchronize()
+        for (dec, tmp, planes, data), ref in zip(keep, refs):
+            for c in range(ref.ncomp):
+                assert np.array_equal(planes[c].cpu().numpy(), ref.planes[c]), ("batch", rounds, len(data), c)
+                planes[c].fill_(0x3C)
+        # the same images through the drop-in call
+        for (dec, tmp, planes, data), ref, it in zip(keep, refs, items):
+            dec.decode(it[1], it[2], it[3], it[4], 0)
+        torch.cuda.synchronize()
+        for (dec, tmp, planes, data), ref in zip(keep, refs):
+            for c in range(ref.ncomp):
+                assert np.array_equal(planes[c].cpu().numpy(), ref.planes[c]), ("single", rounds, len(data), c)
+            dec.cleanup()
+        batch.destroy()
+        rounds += 1
+        images += len(keep)
+    print("soak ok: %d rounds, %d images, %.0f s" % (rounds, images, time.time() - t0))
+
+
+if __name__ == "__main__":
+    main()
