@@ -279,6 +279,56 @@ def test_corrupt_entropy_data_is_memory_safe(torch_cuda):
             assert np.array_equal(planes[c].cpu().numpy(), ref.planes[c]), name
 
 
+def test_corrupt_headers_are_memory_safe(torch_cuda):
+    """Random damage in the header segments (tables, frame and scan headers, restart interval): whatever the
+    parser still accepts must decode inside its buffers. Absurd geometries are skipped (allocation size)."""
+    import jpeggpu_amd
+
+    torch = torch_cuda
+    rng = np.random.default_rng(4321)
+    m = cases.matrix()
+    accepted = 0
+    for name in ("ss_2x2", "dri_7", "four_comp_opt", "ni_420_dri", "opt_tables_420", "q16_tables"):
+        good = m[name]
+        sos = good.index(b"\xff\xda")
+        for trial in range(40):
+            bad = bytearray(good)
+            for pos in rng.integers(2, sos + 12, size=int(rng.integers(1, 4))):
+                bad[pos] = int(rng.integers(0, 256)) if rng.random() < 0.5 else bad[pos] ^ (1 << int(rng.integers(8)))
+            dec = jpeggpu_amd.Decoder(int(rng.choice([32, 64, 128, 256])))
+            try:
+                info = dec.parse_header(bytes(bad))
+                n = dec.get_buffer_size()
+            except jpeggpu_amd.JpegGpuError:
+                dec.cleanup()
+                continue
+            px = sum(info.sizes_x[c] * info.sizes_y[c] for c in range(info.num_components))
+            if px > 48 << 20 or n > 1 << 30:
+                dec.cleanup()
+                continue
+            accepted += 1
+            guard = 4096
+            tmp = torch.full((n + 256 + 2 * guard,), 0x5A, dtype=torch.uint8, device="cuda:0")
+            base = (tmp.data_ptr() + guard + 255) // 256 * 256
+            planes = [torch.full((info.sizes_y[c] + 2, info.sizes_x[c]), 0x5A, dtype=torch.uint8, device="cuda:0")
+                      for c in range(info.num_components)]
+            dec.transfer(base, n, 0)
+            dec.decode([p[1:-1].data_ptr() for p in planes], [p.stride(0) for p in planes], base, n, 0)
+            torch.cuda.synchronize()
+            off = base - tmp.data_ptr()
+            assert (tmp[:off] == 0x5A).all() and (tmp[off + n:] == 0x5A).all(), (name, trial, "tmp overrun")
+            for p in planes:
+                assert (p[0] == 0x5A).all() and (p[-1] == 0x5A).all(), (name, trial, "plane overrun")
+            dec.cleanup()
+    assert accepted > 20  # the test must actually exercise the device
+    planes, _ = jpeggpu_amd.decode_to_planes(m["ss_2x2"])
+    from oracle import oracle
+
+    ref = oracle.decode(m["ss_2x2"])
+    for c in range(ref.ncomp):
+        assert np.array_equal(planes[c].cpu().numpy(), ref.planes[c])
+
+
 def test_random_soak_short(torch_cuda, monkeypatch):
     """A few seconds of tools/soak_gpu.py: random geometry / sampling / restart interval / quality / tables,
     all subsequence sizes, random sync iterations and overlap parts, batch and drop-in calls, bit-exact."""
