@@ -139,7 +139,7 @@ enum jpeggpu_status jpeggpu_ext_upsample_planes(
 
 /* jpeggpu_decoder_parse_header for many images on `num_threads` host threads (the calling thread is one
  * of them). A 12 MP scan costs ~0.2 ms of one core to walk (reference src/reader.cpp:447-489 does the
- * same walk inside its timed loop), so a serving loop at 14 k images/s needs about three cores of it.
+ * same walk inside its timed loop), so a serving loop at 18 k images/s needs about four cores of it.
  * Every decoder must appear once. statuses[i] receives the result of item i; the return value is the
  * first failure, or JPEGGPU_SUCCESS. */
 struct jpeggpu_ext_parse_item {
