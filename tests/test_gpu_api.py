@@ -329,6 +329,33 @@ def test_corrupt_headers_are_memory_safe(torch_cuda):
         assert np.array_equal(planes[c].cpu().numpy(), ref.planes[c])
 
 
+def test_c_caller_decodes_the_reference_photo(torch_cuda, tmp_path):
+    """examples/decode_file.c (plain C, HIP runtime, no Python in the process) on the reference's photo: the
+    planes it writes carry the committed hashes of the oracle's planes (tests/golden/photo_pins.json)."""
+    import hashlib
+    import json
+    import os
+    import subprocess
+
+    from tests.test_host_api import _build_c_example
+
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    exe = str(tmp_path / "decode_file")
+    _build_c_example(exe)
+    prefix = str(tmp_path / "photo")
+    out = subprocess.run([exe, os.path.join(root, "tests", "golden", "IMG_6510.JPG"), prefix, "--rgb"],
+                         stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=120)
+    assert out.returncode == 0, out.stderr.decode()
+    assert b"3 components, 4032x3024" in out.stdout
+    pins = json.load(open(os.path.join(root, "tests", "golden", "photo_pins.json")))
+    for c, (w, h) in enumerate(((4032, 3024), (2016, 1512), (2016, 1512))):
+        raw = open("%s_%d.pgm" % (prefix, c), "rb").read()
+        header = b"P5\n%d %d\n255\n" % (w, h)
+        assert raw.startswith(header) and len(raw) == len(header) + w * h
+        assert hashlib.sha256(raw[len(header):]).hexdigest() == pins["components"][c]["sha256_oracle_plane"], c
+    assert os.path.getsize(prefix + ".ppm") == len(b"P6\n4032 3024\n255\n") + 4032 * 3024 * 3
+
+
 def test_random_soak_short(torch_cuda, monkeypatch):
     """A few seconds of tools/soak_gpu.py: random geometry / sampling / restart interval / quality / tables,
     all subsequence sizes, random sync iterations and overlap parts, batch and drop-in calls, bit-exact."""

@@ -218,6 +218,23 @@ def test_parallel_parse_equals_serial(L):
         d.cleanup()
 
 
+def _build_c_example(out):
+    import subprocess
+
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    lib_dir = os.path.join(root, "jpeggpu_amd", "lib")
+    subprocess.check_call(["gcc", "-std=c11", "-Wall", "-Wextra", "-Werror", "-D__HIP_PLATFORM_AMD__", "-I/opt/rocm/include",
+                           "-I" + os.path.join(root, "include"), os.path.join(root, "examples", "decode_file.c"),
+                           "-L" + lib_dir, "-ljpeggpu", "-L/opt/rocm/lib", "-lamdhip64",
+                           "-Wl,-rpath," + lib_dir, "-Wl,-rpath,/opt/rocm/lib", "-o", out])
+
+
+def test_c_caller_compiles_and_links(L, tmp_path):
+    """The public headers are C (not only C++ / ctypes): examples/decode_file.c, the reference example tool's
+    call sequence, builds as C11 with -Wall -Wextra -Werror against the library."""
+    _build_c_example(str(tmp_path / "decode_file"))
+
+
 def test_fails_loudly_without_a_device(L):
     """No CPU fallback: without a HIP device transfer/decode return an error, never fake planes."""
     import torch
