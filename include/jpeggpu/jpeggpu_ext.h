@@ -11,6 +11,7 @@
  *                                      benchmark/benchmark_jpeggpu.hpp:96-102)
  *   jpeggpu_ext_decode_batch           one launch per stage for many images; the
  *                                      reference decodes one image per call sequence
+ *   jpeggpu_ext_set_device_scan        restart-marker scan and segment / work-list construction on the device
  *   jpeggpu_ext_parse_headers          parse_header of many images on a pool of host threads
  *   jpeggpu_ext_planes_to_rgbi         chroma replication + YCbCr -> interleaved RGB8 (util/util.h:62-104)
  *   jpeggpu_ext_upsample_planes        nearest-neighbour chroma replication on the device, the integer
@@ -57,6 +58,11 @@ struct jpeggpu_ext_scan_layout {
     size_t off_du_table;       /* {uint32 physical index of the first entry, uint32 count}[num_data_units], stream
                                   order; entry k of a unit: w = (first & 7) + k -> (first & ~7) + (w >> 3) * 512 + (w & 7) */
     int symbol_region_entries;
+    /* jpeggpu_ext_set_device_scan: num_subsequences / num_segments / num_chunks above are then capacities from the
+     * header; the real counts are uint32 words 1.. at off_device_status (status, subsequences, segments, chunks,
+     * tail parts), and off_segments / off_chunks point at tables the device has built. */
+    int device_scan;
+    size_t off_device_status;
 };
 
 struct jpeggpu_ext_layout {
@@ -71,6 +77,19 @@ struct jpeggpu_ext_layout {
 };
 
 enum jpeggpu_status jpeggpu_ext_get_layout(jpeggpu_decoder_t decoder, struct jpeggpu_ext_layout* layout);
+
+/* Device-side front end (enable != 0, before parse_header): for a file whose first scan holds every component,
+ * parse_header stops at the scan header instead of walking the entropy-coded bytes for restart markers (the
+ * reference does that walk on the host inside its timed loop, src/reader.cpp:447-489; here it is 0.2 of the
+ * 0.87 ms of a 12 MP image). transfer then copies everything up to the end of the file, and decode first runs two
+ * kernels that find the markers and build the segment table and the destuff work list in device memory. What the
+ * host walk reports at parse time -- a scan without terminating marker, a restart-marker count that does not
+ * match the geometry, restart markers denser than 15 per 4 KiB -- is then known only on the device: decode leaves
+ * the planes untouched, and jpeggpu_ext_get_device_status (which synchronises `stream`) returns the status.
+ * Other files (several scans) take the host walk as before. Batches take host-walked images only. */
+enum jpeggpu_status jpeggpu_ext_set_device_scan(jpeggpu_decoder_t decoder, int enable);
+enum jpeggpu_status jpeggpu_ext_get_device_status(
+    jpeggpu_decoder_t decoder, const void* d_tmp, jpeggpu_stream_t stream, enum jpeggpu_status* status);
 
 /* Stage timing: when enabled, jpeggpu_decoder_decode records HIP events on the caller's stream
  * between its launches; after the stream has been synchronised jpeggpu_ext_get_stage_ms returns the

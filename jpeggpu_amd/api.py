@@ -48,6 +48,7 @@ class ExtScanLayout(C.Structure):
         ("off_segment_index", C.c_size_t), ("off_state_p", C.c_size_t), ("off_state_n", C.c_size_t),
         ("off_state_cz", C.c_size_t), ("off_state_dc01", C.c_size_t), ("off_state_dc23", C.c_size_t),
         ("off_symbols", C.c_size_t), ("off_du_table", C.c_size_t), ("symbol_region_entries", C.c_int),
+        ("device_scan", C.c_int), ("off_device_status", C.c_size_t),
     ]
 
 
@@ -120,6 +121,8 @@ def lib():
     L.jpeggpu_ext_batch_get_stage_ms.argtypes = [C.c_void_p, C.POINTER(C.c_float)]
     L.jpeggpu_ext_upsample_planes.argtypes = [
         C.POINTER(ImgInfo), C.POINTER(Img), C.POINTER(Img), C.c_int, C.c_int, C.c_void_p]
+    L.jpeggpu_ext_set_device_scan.argtypes = [dec, C.c_int]
+    L.jpeggpu_ext_get_device_status.argtypes = [dec, C.c_void_p, C.c_void_p, C.POINTER(C.c_int)]
     L.jpeggpu_ext_parse_headers.argtypes = [C.POINTER(ParseItem), C.c_int, C.c_int, C.POINTER(C.c_int)]
     L.jpeggpu_ext_planes_to_rgbi.argtypes = [
         C.POINTER(ImgInfo), C.POINTER(Img), C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_void_p]
@@ -168,6 +171,14 @@ class Decoder:
             n = data.nbytes if hasattr(data, "nbytes") else data.numel()
         _check(lib().jpeggpu_decoder_parse_header(self._h, C.byref(info), ptr, n), "jpeggpu_decoder_parse_header")
         return info
+
+    def set_device_scan(self, on: bool = True):
+        _check(lib().jpeggpu_ext_set_device_scan(self._h, int(on)), "jpeggpu_ext_set_device_scan")
+
+    def device_status(self, d_tmp: int, stream: int = 0) -> Status:
+        st = C.c_int()
+        _check(lib().jpeggpu_ext_get_device_status(self._h, d_tmp, stream, C.byref(st)), "jpeggpu_ext_get_device_status")
+        return Status(st.value)
 
     def get_buffer_size(self) -> int:
         n = C.c_size_t()

@@ -7,8 +7,8 @@ ROOT = os.path.dirname(_HERE)
 CSRC = os.path.join(_HERE, "csrc")
 LIB_DIR = os.path.join(_HERE, "lib")
 LIB_PATH = os.path.join(LIB_DIR, "libjpeggpu.so")
-SOURCES = ["jg_kernels.hip", "jg_decoder.cpp", "jg_reader.cpp"]
-HEADERS = ["jg_defs.h", "jg_huff_core.h", "jg_kernels.hpp", "jg_reader.hpp"]
+SOURCES = ["jg_kernels.hip", "jg_front.hip", "jg_decoder.cpp", "jg_reader.cpp"]
+HEADERS = ["jg_defs.h", "jg_huff_core.h", "jg_kernels.hpp", "jg_front.hpp", "jg_reader.hpp"]
 
 
 def _stale() -> bool:

@@ -8,6 +8,7 @@
 //     ~10, and no post-EOI trailer; decoder.cpp:175-208);
 //   * coefficients stay in stream order; there are no per-component coefficient planes, no transpose
 //     pass and no DC pass (decoder.cpp:240-314).
+#include "jg_front.hpp"
 #include "jg_kernels.hpp"
 #include "jg_reader.hpp"
 
@@ -74,6 +75,11 @@ struct ScanPlan {
     size_t tails_n = 0, tails_dc01 = 0, tails_dc23 = 0, pending = 0, flow_list = 0;
     size_t sym = 0, du_tab = 0;
     int num_seq = 0;
+    // device-side front end (jg_front.hip): tables built on the device, scratch, the job and the status word
+    size_t d_segments = 0, d_chunks = 0, d_parts = 0;
+    size_t d_win_data = 0, d_win_nmark = 0, d_win_mark = 0, d_win_prefix = 0, d_mark_off = 0;
+    size_t d_mk_pos = 0, d_mk_g = 0, d_seg_cnt = 0, d_seg_nch = 0, d_job = 0, d_status = 0;
+    uint32_t num_windows = 0;
 };
 
 struct Plan {
@@ -95,6 +101,7 @@ struct Decoder {
     size_t data_size    = 0;
     int subseq_bytes    = 128;
     bool parsed         = false;
+    bool device_scan    = false; // jpeggpu_ext_set_device_scan
 
     std::vector<ScanJob> jobs; // scratch of the last decode
 
@@ -175,6 +182,29 @@ void Decoder::make_plan()
         o += align_up(static_cast<size_t>(sp.num_seq) * 4, 256);
         sp.tails_dc23 = o;
         o += align_up(static_cast<size_t>(sp.num_seq) * 4, 256);
+        if (sc.device_walk) {
+            const size_t E   = static_cast<size_t>(sc.expect_segments);
+            sp.num_windows   = static_cast<uint32_t>(align_up(p.bytes_len, kDestuffWin) / kDestuffWin);
+            const size_t Wn  = sp.num_windows;
+            const auto carve = [&](size_t& at, size_t bytes) {
+                at = o;
+                o += align_up(bytes, 256);
+            };
+            carve(sp.d_segments, E * sizeof(Segment));
+            carve(sp.d_chunks, static_cast<size_t>(sc.max_chunks) * sizeof(DestuffChunk));
+            carve(sp.d_parts, static_cast<size_t>(sc.max_tail_parts) * sizeof(int));
+            carve(sp.d_win_data, Wn * 4);
+            carve(sp.d_win_nmark, Wn * 4);
+            carve(sp.d_win_mark, Wn * kMaxWinMarkers * 12);
+            carve(sp.d_win_prefix, (Wn + 1) * 4);
+            carve(sp.d_mark_off, (Wn + 1) * 4);
+            carve(sp.d_mk_pos, E * 4);
+            carve(sp.d_mk_g, E * 4);
+            carve(sp.d_seg_cnt, (E + 1) * 4);
+            carve(sp.d_seg_nch, (E + 1) * 4);
+            carve(sp.d_job, sizeof(ScanJob));
+            carve(sp.d_status, 32);
+        }
     }
     for (int i = 0; i < s.num_scans; ++i) {
         p.scan[i].sym = o; // symbol stream: a fixed region per subsequence
@@ -223,7 +253,8 @@ bool Decoder::fill_blob()
             std::memcpy(blob.ptr + sp.blob_segments, sc.segments.data(), sc.segments.size() * sizeof(Segment));
         if (!sc.chunks.empty())
             std::memcpy(blob.ptr + sp.blob_chunks, sc.chunks.data(), sc.chunks.size() * sizeof(DestuffChunk));
-        std::memcpy(blob.ptr + sp.blob_parts, sc.tail_parts.data(), sc.tail_parts.size() * sizeof(int));
+        if (!sc.tail_parts.empty())
+            std::memcpy(blob.ptr + sp.blob_parts, sc.tail_parts.data(), sc.tail_parts.size() * sizeof(int));
     }
     return true;
 }
@@ -348,6 +379,17 @@ jpeggpu_status build_jobs(
         job.sym_entries = sym_buffer_entries(static_cast<uint32_t>(sc.num_subseq), job.sym_region);
         job.num_chunks = static_cast<int>(sc.chunks.size());
         job.num_seq    = pl.num_seq;
+        if (sc.device_walk) {
+            // tables built by jg_front.hip in device memory; the counts below are capacities (launch extents),
+            // the device writes the real ones into its copy of the job
+            job.chunks         = reinterpret_cast<const DestuffChunk*>(base + pl.d_chunks);
+            job.segments       = reinterpret_cast<const Segment*>(base + pl.d_segments);
+            job.tail_parts     = reinterpret_cast<const int*>(base + pl.d_parts);
+            job.num_chunks     = sc.max_chunks;
+            job.num_tail_parts = sc.max_tail_parts - 1;
+            job.max_tail_part  = s.restart_interval ? kTailPartSubseq : (1 << 30); // lanes of the tail kernel
+            sp.num_segments    = sc.expect_segments;
+        }
         jobs.push_back(job);
     }
     return JPEGGPU_SUCCESS;
@@ -362,6 +404,49 @@ jpeggpu_status do_decode(Decoder& d, jpeggpu_img* img, void* d_tmp, size_t tmp_s
     if (st != JPEGGPU_SUCCESS) return st;
     d.next_event_set();
     d.mark(-1, stream);
+    if (d.reader.s.scans[0].device_walk) {
+        // Device-side front end: the job lives in device memory, front_plan fills in its counts, and the
+        // stages run as a one-job batch with launch extents from the header's upper bounds.
+        const Scan& sc     = d.reader.s.scans[0];
+        const ScanPlan& pl = d.plan.scan[0];
+        uint8_t* base      = static_cast<uint8_t*>(d_tmp);
+        ScanJob* d_job     = reinterpret_cast<ScanJob*>(base + pl.d_job);
+        // pageable source: the runtime stages it before returning, d.jobs may change afterwards
+        JG_CHECK_HIP(hipMemcpyAsync(d_job, d.jobs.data(), sizeof(ScanJob), hipMemcpyHostToDevice, stream));
+        FrontParams P{};
+        P.bytes           = base + d.plan.off_bytes;
+        P.bytes_len       = static_cast<uint32_t>(d.plan.bytes_len);
+        P.scan_begin      = static_cast<uint32_t>(sc.begin - d.reader.s.xfer_begin);
+        P.num_windows     = pl.num_windows;
+        P.expect_segments = static_cast<uint32_t>(sc.expect_segments);
+        P.subseq_bytes    = static_cast<uint32_t>(d.subseq_bytes);
+        P.max_subseq      = static_cast<uint32_t>(sc.num_subseq);
+        P.max_chunks      = static_cast<uint32_t>(sc.max_chunks);
+        P.max_parts       = static_cast<uint32_t>(sc.max_tail_parts);
+        const auto u32    = [&](size_t off) { return reinterpret_cast<uint32_t*>(base + off); };
+        P.win_data   = u32(pl.d_win_data);
+        P.win_nmark  = u32(pl.d_win_nmark);
+        P.win_mark   = u32(pl.d_win_mark);
+        P.win_prefix = u32(pl.d_win_prefix);
+        P.mark_off   = u32(pl.d_mark_off);
+        P.mk_pos     = u32(pl.d_mk_pos);
+        P.mk_g       = u32(pl.d_mk_g);
+        P.seg_cnt    = u32(pl.d_seg_cnt);
+        P.seg_nch    = u32(pl.d_seg_nch);
+        P.segments   = reinterpret_cast<Segment*>(base + pl.d_segments);
+        P.chunks     = reinterpret_cast<DestuffChunk*>(base + pl.d_chunks);
+        P.tail_parts = reinterpret_cast<int*>(base + pl.d_parts);
+        P.job        = d_job;
+        P.status     = u32(pl.d_status);
+        JG_CHECK_HIP(launch_front(P, stream));
+        JobExtent extent;
+        extend(extent, d.jobs[0]);
+        for (int stage = 0; stage < kNumStages; ++stage) {
+            JG_CHECK_HIP(launch_stage_batch(static_cast<Stage>(stage), d_job, 1, extent, stream));
+            d.mark(stage, stream);
+        }
+        return JPEGGPU_SUCCESS;
+    }
     for (size_t i = 0; i < d.jobs.size(); ++i) {
         const ScanJob& job = d.jobs[i];
         d.logger.log(
@@ -429,7 +514,7 @@ enum jpeggpu_status jpeggpu_decoder_parse_header(
     d.parsed   = false;
     jpeggpu_status st;
     try {
-        st = d.reader.parse(data, size, d.subseq_bytes, d.logger);
+        st = d.reader.parse(data, size, d.subseq_bytes, d.logger, d.device_scan);
     } catch (const std::bad_alloc&) {
         return JPEGGPU_OUT_OF_HOST_MEMORY;
     }
@@ -560,7 +645,39 @@ enum jpeggpu_status jpeggpu_ext_get_layout(jpeggpu_decoder_t decoder, struct jpe
         o.off_symbols        = pl.sym;
         o.off_du_table       = pl.du_tab;
         o.symbol_region_entries = static_cast<int>(jg::sym_region_entries(d.subseq_bytes));
+        o.device_scan           = sc.device_walk ? 1 : 0;
+        if (sc.device_walk) {
+            o.num_segments      = sc.expect_segments;
+            o.num_chunks        = sc.max_chunks;
+            o.off_segments      = pl.d_segments;
+            o.off_chunks        = pl.d_chunks;
+            o.off_device_status = pl.d_status;
+        }
     }
+    return JPEGGPU_SUCCESS;
+}
+
+enum jpeggpu_status jpeggpu_ext_set_device_scan(jpeggpu_decoder_t decoder, int enable)
+{
+    if (!decoder) return JPEGGPU_INVALID_ARGUMENT;
+    decoder->d.device_scan = enable != 0;
+    return JPEGGPU_SUCCESS;
+}
+
+enum jpeggpu_status jpeggpu_ext_get_device_status(
+    jpeggpu_decoder_t decoder, const void* d_tmp, jpeggpu_stream_t stream, enum jpeggpu_status* status)
+{
+    if (!decoder || !d_tmp || !status) return JPEGGPU_INVALID_ARGUMENT;
+    Decoder& d = decoder->d;
+    if (!d.parsed) return JPEGGPU_INVALID_ARGUMENT;
+    *status = JPEGGPU_SUCCESS;
+    if (!d.reader.s.scans[0].device_walk) return JPEGGPU_SUCCESS; // the host walk has already judged the stream
+    uint32_t word = 0;
+    const uint8_t* src = static_cast<const uint8_t*>(d_tmp) + d.plan.scan[0].d_status;
+    if (hipMemcpyAsync(&word, src, sizeof(word), hipMemcpyDeviceToHost, stream) != hipSuccess ||
+        hipStreamSynchronize(stream) != hipSuccess)
+        return JPEGGPU_INTERNAL_ERROR;
+    *status = word <= JPEGGPU_INCOMPLETE_BITSTREAM ? static_cast<jpeggpu_status>(word) : JPEGGPU_INTERNAL_ERROR;
     return JPEGGPU_SUCCESS;
 }
 
@@ -645,6 +762,7 @@ enum jpeggpu_status jpeggpu_ext_decode_batch(
         if (!it.decoder || !it.img) return JPEGGPU_INVALID_ARGUMENT;
         if (i == 0) subseq_bytes = it.decoder->d.subseq_bytes;
         if (it.decoder->d.subseq_bytes != subseq_bytes) return JPEGGPU_INVALID_ARGUMENT; // one kernel variant per launch
+        if (it.decoder->d.parsed && it.decoder->d.reader.s.scans[0].device_walk) return JPEGGPU_NOT_SUPPORTED; // host-walked images only
         const jpeggpu_status st = build_jobs(it.decoder->d, it.img, it.d_tmp, it.tmp_size, batch->sync_iters, batch->jobs);
         if (st != JPEGGPU_SUCCESS) return st;
     }

@@ -1,0 +1,313 @@
+// jg_front.hip -- device-side front end: finds the restart markers and the end of the
+// entropy-coded segment on the GPU and builds, in device memory, what the host walk of jg_reader.cpp builds
+// for the default path (reference src/reader.cpp:447-489): the segment table, the destuff work list with
+// destination offsets, the tail-kernel parts and the counts the Huffman kernels read from their job.
+//
+//   front_windows   one workgroup per 4 KiB window: data bytes (the byte rule of decode_destuff.cu:37-44),
+//                   marker records {position, code, data bytes of the window before it}
+//   front_plan      one workgroup: prefix sums over windows and segments, validation, table building
+//
+// Only single-scan files take this path (everything behind the first scan's data would otherwise have to be
+// parsed by the host anyway); sizes are upper bounds computed from the header.
+#include "jg_front.hpp"
+
+#include <hip/hip_runtime.h>
+
+namespace jg {
+
+namespace {
+
+#define JG_GLOBAL __attribute__((address_space(1)))
+template <class T>
+__device__ __forceinline__ JG_GLOBAL T* as_global(T* p)
+{
+    return (JG_GLOBAL T*)p;
+}
+
+__device__ __forceinline__ int lane_id() { return threadIdx.x & 63; }
+
+__device__ __forceinline__ uint32_t wave_incl_scan(uint32_t v)
+{
+#pragma unroll
+    for (int d = 1; d < 64; d <<= 1) {
+        const uint32_t o = __shfl_up(v, d);
+        if (lane_id() >= d) v += o;
+    }
+    return v;
+}
+
+/// Exclusive prefix of `v` over the workgroup's NW waves; `total` gets the workgroup sum.
+template <int NW>
+__device__ __forceinline__ uint32_t block_excl_scan(uint32_t v, uint32_t* s_wave, uint32_t& total)
+{
+    const uint32_t incl = wave_incl_scan(v);
+    __syncthreads(); // previous use of s_wave is over
+    if (lane_id() == 63) s_wave[threadIdx.x >> 6] = incl;
+    __syncthreads();
+    uint32_t off = 0;
+    total        = 0;
+#pragma unroll
+    for (int k = 0; k < NW; ++k) {
+        const uint32_t w = s_wave[k];
+        off += k < static_cast<int>(threadIdx.x >> 6) ? w : 0u;
+        total += w;
+    }
+    return off + incl - v;
+}
+
+__global__ __launch_bounds__(256) void front_windows(FrontParams P)
+{
+    __shared__ uint32_t s_wave[4];
+    JG_GLOBAL const uint8_t* src = as_global(P.bytes);
+    const uint32_t w             = blockIdx.x;
+    const uint32_t t             = threadIdx.x;
+    const uint32_t gpos          = w * kDestuffWin + t * 16;
+
+    uint32_t word[4];
+    {
+        typedef uint32_t V4 __attribute__((ext_vector_type(4)));
+        const V4 v = *reinterpret_cast<JG_GLOBAL const V4*>(src + gpos); // the buffer has a spare window behind bytes_len
+        word[0] = v[0]; word[1] = v[1]; word[2] = v[2]; word[3] = v[3];
+    }
+    uint32_t prev       = gpos > 0 ? src[gpos - 1] : 0u;
+    const uint32_t next = src[gpos + 16];
+
+    uint32_t data_mask = 0, mark_mask = 0;
+#pragma unroll
+    for (int i = 0; i < 16; ++i) {
+        const uint32_t b   = (word[i >> 2] >> (8 * (i & 3))) & 0xFFu;
+        const uint32_t nx  = i < 15 ? (word[(i + 1) >> 2] >> (8 * ((i + 1) & 3))) & 0xFFu : next;
+        const uint32_t pos = gpos + i;
+        const bool in      = pos >= P.scan_begin && pos < P.bytes_len;
+        const bool data    = (prev == 0xFFu && b == 0u) || (prev != 0xFFu && b != 0xFFu);
+        // the FF right in front of a marker code: not followed by a stuffed zero, not by a fill byte, and
+        // the code itself inside the buffer
+        const bool mark = b == 0xFFu && nx != 0u && nx != 0xFFu && pos + 1 < P.bytes_len;
+        if (in && data) data_mask |= 1u << i;
+        if (in && mark) mark_mask |= 1u << i;
+        prev = b;
+    }
+    uint32_t total_data = 0, total_mark = 0;
+    const uint32_t data_before = block_excl_scan<4>(__popc(data_mask), s_wave, total_data);
+    const uint32_t mark_before = block_excl_scan<4>(__popc(mark_mask), s_wave, total_mark);
+    uint32_t m = mark_mask;
+    uint32_t ord = mark_before;
+    while (m) {
+        const int i = __ffs(m) - 1;
+        m &= m - 1;
+        if (ord < kMaxWinMarkers) {
+            const uint32_t nx  = i < 15 ? (word[(i + 1) >> 2] >> (8 * ((i + 1) & 3))) & 0xFFu : next;
+            JG_GLOBAL uint32_t* rec = as_global(P.win_mark) + (static_cast<size_t>(w) * kMaxWinMarkers + ord) * 3;
+            rec[0] = gpos + i;
+            rec[1] = nx;
+            rec[2] = data_before + __popc(data_mask & ((1u << i) - 1u));
+        }
+        ++ord;
+    }
+    if (t == 0) {
+        as_global(P.win_data)[w]  = total_data;
+        as_global(P.win_nmark)[w] = total_mark;
+    }
+}
+
+constexpr int PL = 1024; // lanes of the planning workgroup
+
+/// Exclusive prefix of in[0..n) into out[0..n], out[n] = total (in and out may be the same array).
+__device__ uint32_t scan_array(JG_GLOBAL const uint32_t* in, JG_GLOBAL uint32_t* out, uint32_t n, uint32_t* s_wave)
+{
+    uint32_t carry = 0;
+    for (uint32_t base = 0; base < n; base += PL) {
+        const uint32_t i = base + threadIdx.x;
+        const uint32_t v = i < n ? in[i] : 0u;
+        uint32_t total;
+        const uint32_t ex = block_excl_scan<PL / 64>(v, s_wave, total);
+        if (i < n) out[i] = carry + ex;
+        carry += total;
+    }
+    __syncthreads();
+    if (threadIdx.x == 0) out[n] = carry;
+    __syncthreads();
+    return carry;
+}
+
+__global__ __launch_bounds__(PL) void front_plan(FrontParams P)
+{
+    __shared__ uint32_t s_wave[PL / 64];
+    __shared__ uint32_t s_first_other, s_first_overflow;
+    const uint32_t tid = threadIdx.x;
+    const uint32_t Wn = P.num_windows, E = P.expect_segments, SB = P.subseq_bytes;
+    JG_GLOBAL const uint32_t* win_data  = as_global(P.win_data);
+    JG_GLOBAL const uint32_t* win_nmark = as_global(P.win_nmark);
+    JG_GLOBAL const uint32_t* win_mark  = as_global(P.win_mark);
+    JG_GLOBAL uint32_t* WP   = as_global(P.win_prefix);
+    JG_GLOBAL uint32_t* MO   = as_global(P.mark_off);
+    JG_GLOBAL uint32_t* mkp  = as_global(P.mk_pos);
+    JG_GLOBAL uint32_t* mkg  = as_global(P.mk_g);
+    JG_GLOBAL uint32_t* cnt  = as_global(P.seg_cnt);
+    JG_GLOBAL uint32_t* nch  = as_global(P.seg_nch);
+    JG_GLOBAL Segment* segs  = as_global(P.segments);
+    JG_GLOBAL uint32_t* stat = as_global(P.status);
+
+    if (tid == 0) {
+        s_first_other    = 0xFFFFFFFFu;
+        s_first_overflow = 0xFFFFFFFFu;
+    }
+    scan_array(win_data, WP, Wn, s_wave);
+    scan_array(win_nmark, MO, Wn, s_wave);
+
+    // the first marker that is not RSTn ends the scan; a window with more markers than it can record
+    // makes everything from there on unknown
+    for (uint32_t w = tid; w < Wn; w += PL) {
+        const uint32_t n = win_nmark[w];
+        if (n > kMaxWinMarkers) atomicMin(&s_first_overflow, MO[w] + kMaxWinMarkers);
+        for (uint32_t k = 0; k < n && k < kMaxWinMarkers; ++k) {
+            const uint32_t code = win_mark[(static_cast<size_t>(w) * kMaxWinMarkers + k) * 3 + 1];
+            if (code < 0xD0u || code > 0xD7u) {
+                atomicMin(&s_first_other, MO[w] + k);
+                break;
+            }
+        }
+    }
+    __syncthreads();
+    const uint32_t T = s_first_other; // ordinal of the terminating marker
+    uint32_t status  = 0;             // JPEGGPU_SUCCESS
+    if (s_first_overflow < T) status = 4;       // JPEGGPU_NOT_SUPPORTED: restart markers too dense for this path
+    else if (T == 0xFFFFFFFFu) status = 6;      // JPEGGPU_INCOMPLETE_BITSTREAM: no terminating marker
+    else if (T + 1 != E) status = 2;            // JPEGGPU_INVALID_JPEG: restart segments do not match the geometry
+    if (status != 0) {
+        // nothing downstream may run on tables that were not built
+        if (tid == 0) {
+            JG_GLOBAL ScanJob* job = as_global(P.job);
+            job->num_chunks        = 0;
+            job->num_seq           = 0;
+            job->num_tail_parts    = 0;
+            job->sp.num_subseq     = 0;
+            job->sp.num_segments   = 0;
+            job->ip.num_du         = 0;
+            stat[0] = status;
+            stat[1] = 0;
+            stat[2] = 0;
+            stat[3] = 0;
+            stat[4] = 0;
+        }
+        return;
+    }
+
+    // the markers that matter, in stream order: RST_0 .. RST_{E-2}, terminator
+    for (uint32_t w = tid; w < Wn; w += PL) {
+        const uint32_t n = min(win_nmark[w], static_cast<uint32_t>(kMaxWinMarkers));
+        for (uint32_t k = 0; k < n; ++k) {
+            const uint32_t g = MO[w] + k;
+            if (g > T) break;
+            JG_GLOBAL const uint32_t* rec = win_mark + (static_cast<size_t>(w) * kMaxWinMarkers + k) * 3;
+            mkp[g] = rec[0];
+            mkg[g] = WP[w] + rec[2]; // data bytes of the scan in front of the marker
+        }
+    }
+    __syncthreads();
+
+    // segments: data bytes -> subsequences
+    bool too_big = false;
+    for (uint32_t k = tid; k < E; k += PL) {
+        const uint32_t g0 = k == 0 ? 0u : mkg[k - 1];
+        const uint32_t d  = mkg[k] - g0;
+        too_big |= d > (1u << 27); // bit positions are 32-bit
+        cnt[k] = (d + SB - 1) / SB;
+        // chunks: the 4 KiB windows the segment's bytes touch (at least one, which carries the padding)
+        const uint32_t b0 = k == 0 ? P.scan_begin : mkp[k - 1] + 2;
+        const uint32_t b1 = mkp[k];
+        const uint32_t last = b1 > b0 ? b1 - 1 : b0;
+        nch[k] = last / kDestuffWin - b0 / kDestuffWin + 1;
+    }
+    if (__syncthreads_or(too_big)) {
+        if (tid == 0) {
+            JG_GLOBAL ScanJob* job = as_global(P.job);
+            job->num_chunks = job->num_seq = job->num_tail_parts = 0;
+            job->sp.num_subseq = job->sp.num_segments = 0;
+            job->ip.num_du = 0;
+            stat[0] = 4;
+            stat[1] = stat[2] = stat[3] = stat[4] = 0;
+        }
+        return;
+    }
+    // subsequence offsets in place (cnt becomes the exclusive prefix; counts are recovered as differences)
+    const uint32_t S = scan_array(cnt, cnt, E, s_wave);
+    const uint32_t C = scan_array(nch, nch, E, s_wave);
+    for (uint32_t k = tid; k < E; k += PL) {
+        Segment sg;
+        sg.subseq_offset = static_cast<int>(cnt[k]);
+        sg.subseq_count  = static_cast<int>(cnt[k + 1] - cnt[k]);
+        typedef uint32_t V2 __attribute__((ext_vector_type(2)));
+        *reinterpret_cast<JG_GLOBAL V2*>(segs + k) = __builtin_bit_cast(V2, sg);
+    }
+    // destuff work list: chunk c belongs to the segment whose chunk range holds it
+    for (uint32_t c = tid; c < C && c < P.max_chunks; c += PL) {
+        uint32_t lo = 0, hi = E; // last k with nch[k] <= c
+        while (hi - lo > 1) {
+            const uint32_t mid = (lo + hi) / 2;
+            if (nch[mid] <= c) lo = mid;
+            else hi = mid;
+        }
+        const uint32_t k  = lo;
+        const uint32_t b0 = k == 0 ? P.scan_begin : mkp[k - 1] + 2;
+        const uint32_t b1 = mkp[k];
+        const uint32_t g0 = k == 0 ? 0u : mkg[k - 1];
+        const uint32_t w  = b0 / kDestuffWin + (c - nch[k]);
+        const uint32_t wb = w * kDestuffWin;
+        DestuffChunk ck;
+        ck.win_off  = wb;
+        ck.begin    = b0 > wb ? b0 : wb;
+        ck.end      = b1 < wb + kDestuffWin ? b1 : wb + kDestuffWin;
+        if (ck.end < ck.begin) ck.end = ck.begin;
+        ck.dst_off  = cnt[k] * SB + (ck.begin == b0 ? 0u : WP[w] - g0);
+        ck.pad_end  = c + 1 == nch[k + 1] ? cnt[k + 1] * SB : 0u;
+        ck.seg      = static_cast<int32_t>(k);
+        ck.first    = c == nch[k] ? 1u : 0u;
+        ck.reserved = 0;
+        typedef uint32_t V8 __attribute__((ext_vector_type(8)));
+        *reinterpret_cast<JG_GLOBAL V8*>(as_global(P.chunks) + c) = __builtin_bit_cast(V8, ck);
+    }
+    // tail-kernel parts: cut in front of a segment whose first subsequence opens a new block of
+    // kTailPartSubseq subsequences
+    JG_GLOBAL int* parts = as_global(P.tail_parts);
+    uint32_t nparts      = 0;
+    for (uint32_t base = 0; base < E; base += PL) {
+        const uint32_t k = base + tid;
+        bool cut         = false;
+        if (k < E) cut = k == 0 || cnt[k] / kTailPartSubseq != cnt[k - 1] / kTailPartSubseq;
+        uint32_t total;
+        const uint32_t r = block_excl_scan<PL / 64>(cut ? 1u : 0u, s_wave, total);
+        if (cut && nparts + r < P.max_parts) parts[nparts + r] = static_cast<int>(cnt[k]);
+        nparts += total;
+    }
+    if (nparts >= P.max_parts) nparts = P.max_parts - 1;
+    __syncthreads();
+    if (tid == 0) {
+        parts[nparts]          = static_cast<int>(S);
+        JG_GLOBAL ScanJob* job = as_global(P.job);
+        const bool fits        = S <= P.max_subseq && C <= P.max_chunks;
+        job->num_chunks        = fits ? static_cast<int>(C) : 0;
+        job->num_seq           = fits ? static_cast<int>((S + kSeqSubseq - 1) / kSeqSubseq) : 0;
+        job->num_tail_parts    = fits ? static_cast<int>(nparts) : 0;
+        job->sp.num_subseq     = fits ? static_cast<int>(S) : 0;
+        job->sp.num_segments   = static_cast<int>(E);
+        if (!fits) job->ip.num_du = 0;
+        stat[0] = fits ? 0u : 3u; // JPEGGPU_INTERNAL_ERROR: bounds computed from the header were wrong
+        stat[1] = S;
+        stat[2] = E;
+        stat[3] = C;
+        stat[4] = nparts;
+    }
+}
+
+} // namespace
+
+hipError_t launch_front(const FrontParams& P, hipStream_t stream)
+{
+    if (P.num_windows == 0) return hipErrorInvalidValue;
+    front_windows<<<P.num_windows, 256, 0, stream>>>(P);
+    front_plan<<<1, PL, 0, stream>>>(P);
+    return hipGetLastError();
+}
+
+} // namespace jg

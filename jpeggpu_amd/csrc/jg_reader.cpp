@@ -446,6 +446,27 @@ jpeggpu_status Reader::read_sos(const Logger& log)
     scan.begin            = static_cast<size_t>(cur_ - base_);
     if (s.num_scans == 0) s.xfer_begin = (scan.begin - 1) & ~static_cast<size_t>(15);
     ++s.num_scans;
+    if (device_scan_ && s.num_scans == 1 && ns == s.num_comp) {
+        // Device-side front end: everything up to the end of the file is transferred, the device finds the
+        // restart markers and the end of the scan. Upper bounds: a segment of d data bytes has
+        // ceil(d / subsequence) subsequences, so at most (bytes / subsequence) + segments in total; a chunk
+        // is a 4 KiB window of one segment.
+        const size_t bytes    = static_cast<size_t>(end_ - base_) - scan.begin;
+        const size_t segments = static_cast<size_t>(ceil_div(total_mcus, scan.mcus_per_segment));
+        const size_t windows  = (static_cast<size_t>(end_ - base_) - s.xfer_begin + kDestuffWin - 1) / kDestuffWin;
+        const size_t subseq   = bytes / static_cast<size_t>(subseq_bytes_) + segments + 1;
+        if (segments <= (1u << 20) && subseq < (1u << 24) && bytes < (1u << 27)) {
+            scan.device_walk     = true;
+            scan.expect_segments = static_cast<int>(segments);
+            scan.num_subseq      = static_cast<int>(subseq);
+            scan.max_chunks      = static_cast<int>(windows + segments + 1);
+            scan.max_tail_parts  = static_cast<int>(subseq / kTailPartSubseq + 3);
+            scan.end             = static_cast<size_t>(end_ - base_);
+            s.xfer_end           = scan.end;
+            stop_                = true;
+            return JPEGGPU_SUCCESS;
+        }
+    }
     return walk_scan(scan, log);
 }
 
@@ -590,8 +611,10 @@ jpeggpu_status Reader::walk_scan(Scan& scan, const Logger& log)
     return JPEGGPU_SUCCESS;
 }
 
-jpeggpu_status Reader::parse(const uint8_t* data, size_t size, int subseq_bytes, const Logger& log)
+jpeggpu_status Reader::parse(const uint8_t* data, size_t size, int subseq_bytes, const Logger& log, bool device_scan)
 {
+    device_scan_ = device_scan;
+    stop_        = false;
     {
         // reset, keeping the capacity of the per-scan vectors: a decoder parses image after image
         Scan keep[kMaxScans];
@@ -664,6 +687,7 @@ jpeggpu_status Reader::parse(const uint8_t* data, size_t size, int subseq_bytes,
             st = read_dht(log);
         } else if (marker == M_SOS) {
             st = read_sos(log);
+            if (st == JPEGGPU_SUCCESS && stop_) break;
         } else if (marker == M_DQT) {
             st = read_dqt(log);
         } else if (marker == M_DRI) {

@@ -66,6 +66,12 @@ struct Scan {
     std::vector<Segment> segments;
     std::vector<DestuffChunk> chunks;
     std::vector<int> tail_parts; // subsequence ranges [parts[i], parts[i+1]) cut at segment starts
+    // Device-side front end (jg_front.hip): the host does not walk the scan; num_subseq and the three
+    // capacities are upper bounds from the header, segments / chunks / tail_parts stay empty.
+    bool device_walk    = false;
+    int expect_segments = 0;
+    int max_chunks      = 0;
+    int max_tail_parts  = 0; // entries of the device's tail_parts array
 };
 
 struct Stream {
@@ -83,7 +89,9 @@ struct Stream {
 };
 
 struct Reader {
-    jpeggpu_status parse(const uint8_t* data, size_t size, int subseq_bytes, const Logger& log);
+    /// `device_scan`: a file whose first scan holds every component is not walked on the host (jg_front.hip
+    /// does it on the device); parsing stops at that scan's first entropy-coded byte.
+    jpeggpu_status parse(const uint8_t* data, size_t size, int subseq_bytes, const Logger& log, bool device_scan = false);
 
     Stream s;
 
@@ -97,6 +105,8 @@ struct Reader {
     bool dc_defined_[4]{}, ac_defined_[4]{};
     std::vector<uint8_t> dc_tab_[4], ac_tab_[4]; // device-format tables by table id (T.81 Th)
     bool comp_in_scan_[kMaxComp]{};
+    bool device_scan_ = false;
+    bool stop_        = false; // device mode: nothing behind the scan header is parsed on the host
 
     size_t remaining() const { return static_cast<size_t>(end_ - cur_); }
     uint8_t u8() { return *cur_++; }

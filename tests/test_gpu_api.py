@@ -329,6 +329,81 @@ def test_corrupt_headers_are_memory_safe(torch_cuda):
         assert np.array_equal(planes[c].cpu().numpy(), ref.planes[c])
 
 
+def _decode_device_scan(torch, jpeggpu_amd, data, subseq_bytes):
+    dec = jpeggpu_amd.Decoder(subseq_bytes)
+    dec.set_device_scan(True)
+    info = dec.parse_header(data)
+    lay = dec.layout()
+    n = dec.get_buffer_size()
+    tmp = torch.full((n + 256 + 8192,), 0x5A, dtype=torch.uint8, device="cuda:0")
+    base = (tmp.data_ptr() + 4096 + 255) // 256 * 256
+    planes = [torch.full((info.sizes_y[c] + 2, info.sizes_x[c]), 0x5A, dtype=torch.uint8, device="cuda:0")
+              for c in range(info.num_components)]
+    dec.transfer(base, n, 0)
+    dec.decode([p[1:-1].data_ptr() for p in planes], [p.stride(0) for p in planes], base, n, 0)
+    status = dec.device_status(base, 0)
+    torch.cuda.synchronize()
+    off = base - tmp.data_ptr()
+    assert (tmp[:off] == 0x5A).all() and (tmp[off + n:] == 0x5A).all(), "tmp overrun"
+    for p in planes:
+        assert (p[0] == 0x5A).all() and (p[-1] == 0x5A).all(), "plane overrun"
+    words = None
+    if lay.scans[0].device_scan:
+        w = tmp[off + lay.scans[0].off_device_status: off + lay.scans[0].off_device_status + 32].cpu().numpy().view(np.uint32)
+        words = [int(x) for x in w[:5]]
+    dec.cleanup()
+    return status, [p[1:-1].cpu().numpy() for p in planes], lay, words
+
+
+def test_device_side_marker_scan(torch_cuda):
+    """jpeggpu_ext_set_device_scan: the device finds the restart markers and builds segment table,
+    destuff work list and tail parts; planes bit-exact vs the oracle, counts equal to the host walk's; streams the
+    host walk would have refused at parse time report their status from the device and leave the planes alone."""
+    import jpeggpu_amd
+    from jpeggpu_amd import Status
+    from oracle import oracle
+
+    torch = torch_cuda
+    m = cases.matrix()
+    took_device_path = 0
+    for name, data in m.items():
+        ref = oracle.decode(data)
+        for sb in (128, 32):
+            status, planes, lay, words = _decode_device_scan(torch, jpeggpu_amd, data, sb)
+            if not lay.scans[0].device_scan:
+                assert ref.nscans > 1, name  # only files with several scans keep the host walk
+                assert status == Status.SUCCESS
+            else:
+                host = jpeggpu_amd.Decoder(sb)
+                host.parse_header(data)
+                hl = host.layout().scans[0]
+                host.cleanup()
+                if status == Status.NOT_SUPPORTED:  # restart markers denser than the window records hold
+                    assert name in ("dri_1", "dri_7", "dri_fill", "odd_partial_mcu") or hl.num_segments > 15, name
+                    continue
+                assert status == Status.SUCCESS, (name, sb, status)
+                took_device_path += 1
+                assert words[0] == 0 and words[1] == hl.num_subsequences and words[2] == hl.num_segments, (name, sb, words)
+                assert words[3] == hl.num_chunks, (name, sb, words, hl.num_chunks)
+            if status == Status.SUCCESS:
+                for c in range(ref.ncomp):
+                    assert np.array_equal(planes[c], ref.planes[c]), (name, sb, c)
+    assert took_device_path > 30
+
+    # what the host walk refuses at parse time comes back from the device; the planes are not written
+    good = m["multi_seq_dri"]
+    cut = good[: len(good) * 2 // 3]                       # no terminating marker
+    status, planes, _, _ = _decode_device_scan(torch, jpeggpu_amd, cut, 128)
+    assert status == Status.INCOMPLETE_BITSTREAM and all((p == 0x5A).all() for p in planes)
+    sos = good.index(b"\xff\xda")
+    dri = good.index(b"\xff\xdd")
+    assert dri < sos
+    wrong = bytearray(good)
+    wrong[dri + 5] ^= 0x20                                 # a restart interval (64 -> 96 MCUs) the markers do not follow
+    status, planes, _, _ = _decode_device_scan(torch, jpeggpu_amd, bytes(wrong), 128)
+    assert status == Status.INVALID_JPEG and all((p == 0x5A).all() for p in planes)
+
+
 def test_c_caller_decodes_the_reference_photo(torch_cuda, tmp_path):
     """examples/decode_file.c (plain C, HIP runtime, no Python in the process) on the reference's photo: the
     planes it writes carry the committed hashes of the oracle's planes (tests/golden/photo_pins.json)."""
