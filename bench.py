@@ -49,6 +49,8 @@ def parse_args():
                     help="flow iterations inside the sequence kernel in batch mode (0 = library default, 1)")
     ap.add_argument("--gather", action="store_true", help="RCCL gather of the decoded planes to rank 0 each step")
     ap.add_argument("--latency-iters", type=int, default=50)
+    ap.add_argument("--latency-device-scan", type=int, default=1,
+                    help="latency probe: jpeggpu_ext_set_device_scan (restart-marker scan on the device instead of the host walk)")
     ap.add_argument("--latency-subseq-bytes", type=int, default=64,
                     help="subsequence size of the single-image latency probe (64 B: shorter serial chain)")
     ap.add_argument("--cpu-seconds", type=float, default=12.0, help="budget of the CPU baseline sample")
@@ -76,8 +78,10 @@ def make_images(args, rank, world):
 class Slot:
     """One image in flight: its decoder, its temporary device memory and its output planes."""
 
-    def __init__(self, torch, jp, data, device, subseq_bytes, planes_flat=None, planes_off=0):
+    def __init__(self, torch, jp, data, device, subseq_bytes, planes_flat=None, planes_off=0, device_scan=False):
         self.dec = jp.Decoder(subseq_bytes or None)
+        if device_scan:
+            self.dec.set_device_scan(True)
         self.data = data
         self.info = self.dec.parse_header(data)
         self.tmp_size = self.dec.get_buffer_size()
@@ -116,7 +120,7 @@ def algorithmic_bytes(slot):
         "b_dh": stuffed + 128 * ndu,
         "b_e2e": stuffed + slot.plane_bytes,
         # per-kernel algorithmic bytes
-        "zero": 128 * ndu,
+        "front": stuffed,
         "destuff": 2 * stuffed,
         # sync_intra: destuffed bytes read once + subsequence->segment map read + 21 B of state written
         "sync_intra": nsub * lay.subsequence_bytes + nsub * 4 + nsub * 21,
@@ -319,7 +323,7 @@ def main():
     if rank == 0:
         # single-image latency under the reference's protocol (benchmark/benchmark_jpeggpu.hpp:69-108):
         # parse_header + get_buffer_size + transfer + decode + stream sync, wall clock, pinned input
-        s0 = Slot(torch, jp, slots[0].data, device, args.latency_subseq_bytes)
+        s0 = Slot(torch, jp, slots[0].data, device, args.latency_subseq_bytes, device_scan=bool(args.latency_device_scan))
         pinned = torch.empty(len(s0.data), dtype=torch.uint8).pin_memory()
         pinned.numpy()[:] = memoryview(s0.data)
         host_ptr, host_n = pinned.data_ptr(), pinned.numel()
@@ -347,10 +351,10 @@ def main():
 
         dom = max(stage_us, key=stage_us.get)
         dom_bytes = ab[dom] * images_per_launch
-        kernel_names = {"zero": "zero_kernel", "destuff": "destuff_kernel", "sync_intra": "huff_sync_intra",
+        kernel_names = {"front": "front_windows", "destuff": "destuff_kernel", "sync_intra": "huff_sync_intra",
                         "sync_inter": "huff_sync_tail", "tails": "huff_seq_tails", "write": "huff_write",
                         "idct": "idct_kernel"}
-        t_pass_us = sum(stage_us[k] for k in ("zero", "destuff", "sync_intra", "sync_inter", "tails", "write"))
+        t_pass_us = sum(stage_us[k] for k in ("front", "destuff", "sync_intra", "sync_inter", "tails", "write"))
         roofline = {
             "bound": "hbm", "kernel": kernel_names[dom],
             "achieved": (dom_bytes / (stage_us[dom] * 1e-6) / 1e9) if dom_bytes and stage_us[dom] > 0 else None,
@@ -391,7 +395,7 @@ def main():
                        "parallelism": "image-sharded x%d" % world},
             "roofline": roofline,
             "roofline_pass": {
-                "what": "destuff+Huffman pass (zero, destuff, sync_intra, sync_inter, tails, write), "
+                "what": "destuff+Huffman pass (front end, destuff, sync_intra, sync_inter, tails, write), "
                         "B_dh = stuffed scan bytes + 128 B per data unit (SURVEY.md 8d)",
                 "bytes_per_image": ab["b_dh"], "sum_launch_us_under_load": t_pass_us,
                 "images_per_launch": images_per_launch,
@@ -403,6 +407,7 @@ def main():
             "stage_us_under_load": stage_us, "stage_us_solo": solo,
             "latency_ms": {"protocol": "parse+size+transfer+decode+sync, 1 image, 1 stream, pinned input",
                            "subsequence_bytes": s0.layout.subsequence_bytes,
+                           "device_scan": bool(s0.layout.scans[0].device_scan),
                            "p50": statistics.median(lat), "mean": statistics.fmean(lat), "max": max(lat),
                            "p50_host_parse": statistics.median(lat_parse),
                            "p50_host_enqueue": statistics.median(lat_enqueue),

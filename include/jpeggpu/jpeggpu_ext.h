@@ -96,7 +96,7 @@ enum jpeggpu_status jpeggpu_ext_get_device_status(
  * mean milliseconds per stage (summed over scans) of the decodes since the previous call (at most the
  * last 64), and starts a new measurement window. */
 enum jpeggpu_ext_stage {
-    JPEGGPU_EXT_STAGE_ZERO       = 0, /* unused (always 0): nothing is zero-filled any more */
+    JPEGGPU_EXT_STAGE_FRONT      = 0, /* device-side marker scan (jpeggpu_ext_set_device_scan), else ~0 */
     JPEGGPU_EXT_STAGE_DESTUFF    = 1,
     JPEGGPU_EXT_STAGE_SYNC_INTRA = 2,
     JPEGGPU_EXT_STAGE_SYNC_INTER = 3,

@@ -13,7 +13,7 @@ import os
 from . import build as _build
 
 MAX_COMP = 4
-STAGES = ("zero", "destuff", "sync_intra", "sync_inter", "tails", "write", "idct")
+STAGES = ("front", "destuff", "sync_intra", "sync_inter", "tails", "write", "idct")
 
 
 class Status(enum.IntEnum):

@@ -252,6 +252,7 @@ def test_corrupt_entropy_data_is_memory_safe(torch_cuda):
                 if bad[pos] != 0xFF and bad[pos - 1] != 0xFF:
                     bad[pos] = v
             dec = jpeggpu_amd.Decoder(int(rng.choice([32, 64, 128])))
+            dec.set_device_scan(bool(trial & 1))  # half of the trials find the markers on the device
             try:
                 info = dec.parse_header(bytes(bad))
             except jpeggpu_amd.JpegGpuError:
@@ -296,6 +297,7 @@ def test_corrupt_headers_are_memory_safe(torch_cuda):
             for pos in rng.integers(2, sos + 12, size=int(rng.integers(1, 4))):
                 bad[pos] = int(rng.integers(0, 256)) if rng.random() < 0.5 else bad[pos] ^ (1 << int(rng.integers(8)))
             dec = jpeggpu_amd.Decoder(int(rng.choice([32, 64, 128, 256])))
+            dec.set_device_scan(bool(trial & 1))
             try:
                 info = dec.parse_header(bytes(bad))
                 n = dec.get_buffer_size()

@@ -65,14 +65,31 @@ def main():
             for c in range(ref.ncomp):
                 assert np.array_equal(planes[c].cpu().numpy(), ref.planes[c]), ("batch", rounds, len(data), c)
                 planes[c].fill_(0x3C)
-        # the same images through the drop-in call
+        # the same images through the drop-in call, half of them with the device-side marker scan
+        singles = []
         for (dec, tmp, planes, data), ref, it in zip(keep, refs, items):
-            dec.decode(it[1], it[2], it[3], it[4], 0)
-        torch.cuda.synchronize()
-        for (dec, tmp, planes, data), ref in zip(keep, refs):
-            for c in range(ref.ncomp):
-                assert np.array_equal(planes[c].cpu().numpy(), ref.planes[c]), ("single", rounds, len(data), c)
             dec.cleanup()
+            dec2 = jp.Decoder(sb)
+            dev = bool(rng.integers(2))
+            dec2.set_device_scan(dev)
+            dec2.parse_header(data)
+            n2 = dec2.get_buffer_size()
+            tmp2 = torch.empty(n2 + 256, dtype=torch.uint8, device="cuda:0")
+            base2 = (tmp2.data_ptr() + 255) // 256 * 256
+            dec2.transfer(base2, n2, 0)
+            dec2.decode(it[1], it[2], base2, n2, 0)
+            singles.append((dec2, tmp2, base2))
+        torch.cuda.synchronize()
+        for (dec, tmp, planes, data), ref, (dec2, tmp2, base2) in zip(keep, refs, singles):
+            st = dec2.device_status(base2, 0)
+            if st == jp.Status.NOT_SUPPORTED:  # restart markers too dense for the device path: planes untouched
+                for c in range(ref.ncomp):
+                    assert (planes[c] == 0x3C).all()
+            else:
+                assert st == jp.Status.SUCCESS, st
+                for c in range(ref.ncomp):
+                    assert np.array_equal(planes[c].cpu().numpy(), ref.planes[c]), ("single", rounds, len(data), c)
+            dec2.cleanup()
         batch.destroy()
         rounds += 1
         images += len(keep)
