@@ -81,11 +81,11 @@ enum jpeggpu_status jpeggpu_ext_get_layout(jpeggpu_decoder_t decoder, struct jpe
 /* Device-side front end (enable != 0, before parse_header): for a file whose first scan holds every component,
  * parse_header stops at the scan header instead of walking the entropy-coded bytes for restart markers (the
  * reference does that walk on the host inside its timed loop, src/reader.cpp:447-489; here it is 0.2 of the
- * 0.87 ms of a 12 MP image). transfer then copies everything up to the end of the file, and decode first runs two
- * kernels that find the markers and build the segment table and the destuff work list in device memory. What the
- * host walk reports at parse time -- a scan without terminating marker, a restart-marker count that does not
- * match the geometry, restart markers denser than 15 per 4 KiB -- is then known only on the device: decode leaves
- * the planes untouched, and jpeggpu_ext_get_device_status (which synchronises `stream`) returns the status.
+ * 0.87 ms of a 12 MP image). transfer then copies everything up to the end of the file, and decode first runs four
+ * small kernels that find the markers and build the segment table and the destuff work list in device memory. What
+ * the host walk reports at parse time -- a scan without terminating marker, a restart-marker count that does not
+ * match the geometry -- is then known only on the device: decode leaves the planes untouched, and
+ * jpeggpu_ext_get_device_status (which synchronises `stream`) returns the status.
  * Other files (several scans) take the host walk as before. Batches take host-walked images only. */
 enum jpeggpu_status jpeggpu_ext_set_device_scan(jpeggpu_decoder_t decoder, int enable);
 enum jpeggpu_status jpeggpu_ext_get_device_status(

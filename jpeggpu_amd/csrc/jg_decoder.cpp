@@ -77,7 +77,7 @@ struct ScanPlan {
     int num_seq = 0;
     // device-side front end (jg_front.hip): tables built on the device, scratch, the job and the status word
     size_t d_segments = 0, d_chunks = 0, d_parts = 0;
-    size_t d_win_data = 0, d_win_nmark = 0, d_win_mark = 0, d_win_prefix = 0, d_mark_off = 0;
+    size_t d_win_data = 0, d_win_nmark = 0, d_win_prefix = 0, d_mark_off = 0;
     size_t d_mk_pos = 0, d_mk_g = 0, d_seg_cnt = 0, d_seg_nch = 0, d_job = 0, d_status = 0;
     uint32_t num_windows = 0;
 };
@@ -195,11 +195,10 @@ void Decoder::make_plan()
             carve(sp.d_parts, static_cast<size_t>(sc.max_tail_parts) * sizeof(int));
             carve(sp.d_win_data, Wn * 4);
             carve(sp.d_win_nmark, Wn * 4);
-            carve(sp.d_win_mark, Wn * kMaxWinMarkers * 12);
             carve(sp.d_win_prefix, (Wn + 1) * 4);
             carve(sp.d_mark_off, (Wn + 1) * 4);
-            carve(sp.d_mk_pos, E * 4);
-            carve(sp.d_mk_g, E * 4);
+            carve(sp.d_mk_pos, (E + 1) * 4);
+            carve(sp.d_mk_g, (E + 1) * 4);
             carve(sp.d_seg_cnt, (E + 1) * 4);
             carve(sp.d_seg_nch, (E + 1) * 4);
             carve(sp.d_job, sizeof(ScanJob));
@@ -426,7 +425,6 @@ jpeggpu_status do_decode(Decoder& d, jpeggpu_img* img, void* d_tmp, size_t tmp_s
         const auto u32    = [&](size_t off) { return reinterpret_cast<uint32_t*>(base + off); };
         P.win_data   = u32(pl.d_win_data);
         P.win_nmark  = u32(pl.d_win_nmark);
-        P.win_mark   = u32(pl.d_win_mark);
         P.win_prefix = u32(pl.d_win_prefix);
         P.mark_off   = u32(pl.d_mark_off);
         P.mk_pos     = u32(pl.d_mk_pos);

@@ -3,9 +3,11 @@
 // for the default path (reference src/reader.cpp:447-489): the segment table, the destuff work list with
 // destination offsets, the tail-kernel parts and the counts the Huffman kernels read from their job.
 //
-//   front_windows   one workgroup per 4 KiB window: data bytes (the byte rule of decode_destuff.cu:37-44),
-//                   marker records {position, code, data bytes of the window before it}
-//   front_plan      one workgroup: prefix sums over windows and segments, validation, table building
+//   front_count     one workgroup per 4 KiB window: data bytes (the byte rule of decode_destuff.cu:37-44) and markers
+//   front_prefix    one workgroup: prefix sums over the windows
+//   front_marks     per window again: every marker now knows its ordinal in the scan and the data bytes in
+//                   front of it; the first expect_segments + 1 are recorded, the terminating one is found
+//   front_plan      one workgroup: validation, prefix sums over segments, table building
 //
 // Only single-scan files take this path (everything behind the first scan's data would otherwise have to be
 // parsed by the host anyway); sizes are upper bounds computed from the header.
@@ -55,58 +57,84 @@ __device__ __forceinline__ uint32_t block_excl_scan(uint32_t v, uint32_t* s_wave
     return off + incl - v;
 }
 
-__global__ __launch_bounds__(256) void front_windows(FrontParams P)
-{
-    __shared__ uint32_t s_wave[4];
-    JG_GLOBAL const uint8_t* src = as_global(P.bytes);
-    const uint32_t w             = blockIdx.x;
-    const uint32_t t             = threadIdx.x;
-    const uint32_t gpos          = w * kDestuffWin + t * 16;
-
+/// The 16 bytes of a lane: which are data (byte rule of decode_destuff.cu:37-44), which are the FF right in
+/// front of a marker code (not followed by a stuffed zero nor by a fill byte), and the byte behind the last.
+struct LaneBytes {
     uint32_t word[4];
+    uint32_t next;
+    uint32_t data_mask, mark_mask;
+    __device__ __forceinline__ uint32_t byte_after(int i) const
+    {
+        return i < 15 ? (word[(i + 1) >> 2] >> (8 * ((i + 1) & 3))) & 0xFFu : next;
+    }
+};
+
+__device__ __forceinline__ LaneBytes classify(const FrontParams& P, uint32_t gpos)
+{
+    JG_GLOBAL const uint8_t* src = as_global(P.bytes);
+    LaneBytes L;
     {
         typedef uint32_t V4 __attribute__((ext_vector_type(4)));
         const V4 v = *reinterpret_cast<JG_GLOBAL const V4*>(src + gpos); // the buffer has a spare window behind bytes_len
-        word[0] = v[0]; word[1] = v[1]; word[2] = v[2]; word[3] = v[3];
+        L.word[0] = v[0]; L.word[1] = v[1]; L.word[2] = v[2]; L.word[3] = v[3];
     }
-    uint32_t prev       = gpos > 0 ? src[gpos - 1] : 0u;
-    const uint32_t next = src[gpos + 16];
-
-    uint32_t data_mask = 0, mark_mask = 0;
+    uint32_t prev = gpos > 0 ? src[gpos - 1] : 0u;
+    L.next        = src[gpos + 16];
+    L.data_mask = L.mark_mask = 0;
 #pragma unroll
     for (int i = 0; i < 16; ++i) {
-        const uint32_t b   = (word[i >> 2] >> (8 * (i & 3))) & 0xFFu;
-        const uint32_t nx  = i < 15 ? (word[(i + 1) >> 2] >> (8 * ((i + 1) & 3))) & 0xFFu : next;
+        const uint32_t b   = (L.word[i >> 2] >> (8 * (i & 3))) & 0xFFu;
+        const uint32_t nx  = L.byte_after(i);
         const uint32_t pos = gpos + i;
         const bool in      = pos >= P.scan_begin && pos < P.bytes_len;
         const bool data    = (prev == 0xFFu && b == 0u) || (prev != 0xFFu && b != 0xFFu);
-        // the FF right in front of a marker code: not followed by a stuffed zero, not by a fill byte, and
-        // the code itself inside the buffer
-        const bool mark = b == 0xFFu && nx != 0u && nx != 0xFFu && pos + 1 < P.bytes_len;
-        if (in && data) data_mask |= 1u << i;
-        if (in && mark) mark_mask |= 1u << i;
+        const bool mark    = b == 0xFFu && nx != 0u && nx != 0xFFu && pos + 1 < P.bytes_len; // the code is in the buffer
+        if (in && data) L.data_mask |= 1u << i;
+        if (in && mark) L.mark_mask |= 1u << i;
         prev = b;
     }
+    return L;
+}
+
+/// Pass 1: data bytes and markers per window.
+__global__ __launch_bounds__(256) void front_count(FrontParams P)
+{
+    __shared__ uint32_t s_wave[4];
+    const uint32_t w  = blockIdx.x;
+    const LaneBytes L = classify(P, w * kDestuffWin + threadIdx.x * 16);
     uint32_t total_data = 0, total_mark = 0;
-    const uint32_t data_before = block_excl_scan<4>(__popc(data_mask), s_wave, total_data);
-    const uint32_t mark_before = block_excl_scan<4>(__popc(mark_mask), s_wave, total_mark);
-    uint32_t m = mark_mask;
-    uint32_t ord = mark_before;
+    block_excl_scan<4>(__popc(L.data_mask), s_wave, total_data);
+    block_excl_scan<4>(__popc(L.mark_mask), s_wave, total_mark);
+    if (threadIdx.x == 0) {
+        as_global(P.win_data)[w]  = total_data;
+        as_global(P.win_nmark)[w] = total_mark;
+    }
+}
+
+/// Pass 2, after the prefix sums over windows: every marker knows its ordinal in the scan; the first
+/// expect_segments + 1 of them are recorded {position, data bytes of the scan in front of it}, and the first
+/// one that is not RSTn -- the end of the scan -- is found with an atomic minimum.
+__global__ __launch_bounds__(256) void front_marks(FrontParams P)
+{
+    __shared__ uint32_t s_wave[4];
+    const uint32_t w    = blockIdx.x;
+    const uint32_t gpos = w * kDestuffWin + threadIdx.x * 16;
+    if (as_global(P.win_nmark)[w] == 0) return;
+    const LaneBytes L = classify(P, gpos);
+    uint32_t total_data = 0, total_mark = 0;
+    const uint32_t data_before = as_global(P.win_prefix)[w] + block_excl_scan<4>(__popc(L.data_mask), s_wave, total_data);
+    uint32_t ord               = as_global(P.mark_off)[w] + block_excl_scan<4>(__popc(L.mark_mask), s_wave, total_mark);
+    uint32_t m                 = L.mark_mask;
     while (m) {
         const int i = __ffs(m) - 1;
         m &= m - 1;
-        if (ord < kMaxWinMarkers) {
-            const uint32_t nx  = i < 15 ? (word[(i + 1) >> 2] >> (8 * ((i + 1) & 3))) & 0xFFu : next;
-            JG_GLOBAL uint32_t* rec = as_global(P.win_mark) + (static_cast<size_t>(w) * kMaxWinMarkers + ord) * 3;
-            rec[0] = gpos + i;
-            rec[1] = nx;
-            rec[2] = data_before + __popc(data_mask & ((1u << i) - 1u));
+        if (ord <= P.expect_segments) {
+            as_global(P.mk_pos)[ord] = gpos + i;
+            as_global(P.mk_g)[ord]   = data_before + __popc(L.data_mask & ((1u << i) - 1u));
+            const uint32_t code      = L.byte_after(i);
+            if (code < 0xD0u || code > 0xD7u) atomicMin(P.status + 7, ord);
         }
         ++ord;
-    }
-    if (t == 0) {
-        as_global(P.win_data)[w]  = total_data;
-        as_global(P.win_nmark)[w] = total_mark;
     }
 }
 
@@ -130,50 +158,33 @@ __device__ uint32_t scan_array(JG_GLOBAL const uint32_t* in, JG_GLOBAL uint32_t*
     return carry;
 }
 
+/// Between the passes: prefix sums over the windows.
+__global__ __launch_bounds__(PL) void front_prefix(FrontParams P)
+{
+    __shared__ uint32_t s_wave[PL / 64];
+    scan_array(as_global(P.win_data), as_global(P.win_prefix), P.num_windows, s_wave);
+    scan_array(as_global(P.win_nmark), as_global(P.mark_off), P.num_windows, s_wave);
+    if (threadIdx.x == 0) as_global(P.status)[7] = 0xFFFFFFFFu; // ordinal of the terminating marker (front_marks)
+}
+
 __global__ __launch_bounds__(PL) void front_plan(FrontParams P)
 {
     __shared__ uint32_t s_wave[PL / 64];
-    __shared__ uint32_t s_first_other, s_first_overflow;
     const uint32_t tid = threadIdx.x;
     const uint32_t Wn = P.num_windows, E = P.expect_segments, SB = P.subseq_bytes;
-    JG_GLOBAL const uint32_t* win_data  = as_global(P.win_data);
-    JG_GLOBAL const uint32_t* win_nmark = as_global(P.win_nmark);
-    JG_GLOBAL const uint32_t* win_mark  = as_global(P.win_mark);
-    JG_GLOBAL uint32_t* WP   = as_global(P.win_prefix);
-    JG_GLOBAL uint32_t* MO   = as_global(P.mark_off);
-    JG_GLOBAL uint32_t* mkp  = as_global(P.mk_pos);
-    JG_GLOBAL uint32_t* mkg  = as_global(P.mk_g);
+    JG_GLOBAL const uint32_t* WP  = as_global(P.win_prefix);
+    JG_GLOBAL const uint32_t* mkp = as_global(P.mk_pos);
+    JG_GLOBAL const uint32_t* mkg = as_global(P.mk_g);
     JG_GLOBAL uint32_t* cnt  = as_global(P.seg_cnt);
     JG_GLOBAL uint32_t* nch  = as_global(P.seg_nch);
     JG_GLOBAL Segment* segs  = as_global(P.segments);
     JG_GLOBAL uint32_t* stat = as_global(P.status);
+    (void)Wn;
 
-    if (tid == 0) {
-        s_first_other    = 0xFFFFFFFFu;
-        s_first_overflow = 0xFFFFFFFFu;
-    }
-    scan_array(win_data, WP, Wn, s_wave);
-    scan_array(win_nmark, MO, Wn, s_wave);
-
-    // the first marker that is not RSTn ends the scan; a window with more markers than it can record
-    // makes everything from there on unknown
-    for (uint32_t w = tid; w < Wn; w += PL) {
-        const uint32_t n = win_nmark[w];
-        if (n > kMaxWinMarkers) atomicMin(&s_first_overflow, MO[w] + kMaxWinMarkers);
-        for (uint32_t k = 0; k < n && k < kMaxWinMarkers; ++k) {
-            const uint32_t code = win_mark[(static_cast<size_t>(w) * kMaxWinMarkers + k) * 3 + 1];
-            if (code < 0xD0u || code > 0xD7u) {
-                atomicMin(&s_first_other, MO[w] + k);
-                break;
-            }
-        }
-    }
-    __syncthreads();
-    const uint32_t T = s_first_other; // ordinal of the terminating marker
-    uint32_t status  = 0;             // JPEGGPU_SUCCESS
-    if (s_first_overflow < T) status = 4;       // JPEGGPU_NOT_SUPPORTED: restart markers too dense for this path
-    else if (T == 0xFFFFFFFFu) status = 6;      // JPEGGPU_INCOMPLETE_BITSTREAM: no terminating marker
-    else if (T + 1 != E) status = 2;            // JPEGGPU_INVALID_JPEG: restart segments do not match the geometry
+    const uint32_t T = stat[7]; // ordinal of the first marker that is not RSTn, among the first E + 1 markers
+    uint32_t status  = 0;       // JPEGGPU_SUCCESS
+    if (T == 0xFFFFFFFFu) status = as_global(P.mark_off)[P.num_windows] > E ? 2u : 6u; // too many restart markers : none ends the scan
+    else if (T + 1 != E) status = 2;                                                   // JPEGGPU_INVALID_JPEG: segments do not match the geometry
     if (status != 0) {
         // nothing downstream may run on tables that were not built
         if (tid == 0) {
@@ -192,19 +203,6 @@ __global__ __launch_bounds__(PL) void front_plan(FrontParams P)
         }
         return;
     }
-
-    // the markers that matter, in stream order: RST_0 .. RST_{E-2}, terminator
-    for (uint32_t w = tid; w < Wn; w += PL) {
-        const uint32_t n = min(win_nmark[w], static_cast<uint32_t>(kMaxWinMarkers));
-        for (uint32_t k = 0; k < n; ++k) {
-            const uint32_t g = MO[w] + k;
-            if (g > T) break;
-            JG_GLOBAL const uint32_t* rec = win_mark + (static_cast<size_t>(w) * kMaxWinMarkers + k) * 3;
-            mkp[g] = rec[0];
-            mkg[g] = WP[w] + rec[2]; // data bytes of the scan in front of the marker
-        }
-    }
-    __syncthreads();
 
     // segments: data bytes -> subsequences
     bool too_big = false;
@@ -305,7 +303,9 @@ __global__ __launch_bounds__(PL) void front_plan(FrontParams P)
 hipError_t launch_front(const FrontParams& P, hipStream_t stream)
 {
     if (P.num_windows == 0) return hipErrorInvalidValue;
-    front_windows<<<P.num_windows, 256, 0, stream>>>(P);
+    front_count<<<P.num_windows, 256, 0, stream>>>(P);
+    front_prefix<<<1, PL, 0, stream>>>(P);
+    front_marks<<<P.num_windows, 256, 0, stream>>>(P);
     front_plan<<<1, PL, 0, stream>>>(P);
     return hipGetLastError();
 }

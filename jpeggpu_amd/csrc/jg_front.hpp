@@ -8,8 +8,6 @@
 
 namespace jg {
 
-constexpr uint32_t kMaxWinMarkers = 15; // marker records per 4 KiB window; denser restart markers: host walk
-
 /// Everything front_windows / front_plan need; all pointers are device memory inside d_tmp.
 struct FrontParams {
     const uint8_t* bytes;      // transferred bytes; offset 0 is the origin of the 4 KiB window grid
@@ -23,18 +21,17 @@ struct FrontParams {
     uint32_t max_parts;        // entries of tail_parts (parts + 1)
     uint32_t* win_data;        // [num_windows]      data bytes per window
     uint32_t* win_nmark;       // [num_windows]      markers per window
-    uint32_t* win_mark;        // [num_windows][kMaxWinMarkers][3]  {position, code, data bytes of the window before}
     uint32_t* win_prefix;      // [num_windows + 1]
     uint32_t* mark_off;        // [num_windows + 1]
-    uint32_t* mk_pos;          // [expect_segments]
-    uint32_t* mk_g;            // [expect_segments]
+    uint32_t* mk_pos;          // [expect_segments + 1]  position of the i-th marker of the scan
+    uint32_t* mk_g;            // [expect_segments + 1]  data bytes of the scan in front of it
     uint32_t* seg_cnt;         // [expect_segments + 1]
     uint32_t* seg_nch;         // [expect_segments + 1]
     Segment* segments;         // [expect_segments]          out
     DestuffChunk* chunks;      // [max_chunks]               out
     int* tail_parts;           // [max_parts]                out
     ScanJob* job;              // the scan's job in device memory: counts are filled in
-    uint32_t* status;          // [8]: jpeggpu_status, subsequences, segments, chunks, tail parts
+    uint32_t* status;          // [8]: jpeggpu_status, subsequences, segments, chunks, tail parts, -, -, terminator ordinal
 };
 
 hipError_t launch_front(const FrontParams& P, hipStream_t stream);

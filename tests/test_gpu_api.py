@@ -380,9 +380,6 @@ def test_device_side_marker_scan(torch_cuda):
                 host.parse_header(data)
                 hl = host.layout().scans[0]
                 host.cleanup()
-                if status == Status.NOT_SUPPORTED:  # restart markers denser than the window records hold
-                    assert name in ("dri_1", "dri_7", "dri_fill", "odd_partial_mcu") or hl.num_segments > 15, name
-                    continue
                 assert status == Status.SUCCESS, (name, sb, status)
                 took_device_path += 1
                 assert words[0] == 0 and words[1] == hl.num_subsequences and words[2] == hl.num_segments, (name, sb, words)
@@ -390,7 +387,7 @@ def test_device_side_marker_scan(torch_cuda):
             if status == Status.SUCCESS:
                 for c in range(ref.ncomp):
                     assert np.array_equal(planes[c], ref.planes[c]), (name, sb, c)
-    assert took_device_path > 30
+    assert took_device_path > 40  # every single-scan case, however dense its restart markers
 
     # what the host walk refuses at parse time comes back from the device; the planes are not written
     good = m["multi_seq_dri"]
