@@ -49,6 +49,8 @@ def parse_args():
                     help="flow iterations inside the sequence kernel in batch mode (0 = library default, 1)")
     ap.add_argument("--gather", action="store_true", help="RCCL gather of the decoded planes to rank 0 each step")
     ap.add_argument("--latency-iters", type=int, default=50)
+    ap.add_argument("--device-scan", type=int, default=0,
+                    help="1: the images of the timed batch use jpeggpu_ext_set_device_scan (marker scan inside the timed region)")
     ap.add_argument("--latency-device-scan", type=int, default=1,
                     help="latency probe: jpeggpu_ext_set_device_scan (restart-marker scan on the device instead of the host walk)")
     ap.add_argument("--latency-subseq-bytes", type=int, default=64,
@@ -242,10 +244,11 @@ def main():
     streams = [torch.cuda.Stream(device=device) for _ in range(nstreams)]
 
     # all planes of the rank's batch live in one flat tensor so that a gather is one collective
-    probe = Slot(torch, jp, images[0], device, args.subseq_bytes)
+    probe = Slot(torch, jp, images[0], device, args.subseq_bytes, device_scan=bool(args.device_scan))
     per_image = probe.plane_bytes
     planes_flat = torch.empty(per_image * args.batch, dtype=torch.uint8, device=device)
-    slots = [Slot(torch, jp, images[i % len(images)], device, args.subseq_bytes, planes_flat, i * per_image)
+    slots = [Slot(torch, jp, images[i % len(images)], device, args.subseq_bytes, planes_flat, i * per_image,
+                  device_scan=bool(args.device_scan))
              for i in range(args.batch)]
     probe.dec.cleanup()
     del probe
@@ -391,6 +394,7 @@ def main():
                        else "cfg1 bytes: tests/golden/IMG_6510.JPG (the reference's 12 MP photo)",
                        "images_per_gpu_per_step": args.batch, "mode": args.mode, "streams": nstreams,
                        "subsequence_bytes": slots[0].layout.subsequence_bytes,
+                       "device_scan": bool(slots[0].layout.scans[0].device_scan),
                        "stuffed_scan_bytes": ab["stuffed"], "gather": bool(args.gather and world > 1),
                        "parallelism": "image-sharded x%d" % world},
             "roofline": roofline,

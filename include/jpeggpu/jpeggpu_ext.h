@@ -86,7 +86,8 @@ enum jpeggpu_status jpeggpu_ext_get_layout(jpeggpu_decoder_t decoder, struct jpe
  * the host walk reports at parse time -- a scan without terminating marker, a restart-marker count that does not
  * match the geometry -- is then known only on the device: decode leaves the planes untouched, and
  * jpeggpu_ext_get_device_status (which synchronises `stream`) returns the status.
- * Other files (several scans) take the host walk as before. Batches take host-walked images only. */
+ * Other files (several scans) take the host walk as before. A batch may mix both kinds: the front end of its
+ * device-scanned images runs as four launches for the whole batch (grid.y = image). */
 enum jpeggpu_status jpeggpu_ext_set_device_scan(jpeggpu_decoder_t decoder, int enable);
 enum jpeggpu_status jpeggpu_ext_get_device_status(
     jpeggpu_decoder_t decoder, const void* d_tmp, jpeggpu_stream_t stream, enum jpeggpu_status* status);
@@ -112,7 +113,8 @@ enum jpeggpu_status jpeggpu_ext_get_stage_ms(jpeggpu_decoder_t decoder, float* m
  * a 256-CU device; the drop-in jpeggpu_decoder_decode launches per image. Every item must have been
  * parsed and transferred (jpeggpu_decoder_transfer) into its own d_tmp, and all decoders must use the
  * same subsequence size. `d_scratch` is caller-owned device memory of at least
- * jpeggpu_ext_batch_scratch_size(total number of scans) bytes, private to the stream. The batch
+ * jpeggpu_ext_batch_scratch_size(total number of scans) bytes (job descriptors and front-end parameters),
+ * private to the stream. The batch
  * handle owns page-locked host staging only. */
 struct jpeggpu_batch;
 typedef struct jpeggpu_batch* jpeggpu_batch_t;

@@ -394,6 +394,40 @@ jpeggpu_status build_jobs(
     return JPEGGPU_SUCCESS;
 }
 
+/// Parameters of the device-side front end for scan 0 of a parsed image; `d_job` is the device copy of its job.
+jg::FrontParams front_params(const Decoder& d, void* d_tmp, jg::ScanJob* d_job)
+{
+    using namespace jg;
+    const Scan& sc     = d.reader.s.scans[0];
+    const ScanPlan& pl = d.plan.scan[0];
+    uint8_t* base      = static_cast<uint8_t*>(d_tmp);
+    FrontParams P{};
+    P.bytes           = base + d.plan.off_bytes;
+    P.bytes_len       = static_cast<uint32_t>(d.plan.bytes_len);
+    P.scan_begin      = static_cast<uint32_t>(sc.begin - d.reader.s.xfer_begin);
+    P.num_windows     = pl.num_windows;
+    P.expect_segments = static_cast<uint32_t>(sc.expect_segments);
+    P.subseq_bytes    = static_cast<uint32_t>(d.subseq_bytes);
+    P.max_subseq      = static_cast<uint32_t>(sc.num_subseq);
+    P.max_chunks      = static_cast<uint32_t>(sc.max_chunks);
+    P.max_parts       = static_cast<uint32_t>(sc.max_tail_parts);
+    const auto u32    = [&](size_t off) { return reinterpret_cast<uint32_t*>(base + off); };
+    P.win_data   = u32(pl.d_win_data);
+    P.win_nmark  = u32(pl.d_win_nmark);
+    P.win_prefix = u32(pl.d_win_prefix);
+    P.mark_off   = u32(pl.d_mark_off);
+    P.mk_pos     = u32(pl.d_mk_pos);
+    P.mk_g       = u32(pl.d_mk_g);
+    P.seg_cnt    = u32(pl.d_seg_cnt);
+    P.seg_nch    = u32(pl.d_seg_nch);
+    P.segments   = reinterpret_cast<Segment*>(base + pl.d_segments);
+    P.chunks     = reinterpret_cast<DestuffChunk*>(base + pl.d_chunks);
+    P.tail_parts = reinterpret_cast<int*>(base + pl.d_parts);
+    P.job        = d_job;
+    P.status     = u32(pl.d_status);
+    return P;
+}
+
 jpeggpu_status do_decode(Decoder& d, jpeggpu_img* img, void* d_tmp, size_t tmp_size, hipStream_t stream)
 {
     using namespace jg;
@@ -406,36 +440,10 @@ jpeggpu_status do_decode(Decoder& d, jpeggpu_img* img, void* d_tmp, size_t tmp_s
     if (d.reader.s.scans[0].device_walk) {
         // Device-side front end: the job lives in device memory, front_plan fills in its counts, and the
         // stages run as a one-job batch with launch extents from the header's upper bounds.
-        const Scan& sc     = d.reader.s.scans[0];
-        const ScanPlan& pl = d.plan.scan[0];
-        uint8_t* base      = static_cast<uint8_t*>(d_tmp);
-        ScanJob* d_job     = reinterpret_cast<ScanJob*>(base + pl.d_job);
+        ScanJob* d_job = reinterpret_cast<ScanJob*>(static_cast<uint8_t*>(d_tmp) + d.plan.scan[0].d_job);
         // pageable source: the runtime stages it before returning, d.jobs may change afterwards
         JG_CHECK_HIP(hipMemcpyAsync(d_job, d.jobs.data(), sizeof(ScanJob), hipMemcpyHostToDevice, stream));
-        FrontParams P{};
-        P.bytes           = base + d.plan.off_bytes;
-        P.bytes_len       = static_cast<uint32_t>(d.plan.bytes_len);
-        P.scan_begin      = static_cast<uint32_t>(sc.begin - d.reader.s.xfer_begin);
-        P.num_windows     = pl.num_windows;
-        P.expect_segments = static_cast<uint32_t>(sc.expect_segments);
-        P.subseq_bytes    = static_cast<uint32_t>(d.subseq_bytes);
-        P.max_subseq      = static_cast<uint32_t>(sc.num_subseq);
-        P.max_chunks      = static_cast<uint32_t>(sc.max_chunks);
-        P.max_parts       = static_cast<uint32_t>(sc.max_tail_parts);
-        const auto u32    = [&](size_t off) { return reinterpret_cast<uint32_t*>(base + off); };
-        P.win_data   = u32(pl.d_win_data);
-        P.win_nmark  = u32(pl.d_win_nmark);
-        P.win_prefix = u32(pl.d_win_prefix);
-        P.mark_off   = u32(pl.d_mark_off);
-        P.mk_pos     = u32(pl.d_mk_pos);
-        P.mk_g       = u32(pl.d_mk_g);
-        P.seg_cnt    = u32(pl.d_seg_cnt);
-        P.seg_nch    = u32(pl.d_seg_nch);
-        P.segments   = reinterpret_cast<Segment*>(base + pl.d_segments);
-        P.chunks     = reinterpret_cast<DestuffChunk*>(base + pl.d_chunks);
-        P.tail_parts = reinterpret_cast<int*>(base + pl.d_parts);
-        P.job        = d_job;
-        P.status     = u32(pl.d_status);
+        const FrontParams P = front_params(d, d_tmp, d_job);
         JG_CHECK_HIP(launch_front(P, stream));
         JobExtent extent;
         extend(extent, d.jobs[0]);
@@ -682,7 +690,7 @@ enum jpeggpu_status jpeggpu_ext_get_device_status(
 struct jpeggpu_batch {
     static constexpr int kRing = 4;
     int max_jobs = 0;
-    jg::ScanJob* staging[kRing] = {};
+    uint8_t* staging[kRing]     = {}; // ScanJob[n], then FrontParams[device-scanned images]
     hipEvent_t copied[kRing]    = {};
     bool in_use[kRing]          = {};
     int next                    = 0;
@@ -695,13 +703,17 @@ struct jpeggpu_batch {
     hipStream_t aux[kMaxOverlap - 1] = {};
     hipEvent_t joined[kMaxOverlap - 1] = {};
     std::vector<jg::ScanJob> jobs;
+    std::vector<jg::FrontParams> fronts;
     // optional stage timing, same contract as the decoder's
     bool profiling = false;
     std::vector<std::vector<hipEvent_t>> sets; // ring of kNumStages + 1 events
     int cur_set = -1, sets_valid = 0;
 };
 
-size_t jpeggpu_ext_batch_scratch_size(int max_scans) { return static_cast<size_t>(max_scans > 0 ? max_scans : 0) * sizeof(jg::ScanJob); }
+size_t jpeggpu_ext_batch_scratch_size(int max_scans)
+{
+    return static_cast<size_t>(max_scans > 0 ? max_scans : 0) * (sizeof(jg::ScanJob) + sizeof(jg::FrontParams));
+}
 
 enum jpeggpu_status jpeggpu_ext_batch_create(jpeggpu_batch_t* batch, int max_scans)
 {
@@ -711,13 +723,13 @@ enum jpeggpu_status jpeggpu_ext_batch_create(jpeggpu_batch_t* batch, int max_sca
     b->max_jobs = max_scans;
     for (int r = 0; r < jpeggpu_batch::kRing; ++r) {
         void* p = nullptr;
-        if (hipHostMalloc(&p, sizeof(jg::ScanJob) * max_scans, hipHostMallocDefault) != hipSuccess ||
+        if (hipHostMalloc(&p, jpeggpu_ext_batch_scratch_size(max_scans), hipHostMallocDefault) != hipSuccess ||
             hipEventCreateWithFlags(&b->copied[r], hipEventDisableTiming) != hipSuccess) {
             (void)hipGetLastError();
             jpeggpu_ext_batch_destroy(b);
             return JPEGGPU_INTERNAL_ERROR; // the batch path needs a device: no fallback
         }
-        b->staging[r] = static_cast<jg::ScanJob*>(p);
+        b->staging[r] = static_cast<uint8_t*>(p);
     }
     *batch = b;
     return JPEGGPU_SUCCESS;
@@ -754,29 +766,36 @@ enum jpeggpu_status jpeggpu_ext_decode_batch(
     if (!batch || !items || num_items < 0 || !d_scratch) return JPEGGPU_INVALID_ARGUMENT;
     if (num_items == 0) return JPEGGPU_SUCCESS;
     batch->jobs.clear();
+    batch->fronts.clear();
     int subseq_bytes = 0;
+    jg::ScanJob* d_jobs_rw = static_cast<jg::ScanJob*>(d_scratch);
+    uint32_t front_windows = 0;
     for (int i = 0; i < num_items; ++i) {
         const jpeggpu_ext_batch_item& it = items[i];
         if (!it.decoder || !it.img) return JPEGGPU_INVALID_ARGUMENT;
         if (i == 0) subseq_bytes = it.decoder->d.subseq_bytes;
         if (it.decoder->d.subseq_bytes != subseq_bytes) return JPEGGPU_INVALID_ARGUMENT; // one kernel variant per launch
-        if (it.decoder->d.parsed && it.decoder->d.reader.s.scans[0].device_walk) return JPEGGPU_NOT_SUPPORTED; // host-walked images only
+        const size_t first_job = batch->jobs.size();
         const jpeggpu_status st = build_jobs(it.decoder->d, it.img, it.d_tmp, it.tmp_size, batch->sync_iters, batch->jobs);
         if (st != JPEGGPU_SUCCESS) return st;
+        if (it.decoder->d.reader.s.scans[0].device_walk) {
+            // device-side front end (jpeggpu_ext_set_device_scan): the counts of this job are filled in on the device
+            batch->fronts.push_back(front_params(it.decoder->d, it.d_tmp, d_jobs_rw + first_job));
+            front_windows = std::max(front_windows, batch->fronts.back().num_windows);
+        }
     }
-    const int n = static_cast<int>(batch->jobs.size());
-    if (n > batch->max_jobs || scratch_size < sizeof(jg::ScanJob) * static_cast<size_t>(n)) return JPEGGPU_INVALID_ARGUMENT;
+    const int n         = static_cast<int>(batch->jobs.size());
+    const int nf        = static_cast<int>(batch->fronts.size());
+    const size_t jbytes = sizeof(jg::ScanJob) * static_cast<size_t>(n), fbytes = sizeof(jg::FrontParams) * static_cast<size_t>(nf);
+    if (n > batch->max_jobs || scratch_size < jbytes + fbytes) return JPEGGPU_INVALID_ARGUMENT;
     const int r = batch->next;
     batch->next = (r + 1) % jpeggpu_batch::kRing;
     // the staging buffer may still be the source of a copy enqueued kRing batches ago
     if (batch->in_use[r] && hipEventSynchronize(batch->copied[r]) != hipSuccess) return JPEGGPU_INTERNAL_ERROR;
-    std::memcpy(batch->staging[r], batch->jobs.data(), sizeof(jg::ScanJob) * n);
+    std::memcpy(batch->staging[r], batch->jobs.data(), jbytes);
+    if (nf) std::memcpy(batch->staging[r] + jbytes, batch->fronts.data(), fbytes);
     jg::JobExtent extent;
     for (const jg::ScanJob& j : batch->jobs) jg::extend(extent, j);
-    if (hipMemcpyAsync(d_scratch, batch->staging[r], sizeof(jg::ScanJob) * n, hipMemcpyHostToDevice, stream) != hipSuccess ||
-        hipEventRecord(batch->copied[r], stream) != hipSuccess)
-        return JPEGGPU_INTERNAL_ERROR;
-    batch->in_use[r] = true;
     const jg::ScanJob* d_jobs = static_cast<const jg::ScanJob*>(d_scratch);
     std::vector<hipEvent_t>* ev = nullptr;
     if (batch->profiling) {
@@ -791,6 +810,15 @@ enum jpeggpu_status jpeggpu_ext_decode_batch(
         }
         (void)hipEventRecord((*ev)[0], stream);
     }
+    if (hipMemcpyAsync(d_scratch, batch->staging[r], jbytes + fbytes, hipMemcpyHostToDevice, stream) != hipSuccess) return JPEGGPU_INTERNAL_ERROR;
+    if (nf && jg::launch_front_batch(reinterpret_cast<const jg::FrontParams*>(static_cast<const uint8_t*>(d_scratch) + jbytes), nf,
+                                     front_windows, stream) != hipSuccess) {
+        (void)hipGetLastError();
+        return JPEGGPU_INTERNAL_ERROR;
+    }
+    // the staging buffer is free again, and the parts below may start: the job array is complete
+    if (hipEventRecord(batch->copied[r], stream) != hipSuccess) return JPEGGPU_INTERNAL_ERROR;
+    batch->in_use[r] = true;
     // parts of the job array: contiguous, at least 8 jobs each
     int ways = batch->overlap;
     while (ways > 1 && n / ways < 8) --ways;

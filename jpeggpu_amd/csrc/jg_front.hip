@@ -57,6 +57,17 @@ __device__ __forceinline__ uint32_t block_excl_scan(uint32_t v, uint32_t* s_wave
     return off + incl - v;
 }
 
+/// Where a workgroup finds its parameters: one scan by value (the drop-in decode), or entry blockIdx.y of an
+/// array in device memory (a batch).
+struct FrontOne {
+    FrontParams P;
+    __device__ __forceinline__ const FrontParams& get() const { return P; }
+};
+struct FrontMany {
+    const FrontParams* arr;
+    __device__ __forceinline__ FrontParams get() const { return arr[blockIdx.y]; }
+};
+
 /// The 16 bytes of a lane: which are data (byte rule of decode_destuff.cu:37-44), which are the FF right in
 /// front of a marker code (not followed by a stuffed zero nor by a fill byte), and the byte behind the last.
 struct LaneBytes {
@@ -97,8 +108,11 @@ __device__ __forceinline__ LaneBytes classify(const FrontParams& P, uint32_t gpo
 }
 
 /// Pass 1: data bytes and markers per window.
-__global__ __launch_bounds__(256) void front_count(FrontParams P)
+template <class FS>
+__global__ __launch_bounds__(256) void front_count(FS src)
 {
+    const FrontParams P = src.get();
+    if (blockIdx.x >= P.num_windows) return;
     __shared__ uint32_t s_wave[4];
     const uint32_t w  = blockIdx.x;
     const LaneBytes L = classify(P, w * kDestuffWin + threadIdx.x * 16);
@@ -114,8 +128,11 @@ __global__ __launch_bounds__(256) void front_count(FrontParams P)
 /// Pass 2, after the prefix sums over windows: every marker knows its ordinal in the scan; the first
 /// expect_segments + 1 of them are recorded {position, data bytes of the scan in front of it}, and the first
 /// one that is not RSTn -- the end of the scan -- is found with an atomic minimum.
-__global__ __launch_bounds__(256) void front_marks(FrontParams P)
+template <class FS>
+__global__ __launch_bounds__(256) void front_marks(FS src)
 {
+    const FrontParams P = src.get();
+    if (blockIdx.x >= P.num_windows) return;
     __shared__ uint32_t s_wave[4];
     const uint32_t w    = blockIdx.x;
     const uint32_t gpos = w * kDestuffWin + threadIdx.x * 16;
@@ -159,16 +176,20 @@ __device__ uint32_t scan_array(JG_GLOBAL const uint32_t* in, JG_GLOBAL uint32_t*
 }
 
 /// Between the passes: prefix sums over the windows.
-__global__ __launch_bounds__(PL) void front_prefix(FrontParams P)
+template <class FS>
+__global__ __launch_bounds__(PL) void front_prefix(FS src)
 {
+    const FrontParams P = src.get();
     __shared__ uint32_t s_wave[PL / 64];
     scan_array(as_global(P.win_data), as_global(P.win_prefix), P.num_windows, s_wave);
     scan_array(as_global(P.win_nmark), as_global(P.mark_off), P.num_windows, s_wave);
     if (threadIdx.x == 0) as_global(P.status)[7] = 0xFFFFFFFFu; // ordinal of the terminating marker (front_marks)
 }
 
-__global__ __launch_bounds__(PL) void front_plan(FrontParams P)
+template <class FS>
+__global__ __launch_bounds__(PL) void front_plan(FS src)
 {
+    const FrontParams P = src.get();
     __shared__ uint32_t s_wave[PL / 64];
     const uint32_t tid = threadIdx.x;
     const uint32_t Wn = P.num_windows, E = P.expect_segments, SB = P.subseq_bytes;
@@ -303,10 +324,23 @@ __global__ __launch_bounds__(PL) void front_plan(FrontParams P)
 hipError_t launch_front(const FrontParams& P, hipStream_t stream)
 {
     if (P.num_windows == 0) return hipErrorInvalidValue;
-    front_count<<<P.num_windows, 256, 0, stream>>>(P);
-    front_prefix<<<1, PL, 0, stream>>>(P);
-    front_marks<<<P.num_windows, 256, 0, stream>>>(P);
-    front_plan<<<1, PL, 0, stream>>>(P);
+    const FrontOne src{P};
+    front_count<<<P.num_windows, 256, 0, stream>>>(src);
+    front_prefix<<<1, PL, 0, stream>>>(src);
+    front_marks<<<P.num_windows, 256, 0, stream>>>(src);
+    front_plan<<<1, PL, 0, stream>>>(src);
+    return hipGetLastError();
+}
+
+hipError_t launch_front_batch(const FrontParams* d_params, int count, uint32_t max_windows, hipStream_t stream)
+{
+    if (count <= 0 || max_windows == 0) return hipErrorInvalidValue;
+    const FrontMany src{d_params};
+    const dim3 wide(max_windows, static_cast<uint32_t>(count)), one(1, static_cast<uint32_t>(count));
+    front_count<<<wide, 256, 0, stream>>>(src);
+    front_prefix<<<one, PL, 0, stream>>>(src);
+    front_marks<<<wide, 256, 0, stream>>>(src);
+    front_plan<<<one, PL, 0, stream>>>(src);
     return hipGetLastError();
 }
 

@@ -8,7 +8,7 @@
 
 namespace jg {
 
-/// Everything front_windows / front_plan need; all pointers are device memory inside d_tmp.
+/// Everything the front-end kernels need; all pointers are device memory inside d_tmp.
 struct FrontParams {
     const uint8_t* bytes;      // transferred bytes; offset 0 is the origin of the 4 KiB window grid
     uint32_t bytes_len;        // valid bytes
@@ -35,6 +35,8 @@ struct FrontParams {
 };
 
 hipError_t launch_front(const FrontParams& P, hipStream_t stream);
+/// The same for `count` scans whose parameters sit in device memory (grid.y = scan).
+hipError_t launch_front_batch(const FrontParams* d_params, int count, uint32_t max_windows, hipStream_t stream);
 
 } // namespace jg
 

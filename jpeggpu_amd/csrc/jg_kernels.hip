@@ -1190,7 +1190,7 @@ template <class JS>
 hipError_t launch_any(Stage stage, const JS& js, const JobExtent& e, int grid_y, hipStream_t stream)
 {
     switch (stage) {
-    case kStageZero:
+    case kStageFront:
         return hipSuccess; // nothing to clear any more: the write pass emits a symbol stream
     case kStageDestuff:
         if (e.max_chunks == 0) return hipSuccess;

@@ -12,7 +12,7 @@ bool subseq_bytes_supported(int subseq_bytes);
 
 /// Stages of one decode, in launch order (also the indices of jpeggpu_ext_get_stage_ms).
 enum Stage {
-    kStageZero      = 0, // (kept for stable stage indices; nothing is zero-filled any more)
+    kStageFront     = 0, // device-side marker scan (jg_front.hip), launched by the decoder; nothing to launch here
     kStageDestuff   = 1,
     kStageSyncIntra = 2,
     kStageSyncInter = 3, // huff_sync_tail: sequence boundaries + flows the intra kernel left unfinished

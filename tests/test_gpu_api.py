@@ -196,8 +196,9 @@ def test_batch_decode_equals_single(torch_cuda):
     names = names * 3 + list(m.keys())[:12]  # > 32 scans: enough for four concurrent parts (set_overlap)
     keep, entries, refs = [], [], []
     total_scans = 0
-    for name in names:
+    for k, name in enumerate(names):
         dec = jpeggpu_amd.Decoder()
+        dec.set_device_scan(k % 3 == 1)  # a batch may mix host-walked images and images the device scans for markers
         info = dec.parse_header(m[name])
         n, tmp, base, planes = _alloc(torch, dec, info)
         dec.transfer(base, n, 0)
@@ -216,7 +217,8 @@ def test_batch_decode_equals_single(torch_cuda):
                 p.fill_(0xCD)
         batch.decode(scratch.data_ptr(), 0)
         torch.cuda.synchronize()
-        for name, ref, (_, _, planes) in zip(names, refs, keep):
+        for name, ref, (dec, _, planes), ent in zip(names, refs, keep, entries):
+            assert dec.device_status(ent[3], 0) == jpeggpu_amd.Status.SUCCESS
             for c in range(ref.ncomp):
                 assert np.array_equal(planes[c].cpu().numpy(), ref.planes[c]), (name, c, rep)
     # too small a scratch / handle is rejected

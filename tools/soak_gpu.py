@@ -43,6 +43,7 @@ def main():
                                     qmax=int(rng.choice([0, 0, 255, 65535])))
             ref = oracle.decode(data)
             dec = jp.Decoder(sb)
+            dec.set_device_scan(bool(rng.integers(2)))  # batches mix host-walked and device-scanned images
             info = dec.parse_header(data)
             n = dec.get_buffer_size()
             tmp = torch.empty(n + 256, dtype=torch.uint8, device="cuda:0")
