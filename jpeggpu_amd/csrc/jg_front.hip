@@ -15,6 +15,8 @@
 
 #include <hip/hip_runtime.h>
 
+#include "jg_bytes.h"
+
 namespace jg {
 
 namespace {
@@ -68,12 +70,32 @@ struct FrontMany {
     __device__ __forceinline__ FrontParams get() const { return arr[blockIdx.y]; }
 };
 
-/// The 16 bytes of a lane: which are data (byte rule of decode_destuff.cu:37-44), which are the FF right in
-/// front of a marker code (not followed by a stuffed zero nor by a fill byte), and the byte behind the last.
+/// The 16 bytes of a lane, classified four at a time (jg_bytes.h, masks with one bit per byte at bit 7): which
+/// are data (byte rule of decode_destuff.cu:37-44) and which are the FF right in front of a marker code (followed
+/// neither by a stuffed zero nor by a fill byte). Bytes in front of the scan read as 00 -- the byte in front of
+/// the first entropy-coded byte belongs to the scan header, never stuffing, as in the host walk -- and bytes
+/// behind the buffer as FF (never data, never a marker: its code would lie outside); `lead` counts the former,
+/// which the rule takes for data.
 struct LaneBytes {
     uint32_t word[4];
     uint32_t next;
-    uint32_t data_mask, mark_mask;
+    uint32_t data[4], mark[4]; // 0x80 domain
+    uint32_t lead;
+    __device__ __forceinline__ uint32_t data_count() const
+    {
+        return __popc(data[0]) + __popc(data[1]) + __popc(data[2]) + __popc(data[3]) - lead;
+    }
+    __device__ __forceinline__ uint32_t mark_count() const { return __popc(mark[0]) + __popc(mark[1]) + __popc(mark[2]) + __popc(mark[3]); }
+    /// One bit per byte, bit i = byte i.
+    __device__ __forceinline__ uint32_t data_mask() const
+    {
+        const uint32_t m = collapse80(data[0]) | collapse80(data[1]) << 4 | collapse80(data[2]) << 8 | collapse80(data[3]) << 12;
+        return m & ~((1u << lead) - 1u);
+    }
+    __device__ __forceinline__ uint32_t mark_mask() const
+    {
+        return collapse80(mark[0]) | collapse80(mark[1]) << 4 | collapse80(mark[2]) << 8 | collapse80(mark[3]) << 12;
+    }
     __device__ __forceinline__ uint32_t byte_after(int i) const
     {
         return i < 15 ? (word[(i + 1) >> 2] >> (8 * ((i + 1) & 3))) & 0xFFu : next;
@@ -89,20 +111,41 @@ __device__ __forceinline__ LaneBytes classify(const FrontParams& P, uint32_t gpo
         const V4 v = *reinterpret_cast<JG_GLOBAL const V4*>(src + gpos); // the buffer has a spare window behind bytes_len
         L.word[0] = v[0]; L.word[1] = v[1]; L.word[2] = v[2]; L.word[3] = v[3];
     }
-    uint32_t prev = gpos > 0 ? src[gpos - 1] : 0u;
-    L.next        = src[gpos + 16];
-    L.data_mask = L.mark_mask = 0;
+    // neighbours' bytes from the neighbouring lanes; the ends of a wave read them
+    uint32_t prev = __shfl_up(L.word[3] >> 24, 1);
+    L.next        = __shfl_down(L.word[0] & 0xFFu, 1);
+    if (lane_id() == 0) prev = gpos > 0 ? src[gpos - 1] : 0u;
+    if (lane_id() == 63) L.next = src[gpos + 16];
+    L.lead = 0;
+    if (gpos <= P.scan_begin || gpos + 17 > P.bytes_len) { // a lane at one of the two ends of the scan's bytes
+        if (gpos <= P.scan_begin) prev = 0;
+        if (gpos + 16 >= P.bytes_len) L.next = 0xFFu;
+        L.lead = min(P.scan_begin > gpos ? P.scan_begin - gpos : 0u, 16u);
 #pragma unroll
-    for (int i = 0; i < 16; ++i) {
-        const uint32_t b   = (L.word[i >> 2] >> (8 * (i & 3))) & 0xFFu;
-        const uint32_t nx  = L.byte_after(i);
-        const uint32_t pos = gpos + i;
-        const bool in      = pos >= P.scan_begin && pos < P.bytes_len;
-        const bool data    = (prev == 0xFFu && b == 0u) || (prev != 0xFFu && b != 0xFFu);
-        const bool mark    = b == 0xFFu && nx != 0u && nx != 0xFFu && pos + 1 < P.bytes_len; // the code is in the buffer
-        if (in && data) L.data_mask |= 1u << i;
-        if (in && mark) L.mark_mask |= 1u << i;
-        prev = b;
+        for (int j = 0; j < 4; ++j) {
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+                const uint32_t pos = gpos + 4 * j + k;
+                if (pos < P.scan_begin) L.word[j] &= ~(0xFFu << (8 * k));
+                if (pos >= P.bytes_len) L.word[j] |= 0xFFu << (8 * k);
+            }
+        }
+    }
+    uint32_t F[4], Z[4];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        F[j] = bytes_ff(L.word[j]);
+        Z[j] = bytes_zero(L.word[j]);
+    }
+    const uint32_t f_before = prev == 0xFFu ? 0x80000000u : 0u;
+    const uint32_t f_after = L.next == 0xFFu ? 0x80u : 0u, z_after = L.next == 0u ? 0x80u : 0u;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        const uint32_t PF = of_previous_byte(F[j], j ? F[j - 1] : f_before);
+        const uint32_t NF = of_next_byte(F[j], j < 3 ? F[j + 1] : f_after);
+        const uint32_t NZ = of_next_byte(Z[j], j < 3 ? Z[j + 1] : z_after);
+        L.data[j]         = (PF & Z[j]) | (~(PF | F[j]) & kHi80);
+        L.mark[j]         = F[j] & ~(NF | NZ);
     }
     return L;
 }
@@ -117,8 +160,8 @@ __global__ __launch_bounds__(256) void front_count(FS src)
     const uint32_t w  = blockIdx.x;
     const LaneBytes L = classify(P, w * kDestuffWin + threadIdx.x * 16);
     uint32_t total_data = 0, total_mark = 0;
-    block_excl_scan<4>(__popc(L.data_mask), s_wave, total_data);
-    block_excl_scan<4>(__popc(L.mark_mask), s_wave, total_mark);
+    block_excl_scan<4>(L.data_count(), s_wave, total_data);
+    block_excl_scan<4>(L.mark_count(), s_wave, total_mark);
     if (threadIdx.x == 0) {
         as_global(P.win_data)[w]  = total_data;
         as_global(P.win_nmark)[w] = total_mark;
@@ -139,15 +182,16 @@ __global__ __launch_bounds__(256) void front_marks(FS src)
     if (as_global(P.win_nmark)[w] == 0) return;
     const LaneBytes L = classify(P, gpos);
     uint32_t total_data = 0, total_mark = 0;
-    const uint32_t data_before = as_global(P.win_prefix)[w] + block_excl_scan<4>(__popc(L.data_mask), s_wave, total_data);
-    uint32_t ord               = as_global(P.mark_off)[w] + block_excl_scan<4>(__popc(L.mark_mask), s_wave, total_mark);
-    uint32_t m                 = L.mark_mask;
+    const uint32_t data_before = as_global(P.win_prefix)[w] + block_excl_scan<4>(L.data_count(), s_wave, total_data);
+    uint32_t ord               = as_global(P.mark_off)[w] + block_excl_scan<4>(L.mark_count(), s_wave, total_mark);
+    uint32_t m                 = L.mark_mask();
+    const uint32_t data_mask   = L.data_mask();
     while (m) {
         const int i = __ffs(m) - 1;
         m &= m - 1;
         if (ord <= P.expect_segments) {
             as_global(P.mk_pos)[ord] = gpos + i;
-            as_global(P.mk_g)[ord]   = data_before + __popc(L.data_mask & ((1u << i) - 1u));
+            as_global(P.mk_g)[ord]   = data_before + __popc(data_mask & ((1u << i) - 1u));
             const uint32_t code      = L.byte_after(i);
             if (code < 0xD0u || code > 0xD7u) atomicMin(P.status + 7, ord);
         }

@@ -19,6 +19,8 @@
 
 #include <hip/hip_runtime.h>
 
+#include "jg_bytes.h"
+
 namespace jg {
 
 namespace {
@@ -153,20 +155,35 @@ __global__ __launch_bounds__(256) void destuff_kernel(JS js)
     uint32_t prev = __shfl_up(w[3] >> 24, 1);
     if (lane_id() == 0) prev = gpos > 0 ? src[gpos - 1] : 0u;
 
-    uint32_t mask = 0; // bit i: byte i is data
-    uint32_t ffm  = 0; // bit i: byte i is stored as FF
+    // Byte rule on four bytes at a time (jg_bytes.h): F / Z = bytes equal to FF / 00, PF = the byte in front is
+    // FF. A stuffed zero is data and stands for the FF in front of it: the word is patched so that the
+    // compaction below stores plain bytes.
+    uint32_t F[4], Z[4];
 #pragma unroll
-    for (int i = 0; i < 16; ++i) {
-        const uint32_t b   = (w[i >> 2] >> (8 * (i & 3))) & 0xFFu;
-        const uint32_t pos = gpos + i;
-        uint32_t p         = prev;
-        if (ck.first && pos == ck.begin) p = 0; // predecessor is a marker byte, never stuffing
-        const bool in      = pos >= ck.begin && pos < ck.end;
-        const bool stuffed = p == 0xFFu && b == 0u;
-        const bool plain   = p != 0xFFu && b != 0xFFu;
-        if (in && (stuffed || plain)) mask |= 1u << i;
-        if (stuffed) ffm |= 1u << i;
-        prev = b;
+    for (int j = 0; j < 4; ++j) {
+        F[j] = bytes_ff(w[j]);
+        Z[j] = bytes_zero(w[j]);
+    }
+    uint32_t f_before = prev == 0xFFu ? 0x80000000u : 0u;
+    if (ck.first) { // the byte in front of a segment's first byte belongs to a marker: never stuffing
+        const uint32_t d = ck.begin - gpos;
+        if (d == 0) f_before = 0;
+#pragma unroll
+        for (int j = 0; j < 4; ++j)
+            if (d - 1 - 4 * j < 4u) F[j] &= ~(0x80u << (8 * ((d - 1) & 3u))); // that byte lies outside [begin, end)
+    }
+    uint32_t mask = 0; // bit i: byte i is data
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        const uint32_t PF      = of_previous_byte(F[j], j ? F[j - 1] : f_before);
+        const uint32_t stuffed = PF & Z[j];
+        const uint32_t data    = stuffed | (~(PF | F[j]) & kHi80);
+        w[j] |= spread80(stuffed);
+        mask |= collapse80(data) << (4 * j);
+    }
+    {
+        const uint32_t lo = min(max(static_cast<int>(ck.begin - gpos), 0), 16), hi = min(max(static_cast<int>(ck.end - gpos), 0), 16);
+        mask &= ((1u << hi) - 1u) & ~((1u << lo) - 1u);
     }
 
     const uint32_t cnt  = __popc(mask);
@@ -188,8 +205,7 @@ __global__ __launch_bounds__(256) void destuff_kernel(JS js)
 #pragma unroll
         for (int i = 0; i < 16; ++i) {
             if (mask & (1u << i)) {
-                const uint32_t b = (w[i >> 2] >> (8 * (i & 3))) & 0xFFu;
-                s_out[o++]       = static_cast<uint8_t>((ffm >> i) & 1u ? 0xFFu : b);
+                s_out[o++] = static_cast<uint8_t>(w[i >> 2] >> (8 * (i & 3)));
             }
         }
     }
