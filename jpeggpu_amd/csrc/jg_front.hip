@@ -16,6 +16,7 @@
 #include <hip/hip_runtime.h>
 
 #include "jg_bytes.h"
+#include "jg_wave.h"
 
 namespace jg {
 
@@ -26,18 +27,6 @@ template <class T>
 __device__ __forceinline__ JG_GLOBAL T* as_global(T* p)
 {
     return (JG_GLOBAL T*)p;
-}
-
-__device__ __forceinline__ int lane_id() { return threadIdx.x & 63; }
-
-__device__ __forceinline__ uint32_t wave_incl_scan(uint32_t v)
-{
-#pragma unroll
-    for (int d = 1; d < 64; d <<= 1) {
-        const uint32_t o = __shfl_up(v, d);
-        if (lane_id() >= d) v += o;
-    }
-    return v;
 }
 
 /// Exclusive prefix of `v` over the workgroup's NW waves; `total` gets the workgroup sum.

@@ -20,6 +20,7 @@
 #include <hip/hip_runtime.h>
 
 #include "jg_bytes.h"
+#include "jg_wave.h"
 
 namespace jg {
 
@@ -111,18 +112,6 @@ struct JobArray {
     const ScanJob* jobs;
     __device__ __forceinline__ const ScanJob& get() const { return jobs[blockIdx.y]; }
 };
-
-__device__ __forceinline__ int lane_id() { return threadIdx.x & 63; }
-
-__device__ __forceinline__ uint32_t wave_incl_scan(uint32_t v)
-{
-#pragma unroll
-    for (int d = 1; d < 64; d <<= 1) {
-        const uint32_t o = __shfl_up(v, d);
-        if (lane_id() >= d) v += o;
-    }
-    return v;
-}
 
 // ------------------------------------------------------------------------------------------------
 // destuff
