@@ -279,13 +279,16 @@ class Batch:
             pass
 
 
-def decode_to_planes(data: bytes, device="cuda:0", subseq_bytes=None, return_tmp=False):
+def decode_to_planes(data: bytes, device="cuda:0", subseq_bytes=None, return_tmp=False, device_scan=False):
     """Convenience wrapper used by tests: full call sequence on torch's current stream, returns the
-    planes as torch uint8 tensors on `device` (torch is only the allocator / stream provider)."""
+    planes as torch uint8 tensors on `device` (torch is only the allocator / stream provider). With
+    `device_scan` the restart markers are found on the device and a status it reports there is raised."""
     import torch
 
     dec = Decoder(subseq_bytes)
     try:
+        if device_scan:
+            dec.set_device_scan(True)
         info = dec.parse_header(data)
         n = dec.get_buffer_size()
         tmp = torch.empty(n + 256, dtype=torch.uint8, device=device)
@@ -296,6 +299,8 @@ def decode_to_planes(data: bytes, device="cuda:0", subseq_bytes=None, return_tmp
         dec.transfer(base, n, stream)
         dec.decode([p.data_ptr() for p in planes], [p.stride(0) for p in planes], base, n, stream)
         torch.cuda.synchronize(torch.device(device))
+        if device_scan:
+            _check(int(dec.device_status(base, stream)), "device-side marker scan")
         if return_tmp:
             return planes, info, tmp, base, dec.layout()
         return planes, info

@@ -456,10 +456,11 @@ def test_extreme_geometry(torch_cuda):
                          (1, 4099, S444, {}), (40000, 9, ((4, 1), (1, 1), (1, 1)), dict(optimize=True))):
         data = jpegsynth.encode(w, h, ss, seed=w + h, noise=10, **kw)
         ref = oracle.decode(data)
-        planes, info = jpeggpu_amd.decode_to_planes(data)
-        assert (info.sizes_x[0], info.sizes_y[0]) == (w, h)
-        for c in range(ref.ncomp):
-            assert np.array_equal(planes[c].cpu().numpy(), ref.planes[c]), (w, h, c)
+        for device_scan in (False, True):
+            planes, info = jpeggpu_amd.decode_to_planes(data, device_scan=device_scan)
+            assert (info.sizes_x[0], info.sizes_y[0]) == (w, h)
+            for c in range(ref.ncomp):
+                assert np.array_equal(planes[c].cpu().numpy(), ref.planes[c]), (w, h, c, device_scan)
 
 
 @pytest.mark.parametrize("cfg", [2, 4, 5])
@@ -472,7 +473,8 @@ def test_baseline_configs_full_size(torch_cuda, cfg):
 
     data = jpegsynth.config(cfg, seed=5)
     ref = oracle.decode(data)
-    planes, info = jpeggpu_amd.decode_to_planes(data)
-    assert info.num_components == ref.ncomp
-    for c in range(ref.ncomp):
-        assert np.array_equal(planes[c].cpu().numpy(), ref.planes[c]), (cfg, c)
+    for device_scan in (False, True):  # cfg 4 has three scans and keeps the host walk either way
+        planes, info = jpeggpu_amd.decode_to_planes(data, device_scan=device_scan)
+        assert info.num_components == ref.ncomp
+        for c in range(ref.ncomp):
+            assert np.array_equal(planes[c].cpu().numpy(), ref.planes[c]), (cfg, c, device_scan)

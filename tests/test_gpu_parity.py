@@ -110,8 +110,15 @@ def test_reference_photo_full_size(gpu_lib, torch_cuda, photo_bytes):
     """BASELINE config 1/2 input: the reference's own 12 MP photo, bit-exact vs the oracle."""
     from oracle import oracle
 
+    import jpeggpu_amd
+
     ref = oracle.decode(photo_bytes)
     got, info = _decode_gpu(photo_bytes)
     assert list(info.sizes_x)[:3] == [4032, 2016, 2016] and list(info.sizes_y)[:3] == [3024, 1512, 1512]
     for c in range(3):
         assert np.array_equal(got[c], ref.planes[c]), "component %d" % c
+    # the same with the marker scan on the device: the 1.17 MB behind EOI (an embedded second JPEG with its own
+    # markers) must not confuse the search for the end of the scan
+    planes, _ = jpeggpu_amd.decode_to_planes(photo_bytes, device_scan=True)
+    for c in range(3):
+        assert np.array_equal(planes[c].cpu().numpy(), ref.planes[c]), "device scan, component %d" % c
