@@ -209,45 +209,74 @@ JG_HD inline void decode_subsequence(
     int z       = st.z;
     int units   = 0;
     uint32_t dc01 = st.dc01, dc23 = st.dc23;
-    while (true) {
-        const uint32_t peek = bw.peek(fetch);
-        const bool is_dc    = z == 0;
-        const uint8_t* tab  = tabs + (is_dc ? (JG_CUR_TABS & 0xFFFFu) : (JG_CUR_TABS >> 16));
-        const uint32_t idx  = peek >> (is_dc ? 32 - kLutBitsDc : 32 - kLutBitsAc);
-        uint32_t e          = ld_u16(tab + 2 * idx);
-        if ((e & 31u) == 0) e = huff_second_level(tab, e, peek, is_dc);
-        const int total   = e & 31;
-        const bool beyond = p + total > end_bit;
-        if (Sink::kWholeUnits ? (is_dc && (beyond || sink.full())) : beyond) break;
-        bw.skip(total);
-        p += total;
-        const int adv     = e >> 9;
-        const int z1      = z + adv;
-        const bool du_end = z1 >= 64;
-        if (Sink::kWrite) {
-            // branch-free: every lane computes the magnitude, only DC symbols move the sums
-            const int s       = (e >> 5) & 15;
-            const int v       = extend_magnitude(bits_field(peek, total, s), s);
-            const int sh      = JG_CUR_META & 63;
-            const uint64_t d  = static_cast<uint64_t>(is_dc ? static_cast<uint32_t>(v) & 0xFFFFu : 0u) << sh;
-            dc01              = pk_add_u16(dc01, static_cast<uint32_t>(d));
-            dc23              = pk_add_u16(dc23, static_cast<uint32_t>(d >> 32));
-            // the component's running sum is the absolute DC value, 16-bit wrap like the reference's
-            // int16 prefix sum (decode_dc.cu:129-155); an AC coefficient sits at zig-zag index z1 - 1
-            const int absdc   = static_cast<int>(((static_cast<uint64_t>(dc23) << 32) | dc01) >> sh);
-            sink.symbol(is_dc, s != 0, sym_entry(z1 - 1, is_dc ? absdc : v), du_end);
-        } else if (Sink::kSums && is_dc) {
-            const int s      = (e >> 5) & 15;
-            const int v      = extend_magnitude(bits_field(peek, total, s), s);
-            const uint64_t d = static_cast<uint64_t>(static_cast<uint32_t>(v) & 0xFFFFu) << (JG_CUR_META & 63);
-            dc01             = pk_add_u16(dc01, static_cast<uint32_t>(d));
-            dc23             = pk_add_u16(dc23, static_cast<uint32_t>(d >> 32));
+    bool is_dc = z == 0;
+    uint32_t peek, e;
+    int total;
+    // look the symbol under the bit window up: first-level LUT of the unit's DC or AC table, second level if needed
+#define JG_LOOKUP()                                                                                       \
+    do {                                                                                                  \
+        peek               = bw.peek(fetch);                                                              \
+        const uint8_t* tab = tabs + (is_dc ? (JG_CUR_TABS & 0xFFFFu) : (JG_CUR_TABS >> 16));              \
+        const uint32_t idx = peek >> (is_dc ? 32 - kLutBitsDc : 32 - kLutBitsAc);                         \
+        e                  = ld_u16(tab + 2 * idx);                                                       \
+        if ((e & 31u) == 0) e = huff_second_level(tab, e, peek, is_dc);                                   \
+        total = e & 31;                                                                                   \
+    } while (0)
+    // commit the symbol: advance the window and the zig-zag position, feed the sink / the sums, move the cursor
+#define JG_COMMIT()                                                                                       \
+    do {                                                                                                  \
+        bw.skip(total);                                                                                   \
+        p += total;                                                                                       \
+        const int adv     = e >> 9;                                                                       \
+        const int z1      = z + adv;                                                                      \
+        const bool du_end = z1 >= 64;                                                                     \
+        if (Sink::kWrite) {                                                                               \
+            /* branch-free: every lane computes the magnitude, only DC symbols move the sums */          \
+            const int s      = (e >> 5) & 15;                                                             \
+            const int v      = extend_magnitude(bits_field(peek, total, s), s);                           \
+            const int sh     = JG_CUR_META & 63;                                                          \
+            const uint64_t d = static_cast<uint64_t>(is_dc ? static_cast<uint32_t>(v) & 0xFFFFu : 0u) << sh; \
+            dc01             = pk_add_u16(dc01, static_cast<uint32_t>(d));                                \
+            dc23             = pk_add_u16(dc23, static_cast<uint32_t>(d >> 32));                          \
+            /* the component's running sum is the absolute DC value, 16-bit wrap like the reference's   \
+               int16 prefix sum (decode_dc.cu:129-155); an AC coefficient sits at zig-zag index z1 - 1 */ \
+            const int absdc = static_cast<int>(((static_cast<uint64_t>(dc23) << 32) | dc01) >> sh);       \
+            sink.symbol(is_dc, s != 0, sym_entry(z1 - 1, is_dc ? absdc : v), du_end);                     \
+        } else if (Sink::kSums && is_dc) {                                                                \
+            const int s      = (e >> 5) & 15;                                                             \
+            const int v      = extend_magnitude(bits_field(peek, total, s), s);                           \
+            const uint64_t d = static_cast<uint64_t>(static_cast<uint32_t>(v) & 0xFFFFu) << (JG_CUR_META & 63); \
+            dc01             = pk_add_u16(dc01, static_cast<uint32_t>(d));                                \
+            dc23             = pk_add_u16(dc23, static_cast<uint32_t>(d >> 32));                          \
+        }                                                                                                 \
+        z = du_end ? 0 : z1;                                                                              \
+        if (Sink::kWrite || Sink::kSums) units += du_end ? 1 : 0;                                         \
+        cur = JG_LOAD_CURSOR(du_end ? JG_CUR_NEXT : JG_CUR_SELF);                                         \
+        if (Sink::kWrite) sink.tick(); /* once per iteration, whatever the symbol was */                  \
+        is_dc = du_end;                /* a unit just ended <=> the next symbol is a DC symbol */         \
+    } while (0)
+    if (Sink::kWrite) {
+        // test at the top: measured 5 % faster for the emitting pass than the rotated form below
+        while (true) {
+            JG_LOOKUP();
+            const bool beyond = p + total > end_bit;
+            if (Sink::kWholeUnits ? (is_dc && (beyond || sink.full())) : beyond) break;
+            JG_COMMIT();
         }
-        z = du_end ? 0 : z1;
-        if (Sink::kWrite || Sink::kSums) units += du_end ? 1 : 0;
-        cur = JG_LOAD_CURSOR(du_end ? JG_CUR_NEXT : JG_CUR_SELF);
-        if (Sink::kWrite) sink.tick(); // once per iteration, whatever the symbol was
+    } else {
+        // State-only passes: the loop is written rotated -- look the next symbol up at the END of the body, test it
+        // in the loop condition -- so that the compiler emits one compare and one conditional back edge for "does
+        // the symbol still fit" instead of an exit mask plus a guarded region (two compares of the same operands):
+        // -6 % for the sync kernels. In both forms the DC / AC choice of a symbol is the unit-end flag of the one
+        // before it, not a compare of z with 0.
+        JG_LOOKUP();
+        while (p + total <= end_bit) {
+            JG_COMMIT();
+            JG_LOOKUP();
+        }
     }
+#undef JG_LOOKUP
+#undef JG_COMMIT
     if (Sink::kWrite || Sink::kSums) st.n += 64 * units + z - st.z;
     st.p    = p;
     st.z    = z;
