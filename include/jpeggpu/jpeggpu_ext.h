@@ -43,7 +43,8 @@ struct jpeggpu_ext_scan_layout {
     size_t off_segments;       /* {int subseq_offset, subseq_count}[num_segments] */
     size_t off_chunks;
     size_t off_destuffed;      /* uint8[num_subsequences * subsequence_bytes], TILED: 32-bit word k of subsequence t
-                                  is word (t / 32) * 32 * W + k * 32 + t % 32, W = subsequence_bytes / 4 */
+                                  is word (t / 32) * 32 * W + k * 32 + t % 32, W = subsequence_bytes / 4; a word holds
+                                  its four stream bytes most significant first (stream byte i is byte 3 - i % 4) */
     size_t off_segment_index;  /* int[num_subsequences] */
     size_t off_state_p;        /* int[num_subsequences] */
     size_t off_state_n;

@@ -47,37 +47,38 @@ JG_HD inline uint32_t pk_add_u16(uint32_t a, uint32_t b)
 #endif
 }
 
-/// MSB-first 64-bit window over big-endian 32-bit words. A `Fetch` provides `raw(w)`, which issues the
-/// load of word `w` of the segment's destuffed data, and `cook(raw, w)`, which turns the loaded value
-/// into the big-endian word (zero past the segment's padded end, reference
-/// decode_huffman_reader.hpp:110-152). `next_raw` always holds raw(widx), fetched one refill before it
-/// is cooked and shifted in: nothing touches the loaded value in between, so the load's latency is
-/// covered by the symbols decoded meanwhile.
+/// MSB-first 64-bit window over 32-bit words of the segment's destuffed data. A `Fetch` walks the words in
+/// order: `start(w)` gives the position of word `w`, `load(pos)` issues the load, `advance(pos)` steps to the
+/// next word, and `cook(raw, pos)` turns the loaded value into the word as the window wants it (zero past the
+/// segment's padded end, reference decode_huffman_reader.hpp:110-152). `next_raw` always holds the word at
+/// `pos`, fetched one refill before it is cooked and shifted in: nothing touches the loaded value in between,
+/// so the load's latency is covered by the symbols decoded meanwhile.
 template <class Fetch>
 struct BitWindow {
     uint64_t win;
     int avail;
-    int widx;
+    typename Fetch::Pos pos;
     uint32_t next_raw;
 
     JG_HD inline void seek(int p, const Fetch& fetch)
     {
-        const int w       = p >> 5;
-        const int off     = p & 31;
-        const uint32_t hi = fetch.cook(fetch.raw(w), w);
-        const uint32_t lo = fetch.cook(fetch.raw(w + 1), w + 1);
-        win               = ((static_cast<uint64_t>(hi) << 32) | lo) << off;
-        avail             = 64 - off;
-        widx              = w + 2;
-        next_raw          = fetch.raw(widx);
+        const int off = p & 31;
+        pos           = fetch.start(p >> 5);
+        const uint32_t hi = fetch.cook(fetch.load(pos), pos);
+        fetch.advance(pos);
+        const uint32_t lo = fetch.cook(fetch.load(pos), pos);
+        fetch.advance(pos);
+        win      = ((static_cast<uint64_t>(hi) << 32) | lo) << off;
+        avail    = 64 - off;
+        next_raw = fetch.load(pos);
     }
     JG_HD inline uint32_t peek(const Fetch& fetch)
     {
         if (avail < 32) {
-            win |= static_cast<uint64_t>(fetch.cook(next_raw, widx)) << (32 - avail);
+            win |= static_cast<uint64_t>(fetch.cook(next_raw, pos)) << (32 - avail);
             avail += 32;
-            ++widx;
-            next_raw = fetch.raw(widx);
+            fetch.advance(pos);
+            next_raw = fetch.load(pos);
         }
         return static_cast<uint32_t>(win >> 32);
     }

@@ -210,14 +210,14 @@ __global__ __launch_bounds__(256) void destuff_kernel(JS js)
         const uint32_t b0 = g * 4;
         const uint32_t tw = tiled_word(word0 + g, log2w);
         if (b0 >= lo && b0 + 4 <= hi) {
-            dst32[tw] = *reinterpret_cast<const uint32_t*>(s_out + b0);
+            dst32[tw] = __builtin_bswap32(*reinterpret_cast<const uint32_t*>(s_out + b0)); // most significant byte first
         } else {
-            for (uint32_t b = b0 > lo ? b0 : lo; b < b0 + 4 && b < hi; ++b) dst[tw * 4 + (b & 3)] = s_out[b];
+            for (uint32_t b = b0 > lo ? b0 : lo; b < b0 + 4 && b < hi; ++b) dst[tw * 4 + (3u - (b & 3))] = s_out[b];
         }
     }
     // zero the tail of the segment up to its subsequence-aligned end
     if (ck.pad_end) {
-        for (uint32_t b = ck.dst_off + total + t; b < ck.pad_end; b += 256) dst[tiled_word(b >> 2, log2w) * 4 + (b & 3)] = 0;
+        for (uint32_t b = ck.dst_off + total + t; b < ck.pad_end; b += 256) dst[tiled_word(b >> 2, log2w) * 4 + (3u - (b & 3))] = 0;
     }
     // subsequences that start inside this chunk's destination range belong to this segment
     if (total) {
@@ -231,17 +231,23 @@ __global__ __launch_bounds__(256) void destuff_kernel(JS js)
 // Huffman: bitstream access
 // ------------------------------------------------------------------------------------------------
 
-/// Words of the tiled destuffed buffer (jg_defs.h). raw() only issues the load (address clamped into
-/// the segment); the byte swap and the zero-beyond-the-end select (reference
-/// decode_huffman_reader.hpp:110-152) happen in cook(), when the word is shifted into the window one
-/// refill later -- a select right behind the load would wait for it. The lanes of a wave walk
+/// Words of the tiled destuffed buffer (jg_defs.h); destuff_kernel stores every word most significant byte
+/// first, so a loaded word goes into the bit window as it is. load() only issues the load; the zero-beyond-the-
+/// end select (reference decode_huffman_reader.hpp:110-152) happens in cook(), when the word is shifted into
+/// the window one refill later -- a select right behind the load would wait for it. The lanes of a wave walk
 /// neighbouring subsequences at about the same pace, so their refills share 128-byte lines and hit L1;
 /// nothing is staged in LDS, which keeps eight workgroups of the sync kernel on a CU.
-/// kExact = false (state-only passes): no clamp into the segment and no zeros behind its end. A lane never
-/// commits a symbol that uses a bit past `end_bit` <= the segment's end, and whether a symbol does is
-/// decided by the bits before it (prefix code), so what lies behind the end cannot change p, c, z, n or the
-/// DC sums. The window reads at most word (end_bit / 32) + 3, i.e. the first words of the following
-/// subsequence slot, which the buffer always has (jg_decoder.cpp rounds it up to whole tiles past S).
+///
+/// kExact = true (write pass): word index clamped into the segment, zeros behind its end.
+/// kExact = false (state-only passes): no clamp and no zeros. A lane never commits a symbol that uses a bit past
+/// `end_bit` <= the segment's end, and whether a symbol does is decided by the bits before it (prefix code), so
+/// what lies behind the end cannot change p, c, z, n or the DC sums. The window reads at most word
+/// (end_bit / 32) + 3, i.e. the first words of the following subsequence slot, which the buffer always has
+/// (jg_decoder.cpp rounds it up to whole tiles past S). The position is kept as two running byte offsets
+/// (4 and 128 times the linear word index): a wave executes the refill block in nearly every iteration of the
+/// symbol loop -- some lane always needs a word -- so its address arithmetic is paid per symbol, and the tiled
+/// offset from those two is three ANDs, a shift and an OR3 on the fast integer path instead of the shifts,
+/// bit-field extract and 64-bit add of tiled_word().
 template <int W, bool kExact = true>
 struct GlobalFetch {
     static constexpr int kLog2W = W == 8 ? 3 : W == 16 ? 4 : W == 32 ? 5 : 6;
@@ -249,15 +255,35 @@ struct GlobalFetch {
     JG_GLOBAL const uint32_t* scan32; // the scan's destuffed buffer (tiled): the same for every lane (scalar base address)
     int seg_word0;          // first (linear) word of the lane's segment
     int seg_words;
-    __device__ __forceinline__ uint32_t raw(int w) const
+    struct Pos {
+        int w;                  // word of the segment (kExact)
+        uint32_t lw4, lw128;    // 4 x and 128 x the linear word index in the scan (!kExact); the latter may wrap, only its low bits count
+    };
+    __device__ __forceinline__ Pos start(int w) const
     {
-        const int lw = seg_word0 + (kExact ? min(w, seg_words - 1) : w);
-        return scan32[tiled_word(static_cast<uint32_t>(lw), kLog2W)];
+        const uint32_t lw = static_cast<uint32_t>(seg_word0 + w);
+        return Pos{w, lw * 4u, lw * 128u};
     }
-    __device__ __forceinline__ uint32_t cook(uint32_t v, int w) const
+    __device__ __forceinline__ void advance(Pos& q) const
     {
-        return !kExact || w < seg_words ? __builtin_bswap32(v) : 0u;
+        if (kExact) {
+            ++q.w;
+        } else {
+            q.lw4 += 4u;
+            q.lw128 += 128u;
+        }
     }
+    __device__ __forceinline__ uint32_t load(const Pos& q) const
+    {
+        if (kExact) {
+            const int lw = seg_word0 + min(q.w, seg_words - 1);
+            return scan32[tiled_word(static_cast<uint32_t>(lw), kLog2W)];
+        }
+        // byte offset of tiled_word(lw): tile | word within the subsequence | subsequence within the tile
+        const uint32_t off = (q.lw4 & ~(128u * W - 1u)) | (q.lw128 & ((W - 1u) << 7)) | ((q.lw4 >> kLog2W) & (31u << 2));
+        return *reinterpret_cast<JG_GLOBAL const uint32_t*>(reinterpret_cast<JG_GLOBAL const uint8_t*>(scan32) + off);
+    }
+    __device__ __forceinline__ uint32_t cook(uint32_t v, const Pos& q) const { return !kExact || q.w < seg_words ? v : 0u; }
 };
 
 /// Copy the scan's Huffman table pack (a multiple of 16 bytes) into LDS.

@@ -19,13 +19,16 @@ namespace {
 struct HostFetch {
     const uint8_t* seg; // first byte of the segment in the destuffed buffer
     int seg_words;
-    uint32_t raw(int w) const
+    typedef int Pos; // word of the segment
+    Pos start(int w) const { return w; }
+    void advance(Pos& q) const { ++q; }
+    uint32_t load(const Pos& w) const
     {
         if (w >= seg_words) return 0;
         const uint8_t* p = seg + static_cast<size_t>(w) * 4;
         return static_cast<uint32_t>(p[0]) << 24 | p[1] << 16 | p[2] << 8 | p[3];
     }
-    uint32_t cook(uint32_t v, int) const { return v; }
+    uint32_t cook(uint32_t v, const Pos&) const { return v; }
 };
 
 /// Host twin of the write pass's sink (StreamSink in jg_kernels.hip): symbol stream + data-unit table.

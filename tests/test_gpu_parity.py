@@ -65,10 +65,11 @@ def test_stage_parity(gpu_lib, torch_cuda, inputs, name, subseq_bytes):
         tw = oracle.scan_stages(data, s, subseq_bytes)
         S = sl.num_subsequences
         assert S == tw.num_subseq and sl.num_segments == tw.num_segments and sl.num_data_units == tw.num_du
-        # the device keeps the destuffed bytes in tiles of 32 subsequences, word-major (jpeggpu_ext.h)
+        # the device keeps the destuffed bytes in tiles of 32 subsequences, word-major, every 32-bit word most
+        # significant byte first (jpeggpu_ext.h)
         W, tiles = subseq_bytes // 4, (S + 31) // 32
         tiled = _tmp_view(torch, tmp, base, sl.off_destuffed, tiles * 32 * subseq_bytes, torch.uint8)
-        dst = tiled.reshape(tiles, W, 32, 4).transpose(0, 2, 1, 3).reshape(-1)[:S * subseq_bytes]
+        dst = tiled.reshape(tiles, W, 32, 4)[..., ::-1].transpose(0, 2, 1, 3).reshape(-1)[:S * subseq_bytes]
         assert np.array_equal(dst, tw.destuffed), "destuffed bytes"
         seg = _tmp_view(torch, tmp, base, sl.off_segment_index, S, torch.int32)
         assert np.array_equal(seg, tw.seg_index), "segment index"
