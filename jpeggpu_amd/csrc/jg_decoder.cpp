@@ -159,7 +159,7 @@ void Decoder::make_plan()
         const size_t S = static_cast<size_t>(sc.num_subseq);
         sp.num_seq     = static_cast<int>((S + kSeqSubseq - 1) / kSeqSubseq);
         sp.destuffed   = o;
-        o += align_up((S + kTileSubseq) / kTileSubseq * kTileSubseq * subseq_bytes + 256, 256); // whole tiles
+        o += align_up((S + 2 * kTileSubseq) / kTileSubseq * kTileSubseq * subseq_bytes + 256, 256); // whole tiles, more than one spare
         sp.seg_idx = o;
         o += align_up(S * 4, 256);
         sp.st_p = o;

@@ -49,8 +49,9 @@ JG_HD inline uint32_t pk_add_u16(uint32_t a, uint32_t b)
 
 /// MSB-first 64-bit window over 32-bit words of the segment's destuffed data. A `Fetch` walks the words in
 /// order: `start(w)` gives the position of word `w`, `load(pos)` issues the load, `advance(pos)` steps to the
-/// next word, and `cook(raw, pos)` turns the loaded value into the word as the window wants it (zero past the
-/// segment's padded end, reference decode_huffman_reader.hpp:110-152). `next_raw` always holds the word at
+/// next word, and `cook(raw, pos)` turns the loaded value into the word as the window wants it (the host twin
+/// reads zero past the segment's padded end as the reference does, decode_huffman_reader.hpp:110-152; the device
+/// fetch does not need to, see GlobalFetch). `next_raw` always holds the word at
 /// `pos`, fetched one refill before it is cooked and shifted in: nothing touches the loaded value in between,
 /// so the load's latency is covered by the symbols decoded meanwhile.
 template <class Fetch>

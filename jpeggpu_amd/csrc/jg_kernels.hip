@@ -232,58 +232,50 @@ __global__ __launch_bounds__(256) void destuff_kernel(JS js)
 // ------------------------------------------------------------------------------------------------
 
 /// Words of the tiled destuffed buffer (jg_defs.h); destuff_kernel stores every word most significant byte
-/// first, so a loaded word goes into the bit window as it is. load() only issues the load; the zero-beyond-the-
-/// end select (reference decode_huffman_reader.hpp:110-152) happens in cook(), when the word is shifted into
-/// the window one refill later -- a select right behind the load would wait for it. The lanes of a wave walk
-/// neighbouring subsequences at about the same pace, so their refills share 128-byte lines and hit L1;
-/// nothing is staged in LDS, which keeps eight workgroups of the sync kernel on a CU.
+/// first, so a loaded word goes into the bit window as it is, one refill after its load was issued. The lanes of
+/// a wave walk neighbouring subsequences at about the same pace, so their refills share 128-byte lines and hit
+/// L1; nothing is staged in LDS, which keeps eight workgroups of the sync kernel on a CU.
 ///
-/// kExact = true (write pass): word index clamped into the segment, zeros behind its end.
-/// kExact = false (state-only passes): no clamp and no zeros. A lane never commits a symbol that uses a bit past
-/// `end_bit` <= the segment's end, and whether a symbol does is decided by the bits before it (prefix code), so
-/// what lies behind the end cannot change p, c, z, n or the DC sums. The window reads at most word
-/// (end_bit / 32) + 3, i.e. the first words of the following subsequence slot, which the buffer always has
-/// (jg_decoder.cpp rounds it up to whole tiles past S). The position is kept as two running byte offsets
-/// (4 and 128 times the linear word index): a wave executes the refill block in nearly every iteration of the
-/// symbol loop -- some lane always needs a word -- so its address arithmetic is paid per symbol, and the tiled
-/// offset from those two is three ANDs, a shift and an OR3 on the fast integer path instead of the shifts,
-/// bit-field extract and 64-bit add of tiled_word().
-template <int W, bool kExact = true>
+/// Reads are not clamped into the segment and nothing is zeroed behind its end (the reference's reader does
+/// both, decode_huffman_reader.hpp:110-152). A lane never commits a symbol that uses a bit past the end of its
+/// segment on a valid stream -- whether a symbol still fits is decided by the bits in front of it (prefix
+/// code), and the write pass stops at the segment's data-unit quota -- so what lies behind the end cannot
+/// change p, c, z, n, the DC sums or an emitted coefficient. On a corrupt stream a lane of the write pass may
+/// run up to one data unit (64 symbols of at most 27 bits: 54 words, plus the window's 3) past its
+/// subsequence: the buffer carries more than one spare tile of subsequence slots behind the last one
+/// (jg_decoder.cpp), whatever they hold.
+///
+/// The position is kept as two running byte offsets (4 and 128 times the linear word index): a wave executes
+/// the refill block in nearly every iteration of the symbol loop -- some lane always needs a word -- so its
+/// address arithmetic is paid per symbol, and the tiled offset from those two is three ANDs, a shift and an
+/// OR3, mostly on the fast integer path, instead of the shifts, bit-field extract and 64-bit add
+/// of tiled_word().
+template <int W>
 struct GlobalFetch {
     static constexpr int kLog2W = W == 8 ? 3 : W == 16 ? 4 : W == 32 ? 5 : 6;
     static_assert((1 << kLog2W) == W, "subsequence words must be 8, 16, 32 or 64");
     JG_GLOBAL const uint32_t* scan32; // the scan's destuffed buffer (tiled): the same for every lane (scalar base address)
-    int seg_word0;          // first (linear) word of the lane's segment
-    int seg_words;
+    int seg_word0;                    // first (linear) word of the lane's segment
     struct Pos {
-        int w;                  // word of the segment (kExact)
-        uint32_t lw4, lw128;    // 4 x and 128 x the linear word index in the scan (!kExact); the latter may wrap, only its low bits count
+        uint32_t lw4, lw128; // 4 x and 128 x the linear word index in the scan; the latter may wrap, only its low bits count
     };
     __device__ __forceinline__ Pos start(int w) const
     {
         const uint32_t lw = static_cast<uint32_t>(seg_word0 + w);
-        return Pos{w, lw * 4u, lw * 128u};
+        return Pos{lw * 4u, lw * 128u};
     }
     __device__ __forceinline__ void advance(Pos& q) const
     {
-        if (kExact) {
-            ++q.w;
-        } else {
-            q.lw4 += 4u;
-            q.lw128 += 128u;
-        }
+        q.lw4 += 4u;
+        q.lw128 += 128u;
     }
     __device__ __forceinline__ uint32_t load(const Pos& q) const
     {
-        if (kExact) {
-            const int lw = seg_word0 + min(q.w, seg_words - 1);
-            return scan32[tiled_word(static_cast<uint32_t>(lw), kLog2W)];
-        }
         // byte offset of tiled_word(lw): tile | word within the subsequence | subsequence within the tile
         const uint32_t off = (q.lw4 & ~(128u * W - 1u)) | (q.lw128 & ((W - 1u) << 7)) | ((q.lw4 >> kLog2W) & (31u << 2));
         return *reinterpret_cast<JG_GLOBAL const uint32_t*>(reinterpret_cast<JG_GLOBAL const uint8_t*>(scan32) + off);
     }
-    __device__ __forceinline__ uint32_t cook(uint32_t v, const Pos& q) const { return !kExact || q.w < seg_words ? v : 0u; }
+    __device__ __forceinline__ uint32_t cook(uint32_t v, const Pos&) const { return v; }
 };
 
 /// Copy the scan's Huffman table pack (a multiple of 16 bytes) into LDS.
@@ -345,8 +337,8 @@ __global__ __launch_bounds__(T) void huff_sync_intra(JS js)
     const int sub       = img_first + t;
     const bool active   = sub >= 0 && t < img_end;
     LaneState st{};
-    BitWindow<GlobalFetch<W, false>> bw{};
-    GlobalFetch<W, false> fetch{reinterpret_cast<JG_GLOBAL const uint32_t*>(J.destuffed), 0, 1};
+    BitWindow<GlobalFetch<W>> bw{};
+    GlobalFetch<W> fetch{reinterpret_cast<JG_GLOBAL const uint32_t*>(J.destuffed), 0};
     Segment seg{0, 0};
     int rel = 0;
     if (active) {
@@ -354,7 +346,6 @@ __global__ __launch_bounds__(T) void huff_sync_intra(JS js)
         seg             = ld_global(J.segments + J.seg_idx[sub]);
         rel             = sub - seg.subseq_offset;
         fetch.seg_word0 = seg.subseq_offset * W;
-        fetch.seg_words = seg.subseq_count * W;
         st.p            = rel * kBits;
         bw.seek(st.p, fetch);
         if (JS::kSpeculateStateOnly) {
@@ -385,7 +376,6 @@ __global__ __launch_bounds__(T) void huff_sync_intra(JS js)
             seg             = ld_global(J.segments + J.seg_idx[sub_j]);
             rel             = -1;
             fetch.seg_word0 = seg.subseq_offset * W;
-            fetch.seg_words = seg.subseq_count * W;
             st              = LaneState{};
             bw.seek(0, fetch);
         }
@@ -526,12 +516,12 @@ __global__ __launch_bounds__(TL) void huff_sync_tail(JS js)
                 const Segment seg = ld_global(J.segments + J.seg_idx[j - 1]);
                 const int lim     = seg.subseq_offset + seg.subseq_count;
                 if (j < lim) {
-                    GlobalFetch<W, false> fetch{scan32, seg.subseq_offset * W, seg.subseq_count * W};
+                    GlobalFetch<W> fetch{scan32, seg.subseq_offset * W};
                     LaneState st{};
                     st.p = p;
                     st.c = cz & 0xFF;
                     st.z = cz >> 8;
-                    BitWindow<GlobalFetch<W, false>> bw{};
+                    BitWindow<GlobalFetch<W>> bw{};
                     bw.seek(st.p, fetch);
                     decode_subsequence(st, bw, fetch, (j - seg.subseq_offset + 1) * (W * 32), s_tab, sp, sink);
                     p        = st.p;
@@ -861,7 +851,7 @@ __global__ __launch_bounds__(T) void huff_write(JS js)
         st.z         = cz >> 8;
     }
     sink.started = st.z == 0;
-    GlobalFetch<W> fetch{reinterpret_cast<JG_GLOBAL const uint32_t*>(J.destuffed), seg.subseq_offset * W, seg.subseq_count * W};
+    GlobalFetch<W> fetch{reinterpret_cast<JG_GLOBAL const uint32_t*>(J.destuffed), seg.subseq_offset * W};
     BitWindow<GlobalFetch<W>> bw{};
     bw.seek(st.p, fetch);
     decode_subsequence(st, bw, fetch, (rel + 1) * (W * 32), s_tab, sp, sink);
