@@ -463,6 +463,23 @@ def test_extreme_geometry(torch_cuda):
                 assert np.array_equal(planes[c].cpu().numpy(), ref.planes[c]), (w, h, c, device_scan)
 
 
+def test_dense_restart_markers_full_size(torch_cuda):
+    """A restart marker behind every MCU of a 12 MP image (47 628 segments of ~36 bytes) and behind every second
+    MCU of a 48 MP one (93 750 segments): host walk and device-side marker scan, bit-exact vs the oracle."""
+    import jpeggpu_amd
+    from oracle import oracle
+    from tools import jpegsynth
+
+    S420 = ((2, 2), (1, 1), (1, 1))
+    for w, h, dri in ((4032, 3024, 1), (8000, 6000, 2)):
+        data = jpegsynth.encode(w, h, S420, restart_interval=dri, quality=80, noise=6, seed=w + dri)
+        ref = oracle.decode(data)
+        for device_scan in (False, True):
+            planes, _ = jpeggpu_amd.decode_to_planes(data, device_scan=device_scan)
+            for c in range(3):
+                assert np.array_equal(planes[c].cpu().numpy(), ref.planes[c]), (w, h, dri, c, device_scan)
+
+
 @pytest.mark.parametrize("cfg", [2, 4, 5])
 def test_baseline_configs_full_size(torch_cuda, cfg):
     """BASELINE.json configs 2, 4 (39 MP, three non-interleaved scans) and 5 (4 components, 4+4
