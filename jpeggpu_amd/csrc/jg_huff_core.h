@@ -90,19 +90,33 @@ struct BitWindow {
     }
 };
 
-JG_HD inline uint32_t ld_u16(const uint8_t* p) { return *reinterpret_cast<const uint16_t*>(p); }
+/// Pointers into the scan's table pack. On the device the pack lives in LDS and the offsets a kernel hands to the
+/// symbol loop (cursor ring position, and the offsets inside the cursor entries, which the kernel patches after
+/// loading the pack) are absolute LDS addresses: an address is then a register as it stands, where `base + offset`
+/// costs a VALU add per table access -- the base of dynamic LDS is a link-time symbol the compiler does not fold.
+/// Only the kernels' translation unit asks for this (JG_TABS_IN_LDS); the parser builds tables with plain pointers.
+#if defined(JG_TABS_IN_LDS)
+#define JG_TAB_AS __attribute__((address_space(3)))
+#define JG_TAB_AT(tabs, off) (reinterpret_cast<::jg::TabPtr>(static_cast<uintptr_t>(static_cast<uint32_t>(off))))
+#else
+#define JG_TAB_AS
+#define JG_TAB_AT(tabs, off) ((tabs) + (off))
+#endif
+typedef JG_TAB_AS const uint8_t* TabPtr;
+
+JG_HD inline uint32_t ld_u16(TabPtr p) { return *reinterpret_cast<JG_TAB_AS const uint16_t*>(p); }
 
 /// Code longer than the first-level LUT: find its length by counting thresholds (all eight
 /// thresholds come from one 16-byte read), then one huffval read. Reproduces the reference's
 /// `get_category` (src/decode_huffman.cu:167-194): the 16-bit candidate always accepts and the
 /// huffval index is reduced modulo 256, so an invalid code still consumes 9..16 bits.
-JG_HD inline uint32_t huff_long_code(const uint8_t* aux, uint32_t peek, bool is_dc)
+JG_HD inline uint32_t huff_long_code(TabPtr aux, uint32_t peek, bool is_dc)
 {
     const uint32_t v = peek >> 16;
     int l            = 9;
 #if defined(__HIP_DEVICE_COMPILE__)
     typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
-    const u32x4 lim = *reinterpret_cast<const u32x4*>(aux); // one 16-byte LDS read
+    const u32x4 lim = *reinterpret_cast<JG_TAB_AS const u32x4*>(aux); // one 16-byte LDS read
 #pragma unroll
     for (int j = 0; j < 7; ++j) l += v >= ((lim[j >> 1] >> (16 * (j & 1))) & 0xFFFFu) ? 1 : 0;
 #else
@@ -116,10 +130,10 @@ JG_HD inline uint32_t huff_long_code(const uint8_t* aux, uint32_t peek, bool is_
 
 /// First-level entry without a length: second-level table if the host built one for this prefix,
 /// else the long-code path.
-JG_HD inline uint32_t huff_second_level(const uint8_t* tab, uint32_t e, uint32_t peek, bool is_dc)
+JG_HD inline uint32_t huff_second_level(TabPtr tab, uint32_t e, uint32_t peek, bool is_dc)
 {
     const int lb       = is_dc ? kLutBitsDc : kLutBitsAc;
-    const uint8_t* aux = tab + (is_dc ? (2 << kLutBitsDc) : (2 << kLutBitsAc));
+    const TabPtr aux   = tab + (is_dc ? (2 << kLutBitsDc) : (2 << kLutBitsAc));
     if (e != 0) {
         const uint32_t i2 = (peek >> (32 - kSubBits - lb)) & ((1u << kSubBits) - 1u);
         e                 = ld_u16(aux + kHuffAuxSize - kSubTableSize + (e >> 5) * kSubTableSize + 2 * i2);
@@ -193,7 +207,7 @@ JG_HD inline void decode_subsequence(
 {
 #if defined(__HIP_DEVICE_COMPILE__)
     typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
-#define JG_LOAD_CURSOR(off) (*reinterpret_cast<const u32x4*>(tabs + (off)))
+#define JG_LOAD_CURSOR(off) (*reinterpret_cast<JG_TAB_AS const u32x4*>(JG_TAB_AT(tabs, off)))
     u32x4 cur = JG_LOAD_CURSOR(sp.cursor_off + 16u * static_cast<uint32_t>(st.c));
 #define JG_CUR_TABS cur[0]
 #define JG_CUR_META cur[1]
@@ -218,7 +232,7 @@ JG_HD inline void decode_subsequence(
 #define JG_LOOKUP()                                                                                       \
     do {                                                                                                  \
         peek               = bw.peek(fetch);                                                              \
-        const uint8_t* tab = tabs + (is_dc ? (JG_CUR_TABS & 0xFFFFu) : (JG_CUR_TABS >> 16));              \
+        const TabPtr tab   = JG_TAB_AT(tabs, is_dc ? (JG_CUR_TABS & 0xFFFFu) : (JG_CUR_TABS >> 16));      \
         const uint32_t idx = peek >> (is_dc ? 32 - kLutBitsDc : 32 - kLutBitsAc);                         \
         e                  = ld_u16(tab + 2 * idx);                                                       \
         if ((e & 31u) == 0) e = huff_second_level(tab, e, peek, is_dc);                                   \

@@ -14,6 +14,7 @@
 // images, which is what fills 256 CUs). The destuffed bitstream is kept in tiles of 32 subsequences,
 // word-major (jg_defs.h), so that the 64 lanes of a wave, each walking its own subsequence, share cache
 // lines; nothing but the Huffman tables and a small write-combining ring lives in LDS.
+#define JG_TABS_IN_LDS 1 // table offsets handed to the symbol loop are absolute LDS addresses (jg_huff_core.h)
 #include "jg_huff_core.h"
 #include "jg_kernels.hpp"
 
@@ -278,12 +279,30 @@ struct GlobalFetch {
     __device__ __forceinline__ uint32_t cook(uint32_t v, const Pos&) const { return v; }
 };
 
-/// Copy the scan's Huffman table pack (a multiple of 16 bytes) into LDS.
-__device__ __forceinline__ void load_tables(uint8_t* s_tab, JG_GLOBAL const uint8_t* __restrict__ g_tab, uint32_t bytes)
+/// LDS address of a pointer into the workgroup's shared memory.
+__device__ __forceinline__ uint32_t lds_address(const void* p)
+{
+    return static_cast<uint32_t>(reinterpret_cast<uintptr_t>((const __attribute__((address_space(3))) uint8_t*)p));
+}
+
+/// Copy the scan's Huffman table pack (a multiple of 16 bytes) into LDS and make the offsets of the cursor ring
+/// at its end (from `sp.cursor_off` on: table offsets in the two halves of word 0, own and next entry in words 2
+/// and 3) absolute LDS addresses, as is `sp.cursor_off` afterwards (jg_huff_core.h, JG_TAB_AT).
+__device__ __forceinline__ void load_tables(uint8_t* s_tab, JG_GLOBAL const uint8_t* __restrict__ g_tab, ScanParams& sp)
 {
     uint4* d       = reinterpret_cast<uint4*>(s_tab);
     JG_GLOBAL const uint4* s = reinterpret_cast<JG_GLOBAL const uint4*>(g_tab);
-    for (uint32_t i = threadIdx.x; i < bytes / 16; i += blockDim.x) d[i] = ld_global(s + i);
+    const uint32_t base = lds_address(s_tab), ring = sp.cursor_off / 16;
+    for (uint32_t i = threadIdx.x; i < sp.tab_bytes / 16; i += blockDim.x) {
+        uint4 v = ld_global(s + i);
+        if (i >= ring) {
+            v.x += base * 0x00010001u; // LDS addresses stay below 64 KB (launch_huff checks the size)
+            v.z += base;
+            v.w += base;
+        }
+        d[i] = v;
+    }
+    sp.cursor_off += base;
 }
 
 /// Carve of the dynamic LDS of the two sequence-wide Huffman kernels.
@@ -323,14 +342,14 @@ __global__ __launch_bounds__(T) void huff_sync_intra(JS js)
 
     const JobView J(js.get());
     if (static_cast<int>(blockIdx.x) >= J.num_seq) return;
-    const ScanParams sp = J.sp;
+    ScanParams sp = J.sp;
     const int t         = threadIdx.x;
     s_pend[t]           = 0;
     const int first_sub = blockIdx.x * SEQ;                  // first subsequence this workgroup owns
     const int img_first = first_sub - OV;                    // subsequence of lane 0
     const int img_end   = min(T, sp.num_subseq - img_first); // lanes below this have a subsequence
 
-    load_tables(s_tab, J.tables, sp.tab_bytes);
+    load_tables(s_tab, J.tables, sp);
     __syncthreads();
 
     constexpr int kBits = W * 32;
@@ -479,12 +498,12 @@ __global__ __launch_bounds__(TL) void huff_sync_tail(JS js)
 
     const JobView J(js.get());
     if (static_cast<int>(blockIdx.x) >= J.num_tail_parts) return;
-    const ScanParams sp    = J.sp;
+    ScanParams sp          = J.sp;
     JG_GLOBAL const uint32_t* scan32 = reinterpret_cast<JG_GLOBAL const uint32_t*>(J.destuffed);
     const int lo           = J.tail_parts[blockIdx.x];
     const int hi           = J.tail_parts[blockIdx.x + 1];
     const int tid          = threadIdx.x;
-    load_tables(s_tab, J.tables, sp.tab_bytes);
+    load_tables(s_tab, J.tables, sp);
 
     // ordered list of flow origins in [lo, hi)
     int count = 0;
@@ -765,12 +784,12 @@ __global__ __launch_bounds__(T) void huff_write(JS js)
 
     const JobView J(js.get());
     if (static_cast<int>(blockIdx.x) >= J.num_seq) return;
-    const ScanParams sp = J.sp;
+    ScanParams sp = J.sp;
     const int t         = threadIdx.x;
     const int first_sub = blockIdx.x * SEQ;
     const int nsub      = min(SEQ, sp.num_subseq - first_sub);
 
-    load_tables(s_tab, J.tables, sp.tab_bytes);
+    load_tables(s_tab, J.tables, sp);
 
     // carry-in of the segment that is open at the sequence's first subsequence
     {
