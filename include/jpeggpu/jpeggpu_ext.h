@@ -89,6 +89,8 @@ enum jpeggpu_status jpeggpu_ext_get_layout(jpeggpu_decoder_t decoder, struct jpe
  * jpeggpu_ext_get_device_status (which synchronises `stream`) returns the status.
  * Other files (several scans) take the host walk as before. A batch may mix both kinds: the front end of its
  * device-scanned images runs as four launches for the whole batch (grid.y = image). */
+/* Off by default; the environment variable JPEGGPU_DEVICE_SCAN=1 turns it on at jpeggpu_decoder_startup for
+ * callers of the drop-in API alone (they then learn of a truncated scan from the pixels, not from parse_header). */
 enum jpeggpu_status jpeggpu_ext_set_device_scan(jpeggpu_decoder_t decoder, int enable);
 enum jpeggpu_status jpeggpu_ext_get_device_status(
     jpeggpu_decoder_t decoder, const void* d_tmp, jpeggpu_stream_t stream, enum jpeggpu_status* status);

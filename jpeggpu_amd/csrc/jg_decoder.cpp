@@ -493,6 +493,8 @@ enum jpeggpu_status jpeggpu_decoder_startup(jpeggpu_decoder_t* decoder)
         const int v = std::atoi(e);
         if (jg::subseq_bytes_supported(v)) (*decoder)->d.subseq_bytes = v;
     }
+    // a caller of the drop-in API alone can opt into the device-side marker scan (jpeggpu_ext_set_device_scan)
+    if (const char* e = std::getenv("JPEGGPU_DEVICE_SCAN")) (*decoder)->d.device_scan = std::atoi(e) != 0;
     return JPEGGPU_SUCCESS;
 }
 

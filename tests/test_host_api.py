@@ -174,6 +174,34 @@ def test_decoder_reuse_and_subsequence_knob(L):
     dec.cleanup()
 
 
+def test_device_scan_knob_and_environment(L, monkeypatch):
+    """jpeggpu_ext_set_device_scan / JPEGGPU_DEVICE_SCAN: a file whose first scan holds every component is parsed
+    up to the scan header only (capacities instead of counts, a bigger buffer), a file with several scans keeps
+    the host walk; the environment variable switches it on for decoders created afterwards."""
+    m = cases.matrix()
+
+    def layouts(dec):
+        out = []
+        for name in ("multi_seq_dri", "ni_420_dri"):
+            dec.parse_header(m[name])
+            out.append((dec.layout().scans[0], dec.get_buffer_size()))
+        return out
+
+    plain = jpeggpu_amd.Decoder()
+    a = layouts(plain)
+    assert not a[0][0].device_scan and not a[1][0].device_scan
+    plain.set_device_scan(True)
+    b = layouts(plain)
+    assert b[0][0].device_scan and b[0][0].num_subsequences >= a[0][0].num_subsequences and b[0][1] > a[0][1]
+    assert not b[1][0].device_scan and b[1][1] == a[1][1]  # three scans: host walk as before
+    plain.cleanup()
+    monkeypatch.setenv("JPEGGPU_DEVICE_SCAN", "1")
+    env = jpeggpu_amd.Decoder()
+    c = layouts(env)
+    assert c[0][0].device_scan and c[0][1] == b[0][1] and not c[1][0].device_scan
+    env.cleanup()
+
+
 def test_parallel_parse_equals_serial(L):
     """jpeggpu_ext_parse_headers on a thread pool: same geometry, sizes and layouts as one-by-one parsing,
     per-item statuses for bad inputs, duplicate decoders rejected."""
