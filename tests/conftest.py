@@ -9,6 +9,10 @@ if ROOT not in sys.path:
 
 GOLDEN = os.path.join(ROOT, "tests", "golden")
 
+# the tests choose per decoder; an inherited opt-in would change what the default-path tests cover
+os.environ.pop("JPEGGPU_DEVICE_SCAN", None)
+os.environ.pop("JPEGGPU_SUBSEQ_BYTES", None)
+
 
 def pytest_configure(config):
     config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")

@@ -51,20 +51,31 @@ def _tmp_view(torch, tmp, base, off, count, dtype):
 
 @pytest.mark.parametrize("name", ["dri_row", "multi_seq_nodri", "ni_420_dri", "cfg5_small", "dri_fill"])
 @pytest.mark.parametrize("subseq_bytes", [128, 32])
-def test_stage_parity(gpu_lib, torch_cuda, inputs, name, subseq_bytes):
+@pytest.mark.parametrize("device_scan", [False, True])
+def test_stage_parity(gpu_lib, torch_cuda, inputs, name, subseq_bytes, device_scan):
     """Every intermediate buffer against its CPU twin: destuffed bytes, subsequence->segment map,
-    synchronised states, stream-order coefficients."""
+    synchronised states, stream-order coefficients -- with the segment table and the destuff work list from the
+    host walk, and with the ones the device-side front end builds (jpeggpu_ext_set_device_scan)."""
     import jpeggpu_amd
     from oracle import oracle
 
     torch = torch_cuda
     data = inputs[name]
-    planes, info, tmp, base, lay = jpeggpu_amd.decode_to_planes(data, subseq_bytes=subseq_bytes, return_tmp=True)
+    planes, info, tmp, base, lay = jpeggpu_amd.decode_to_planes(data, subseq_bytes=subseq_bytes, return_tmp=True,
+                                                                device_scan=device_scan)
     for s in range(lay.num_scans):
         sl = lay.scans[s]
         tw = oracle.scan_stages(data, s, subseq_bytes)
-        S = sl.num_subsequences
-        assert S == tw.num_subseq and sl.num_segments == tw.num_segments and sl.num_data_units == tw.num_du
+        S, G = sl.num_subsequences, sl.num_segments
+        if sl.device_scan:  # the layout holds capacities; the device reports what it found
+            words = _tmp_view(torch, tmp, base, sl.off_device_status, 5, torch.int32)
+            assert words[0] == 0 and S >= words[1]
+            S, G = int(words[1]), int(words[2])
+            segs = _tmp_view(torch, tmp, base, sl.off_segments, 2 * G, torch.int32).reshape(G, 2)
+            assert np.array_equal(segs[:, 0], tw.seg_offset) and np.array_equal(segs[:, 1], tw.seg_count), "segment table"
+        else:
+            assert not device_scan or lay.num_scans > 1
+        assert S == tw.num_subseq and G == tw.num_segments and sl.num_data_units == tw.num_du
         # the device keeps the destuffed bytes in tiles of 32 subsequences, word-major, every 32-bit word most
         # significant byte first (jpeggpu_ext.h)
         W, tiles = subseq_bytes // 4, (S + 31) // 32
