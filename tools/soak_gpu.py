@@ -90,6 +90,8 @@ def main():
         batch.destroy()
         rounds += 1
         images += len(keep)
+        if rounds % 20 == 0:  # a run that stays silent for minutes is taken to be hung on the GPU pool
+            print("  %d rounds, %d images, %.0f s" % (rounds, images, time.time() - t0), flush=True)
     print("soak ok: %d rounds, %d images, %.0f s" % (rounds, images, time.time() - t0))
 
 
