@@ -405,6 +405,55 @@ def test_device_side_marker_scan(torch_cuda):
     assert status == Status.INVALID_JPEG and all((p == 0x5A).all() for p in planes)
 
 
+def test_batch_with_bad_device_scanned_items(torch_cuda):
+    """A batch in which some device-scanned items turn out to be unusable on the device (scan without terminating
+    marker, restart markers that do not follow DRI): those report their status and leave their planes alone, the
+    other items of the same launches decode bit-exact."""
+    import jpeggpu_amd
+    from jpeggpu_amd import Status
+    from oracle import oracle
+
+    torch = torch_cuda
+    m = cases.matrix()
+    good = m["multi_seq_dri"]
+    cut = good[: len(good) * 2 // 3]
+    wrong = bytearray(good)
+    wrong[good.index(b"\xff\xdd") + 5] ^= 0x20
+    items = [("good_host", good, False, Status.SUCCESS), ("cut", cut, True, Status.INCOMPLETE_BITSTREAM),
+             ("good_dev", good, True, Status.SUCCESS), ("wrong_dri", bytes(wrong), True, Status.INVALID_JPEG),
+             ("other_dev", m["dri_row"], True, Status.SUCCESS), ("gray_host", m["gray"], False, Status.SUCCESS)] * 3
+    keep, entries = [], []
+    for name, data, dev, _ in items:
+        dec = jpeggpu_amd.Decoder()
+        dec.set_device_scan(dev)
+        info = dec.parse_header(data)
+        n, tmp, base, planes = _alloc(torch, dec, info)
+        dec.transfer(base, n, 0)
+        keep.append((dec, tmp, planes))
+        entries.append((dec, [p.data_ptr() for p in planes], [p.stride(0) for p in planes], base, n))
+    batch = jpeggpu_amd.Batch(len(items))
+    scratch = torch.empty(batch.scratch_size, dtype=torch.uint8, device="cuda:0")
+    batch.set_items(entries)
+    for overlap in (1, 2):
+        batch.set_overlap(overlap)
+        for _, _, planes in keep:
+            for p in planes:
+                p.fill_(0xAB)
+        batch.decode(scratch.data_ptr(), 0)
+        torch.cuda.synchronize()
+        for (name, data, dev, want), (dec, _, planes), ent in zip(items, keep, entries):
+            assert dec.device_status(ent[3], 0) == want, name
+            if want == Status.SUCCESS:
+                ref = oracle.decode(data)
+                for c in range(ref.ncomp):
+                    assert np.array_equal(planes[c].cpu().numpy(), ref.planes[c]), (name, c, overlap)
+            else:
+                assert all((p == 0xAB).all() for p in planes), name
+    batch.destroy()
+    for dec, _, _ in keep:
+        dec.cleanup()
+
+
 def test_c_caller_decodes_the_reference_photo(torch_cuda, tmp_path):
     """examples/decode_file.c (plain C, HIP runtime, no Python in the process) on the reference's photo: the
     planes it writes carry the committed hashes of the oracle's planes (tests/golden/photo_pins.json)."""
