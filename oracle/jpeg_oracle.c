@@ -537,6 +537,17 @@ static void idct_vector(int* v0, int* v1, int* v2, int* v3, int* v4, int* v5, in
     *v7 = unfixh(tmp20 - tmp50);
 }
 
+/* the 8-point transform alone on n vectors (pinned by tests/golden/idct_kats.npz: vec_in -> vec_out) */
+void jo_idct_vectors(const int32_t* in, int32_t* out, int n)
+{
+    for (int i = 0; i < n; ++i) {
+        int v[8];
+        for (int k = 0; k < 8; ++k) v[k] = in[8 * i + k];
+        idct_vector(&v[0], &v[1], &v[2], &v[3], &v[4], &v[5], &v[6], &v[7]);
+        for (int k = 0; k < 8; ++k) out[8 * i + k] = v[k];
+    }
+}
+
 void jo_idct_block(const int16_t coef[64], const uint16_t q[64], uint8_t out[64], int flags)
 {
     int16_t blk[64];

@@ -45,6 +45,9 @@ void jo_free(jo_image* img);
 /* dequant + IDCT + level shift + clamp of one data unit (natural order in, raster out) */
 void jo_idct_block(const int16_t coef[64], const uint16_t q[64], uint8_t out[64], int flags);
 
+/* the 8-point fixed-point transform (reference idct_vector, src/idct.cu:50-95) on n vectors of 8 */
+void jo_idct_vectors(const int32_t* in, int32_t* out, int n);
+
 typedef struct {
     int num_subseq, num_segments, num_du;
     size_t scan_begin, scan_end;

@@ -56,6 +56,7 @@ def lib():
         _lib.jo_decode.argtypes = [C.c_char_p, C.c_size_t, C.POINTER(_JoImage), C.c_int]
         _lib.jo_free.argtypes = [C.POINTER(_JoImage)]
         _lib.jo_idct_block.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int]
+        _lib.jo_idct_vectors.argtypes = [C.c_void_p, C.c_void_p, C.c_int]
         _lib.jo_scan_info.argtypes = [C.c_char_p, C.c_size_t, C.c_int, C.c_int, C.POINTER(_JoScanLayout)]
         _lib.jo_scan_stages.argtypes = [C.c_char_p, C.c_size_t, C.c_int, C.c_int] + [C.c_void_p] * 12
     return _lib
@@ -108,6 +109,14 @@ def idct_block(coef, q, flags: int = 0):
     out = np.zeros(64, dtype=np.uint8)
     lib().jo_idct_block(coef.ctypes.data, q.ctypes.data, out.ctypes.data, flags)
     return out.reshape(8, 8)
+
+
+def idct_vectors(vec):
+    """idct_vector of the oracle on int32[n, 8]."""
+    vec = np.ascontiguousarray(vec, dtype=np.int32).reshape(-1, 8)
+    out = np.zeros_like(vec)
+    lib().jo_idct_vectors(vec.ctypes.data, out.ctypes.data, len(vec))
+    return out
 
 
 def scan_info(data: bytes, scan_idx: int, subseq_bytes: int):

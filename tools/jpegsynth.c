@@ -495,3 +495,65 @@ done:
     for (int c = 0; c < 4; ++c) free(coef[c]);
     return result;
 }
+
+/* A grayscale baseline JPEG made of GIVEN quantised coefficient blocks (natural order, DC absolute; DC in
+ * [-1024, 1023], AC in [-1023, 1023]) and a given 8-bit quantisation table (natural order), Annex-K luma
+ * Huffman tables: blocks_x * blocks_y data units in raster order. Lets a test push chosen coefficients
+ * through a decoder's dequantisation + IDCT (tests/golden/idct_kats.npz). */
+size_t js_encode_blocks(const int16_t* coef, int blocks_x, int blocks_y, const uint8_t* q, int restart_interval, uint8_t* out, size_t cap)
+{
+    bitw w = {out, 0, cap, 0, 0, 0};
+    htab dc, ac;
+    if (blocks_x < 1 || blocks_y < 1 || blocks_x > 8191 || blocks_y > 8191) return 0;
+    htab_std(&dc, kDcLumaBits, kDcVals, 12);
+    htab_std(&ac, kAcLumaBits, kAcLumaVals, 162);
+    put_marker(&w, 0xD8);
+    put_marker(&w, 0xDB);
+    put_u16(&w, 2 + 65);
+    put_byte_raw(&w, 0);
+    for (int k = 0; k < 64; ++k) put_byte_raw(&w, q[kZigzag[k]]);
+    put_marker(&w, 0xC0);
+    put_u16(&w, 8 + 3);
+    put_byte_raw(&w, 8);
+    put_u16(&w, blocks_y * 8);
+    put_u16(&w, blocks_x * 8);
+    put_byte_raw(&w, 1);
+    put_byte_raw(&w, 1);
+    put_byte_raw(&w, 0x11);
+    put_byte_raw(&w, 0);
+    if (restart_interval) {
+        put_marker(&w, 0xDD);
+        put_u16(&w, 4);
+        put_u16(&w, restart_interval);
+    }
+    for (int cls = 0; cls < 2; ++cls) {
+        const htab* t = cls ? &ac : &dc;
+        put_marker(&w, 0xC4);
+        put_u16(&w, 2 + 1 + 16 + t->count);
+        put_byte_raw(&w, cls << 4);
+        for (int i = 0; i < 16; ++i) put_byte_raw(&w, t->bits[i]);
+        for (int i = 0; i < t->count; ++i) put_byte_raw(&w, t->vals[i]);
+    }
+    put_marker(&w, 0xDA);
+    put_u16(&w, 8);
+    put_byte_raw(&w, 1);
+    put_byte_raw(&w, 1);
+    put_byte_raw(&w, 0);
+    put_byte_raw(&w, 0);
+    put_byte_raw(&w, 63);
+    put_byte_raw(&w, 0);
+    int pred = 0, rst = 0, count = 0;
+    for (int m = 0; m < blocks_x * blocks_y; ++m) {
+        if (restart_interval && count == restart_interval) {
+            flush_bits(&w);
+            put_marker(&w, 0xD0 + (rst++ & 7));
+            pred  = 0;
+            count = 0;
+        }
+        ++count;
+        code_block(&w, coef + (size_t)m * 64, &pred, &dc, &ac, NULL, NULL);
+    }
+    flush_bits(&w);
+    put_marker(&w, 0xD9);
+    return w.overflow ? 0 : w.n;
+}

@@ -24,15 +24,40 @@ def build(force=False):
 _lib = None
 
 
-def encode(width, height, sampling=((2, 2), (1, 1), (1, 1)), interleaved=True, restart_interval=0,
-           quality=75, optimize=False, noise=6, fill_bytes=0, seed=0, qmax=0) -> bytes:
-    """sampling: one (h, v) pair per component (1..4 components)."""
+def _load():
     global _lib
     if _lib is None:
         build()
         _lib = C.CDLL(_LIB)
         _lib.js_encode.restype = C.c_size_t
         _lib.js_encode.argtypes = [C.POINTER(_Params), C.c_void_p, C.c_size_t]
+        _lib.js_encode_blocks.restype = C.c_size_t
+        _lib.js_encode_blocks.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_int, C.c_void_p, C.c_size_t]
+    return _lib
+
+
+def encode_blocks(coef, blocks_x, q, restart_interval=0) -> bytes:
+    """Grayscale JPEG whose data units are the given quantised coefficient blocks: `coef` int16 [n, 64] in
+    natural order (n a multiple of blocks_x), `q` uint8 [64] natural order. Block b lands at block row
+    b // blocks_x, column b % blocks_x."""
+    import numpy as np
+
+    coef = np.ascontiguousarray(coef, dtype=np.int16).reshape(-1, 64)
+    q = np.ascontiguousarray(q, dtype=np.uint8).reshape(64)
+    n = len(coef)
+    assert n % blocks_x == 0
+    cap = 4096 + n * 64 * 4
+    buf = C.create_string_buffer(cap)
+    m = _load().js_encode_blocks(coef.ctypes.data, blocks_x, n // blocks_x, q.ctypes.data, restart_interval, buf, cap)
+    if m == 0:
+        raise RuntimeError("jpegsynth: encode_blocks failed")
+    return buf.raw[:m]
+
+
+def encode(width, height, sampling=((2, 2), (1, 1), (1, 1)), interleaved=True, restart_interval=0,
+           quality=75, optimize=False, noise=6, fill_bytes=0, seed=0, qmax=0) -> bytes:
+    """sampling: one (h, v) pair per component (1..4 components)."""
+    _load()
     p = _Params()
     p.width, p.height, p.ncomp = width, height, len(sampling)
     for c, (h, v) in enumerate(sampling):
