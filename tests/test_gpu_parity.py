@@ -2,7 +2,7 @@
 import numpy as np
 import pytest
 
-from tests import cases
+from tests import cases, gpu_util
 
 pytestmark = pytest.mark.gpu
 
@@ -43,10 +43,7 @@ def test_matrix_planes_bit_exact(gpu_lib, torch_cuda, inputs, subseq_bytes):
     assert not bad, bad
 
 
-def _tmp_view(torch, tmp, base, off, count, dtype):
-    start = base - tmp.data_ptr() + off
-    nbytes = count * torch.tensor([], dtype=dtype).element_size()
-    return tmp[start:start + nbytes].view(dtype).cpu().numpy()
+_tmp_view = gpu_util.tmp_view
 
 
 @pytest.mark.parametrize("name", ["dri_row", "multi_seq_nodri", "ni_420_dri", "cfg5_small", "dri_fill"])
@@ -96,25 +93,7 @@ def test_stage_parity(gpu_lib, torch_cuda, inputs, name, subseq_bytes, device_sc
             assert np.array_equal(halves[k][ok], tw.dc[k][ok].astype(np.uint32) & 0xFFFF), "state dc%d" % k
         # the write pass emits a symbol stream + a table {first entry, count} per data unit: rebuild the
         # dense stream-order coefficients from it
-        ND = sl.num_data_units
-        # regions of 64 subsequences are interleaved sector by sector (jpeggpu_ext.h)
-        nsym = ((S + 63) // 64) * (sl.symbol_region_entries // 8) * 512
-        sym = _tmp_view(torch, tmp, base, sl.off_symbols, nsym, torch.int32).view(np.uint32)
-        tab = _tmp_view(torch, tmp, base, sl.off_du_table, ND * 2, torch.int32).view(np.uint32).reshape(ND, 2)
-        assert tab[:, 1].max() <= 64 and tab[:, 1].min() >= 1
-        nat = np.array([0, 1, 8, 16, 9, 2, 3, 10, 17, 24, 32, 25, 18, 11, 4, 5, 12, 19, 26, 33, 40, 48, 41, 34, 27, 20, 13,
-                        6, 7, 14, 21, 28, 35, 42, 49, 56, 57, 50, 43, 36, 29, 22, 15, 23, 30, 37, 44, 51, 58, 59, 52, 45,
-                        38, 31, 39, 46, 53, 60, 61, 54, 47, 55, 62, 63])
-        coef = np.zeros((ND, 64), np.int16)
-        du = np.repeat(np.arange(ND), tab[:, 1])
-        def unit(first, count):  # physical indices of a unit's entries
-            w = (int(first) & 7) + np.arange(count)
-            return (int(first) & ~7) + (w >> 3) * 512 + (w & 7)
-
-        idx = np.concatenate([unit(o, c) for o, c in tab]) if ND else np.zeros(0, np.int64)
-        assert idx.max() < sym.size
-        ent = sym[idx]
-        coef[du, nat[(ent >> 16) & 63]] = (ent & 0xFFFF).astype(np.uint16).view(np.int16)
+        coef = gpu_util.stream_coefficients(torch, tmp, base, sl, S)
         assert np.array_equal(coef, tw.stream_coef), "coefficients"
 
 
