@@ -139,6 +139,16 @@ def _check(status, where):
         raise JpegGpuError(status, where)
 
 
+def _host_buffer(data):
+    """(address, size, object to keep alive) of a bytes / bytearray input. The decoder borrows the address until
+    the copy enqueued by transfer() has executed, so the address must belong to the object that is kept: the
+    bytes object itself, or a ctypes view of the bytearray's own storage (no temporary copy)."""
+    if isinstance(data, bytearray):
+        view = (C.c_char * len(data)).from_buffer(data) if len(data) else (C.c_char * 1)()
+        return C.addressof(view), len(data), (data, view)
+    return C.cast(C.c_char_p(data), C.c_void_p).value, len(data), data
+
+
 class Decoder:
     """One jpeggpu_decoder_t. Not thread-safe; one decoder per host thread / stream."""
 
@@ -162,9 +172,7 @@ class Decoder:
         if isinstance(data, int):
             ptr, n = data, size
         elif isinstance(data, (bytes, bytearray)):
-            self._keep = data
-            ptr = C.cast(C.c_char_p(bytes(data)) if isinstance(data, bytearray) else C.c_char_p(data), C.c_void_p).value
-            n = len(data)
+            ptr, n, self._keep = _host_buffer(data)
         else:  # numpy / torch-like with ctypes or data_ptr
             self._keep = data
             ptr = data.ctypes.data if hasattr(data, "ctypes") else data.data_ptr()
@@ -317,7 +325,7 @@ def parse_headers(decoders, buffers, num_threads=4):
     for i, (d, b) in enumerate(zip(decoders, buffers)):
         d._keep = b
         if isinstance(b, (bytes, bytearray)):
-            ptr, size = C.cast(C.c_char_p(bytes(b)) if isinstance(b, bytearray) else C.c_char_p(b), C.c_void_p).value, len(b)
+            ptr, size, d._keep = _host_buffer(b)
         else:
             ptr = b.ctypes.data if hasattr(b, "ctypes") else b.data_ptr()
             size = b.nbytes if hasattr(b, "nbytes") else b.numel()

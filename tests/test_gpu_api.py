@@ -80,6 +80,24 @@ def test_decoder_reuse_across_geometries_and_streams(torch_cuda):
     dec.cleanup()
 
 
+def test_decode_from_bytearray(torch_cuda):
+    """A bytearray input is read in place at transfer time (a temporary copy used to dangle)."""
+    import gc
+
+    import jpeggpu_amd
+    from oracle import oracle
+
+    src = cases.matrix()["dri_7"]
+    data = bytearray(src)
+    ref = oracle.decode(src)
+    for _ in range(3):
+        gc.collect()
+        _ = [bytes(len(src)) for _ in range(8)]  # churn the allocator where a freed copy would have lived
+        planes, _info = jpeggpu_amd.decode_to_planes(data)
+        for c in range(ref.ncomp):
+            assert np.array_equal(planes[c].cpu().numpy(), ref.planes[c])
+
+
 def test_two_decoders_on_two_host_threads(torch_cuda):
     import jpeggpu_amd
     from oracle import oracle

@@ -158,6 +158,30 @@ def test_negative_inputs_same_status_as_oracle(L):
     assert both(variants["truncated"])[0] == Status.INVALID_JPEG
 
 
+def test_bytearray_input_is_borrowed_not_copied(L):
+    """The decoder keeps the address it was given until transfer(): for a bytearray that must be the bytearray's
+    own storage, kept alive by the Decoder object (a temporary bytes copy would dangle)."""
+    import gc
+
+    from jpeggpu_amd import api
+
+    data = bytearray(cases.matrix()["ss_2x2"])
+    ptr, n, keep = api._host_buffer(data)
+    assert n == len(data) and ptr == np.frombuffer(data, np.uint8).ctypes.data
+    dec = jpeggpu_amd.Decoder()
+    dec.parse_header(data)
+    assert dec._keep[0] is data
+    gc.collect()
+    lay = dec.layout()
+    assert lay.num_scans == 1
+    bufs = [bytearray(cases.matrix()["gray"]), cases.matrix()["ss_1x1"]]
+    decs = [jpeggpu_amd.Decoder(), jpeggpu_amd.Decoder()]
+    jpeggpu_amd.parse_headers(decs, bufs, num_threads=2)
+    assert decs[0]._keep[0] is bufs[0] and decs[1]._keep is bufs[1]
+    for d in decs + [dec]:
+        d.cleanup()
+
+
 def test_decoder_reuse_and_subsequence_knob(L):
     m = cases.matrix()
     dec = jpeggpu_amd.Decoder()
