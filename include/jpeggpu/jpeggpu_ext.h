@@ -85,12 +85,17 @@ enum jpeggpu_status jpeggpu_ext_get_layout(jpeggpu_decoder_t decoder, struct jpe
  * 0.87 ms of a 12 MP image). transfer then copies everything up to the end of the file, and decode first runs four
  * small kernels that find the markers and build the segment table and the destuff work list in device memory. What
  * the host walk reports at parse time -- a scan without terminating marker, a restart-marker count that does not
- * match the geometry -- is then known only on the device: decode leaves the planes untouched, and
- * jpeggpu_ext_get_device_status (which synchronises `stream`) returns the status.
+ * match the geometry, an FF FF 00 sequence: JPEGGPU_INVALID_JPEG in each case, from either walk -- is then known
+ * only on the device: decode leaves the planes untouched, and jpeggpu_ext_get_device_status (which synchronises
+ * `stream`) returns the status. If the file ends in an end-of-image marker, or in one followed by padding, the
+ * copy stops there (a backwards search on the host); otherwise it runs to the end of the file.
  * Other files (several scans) take the host walk as before. A batch may mix both kinds: the front end of its
  * device-scanned images runs as four launches for the whole batch (grid.y = image). */
-/* Off by default; the environment variable JPEGGPU_DEVICE_SCAN=1 turns it on at jpeggpu_decoder_startup for
- * callers of the drop-in API alone (they then learn of a truncated scan from the pixels, not from parse_header). */
+/* enable: 0 off (default); 1 on, the caller asks for the status as above; 2 on and CHECKED: jpeggpu_decoder_decode
+ * itself waits for the stream and returns the device's status (it then blocks the host, unlike every other mode).
+ * The environment variable JPEGGPU_DEVICE_SCAN=1 selects mode 2 at jpeggpu_decoder_startup: it is meant for callers
+ * of the drop-in API alone, who cannot ask the device and would otherwise learn of a truncated scan from unwritten
+ * planes. Items of jpeggpu_ext_decode_batch are never waited for: their status is read with the call below. */
 enum jpeggpu_status jpeggpu_ext_set_device_scan(jpeggpu_decoder_t decoder, int enable);
 enum jpeggpu_status jpeggpu_ext_get_device_status(
     jpeggpu_decoder_t decoder, const void* d_tmp, jpeggpu_stream_t stream, enum jpeggpu_status* status);

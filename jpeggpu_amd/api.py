@@ -180,7 +180,9 @@ class Decoder:
         _check(lib().jpeggpu_decoder_parse_header(self._h, C.byref(info), ptr, n), "jpeggpu_decoder_parse_header")
         return info
 
-    def set_device_scan(self, on: bool = True):
+    def set_device_scan(self, on=True):
+        """False / 0: host walk; True / 1: marker scan on the device, status via device_status(); 2: checked --
+        decode() waits for the stream and raises the device's status (what JPEGGPU_DEVICE_SCAN=1 selects)."""
         _check(lib().jpeggpu_ext_set_device_scan(self._h, int(on)), "jpeggpu_ext_set_device_scan")
 
     def device_status(self, d_tmp: int, stream: int = 0) -> Status:

@@ -8,14 +8,14 @@ CSRC = os.path.join(_HERE, "csrc")
 LIB_DIR = os.path.join(_HERE, "lib")
 LIB_PATH = os.path.join(LIB_DIR, "libjpeggpu.so")
 SOURCES = ["jg_kernels.hip", "jg_front.hip", "jg_decoder.cpp", "jg_reader.cpp"]
-HEADERS = ["jg_defs.h", "jg_huff_core.h", "jg_kernels.hpp", "jg_front.hpp", "jg_reader.hpp"]
 
 
 def _stale() -> bool:
     if not os.path.exists(LIB_PATH):
         return True
     t = os.path.getmtime(LIB_PATH)
-    deps = [os.path.join(CSRC, f) for f in SOURCES + HEADERS]
+    # every source and header under csrc/ (a header missing from a hand-kept list once left a stale library)
+    deps = [os.path.join(CSRC, f) for f in os.listdir(CSRC) if f.endswith((".h", ".hpp", ".hip", ".cpp"))]
     deps += [os.path.join(ROOT, "include", "jpeggpu", h) for h in ("jpeggpu.h", "jpeggpu_ext.h")]
     return any(os.path.getmtime(d) > t for d in deps)
 

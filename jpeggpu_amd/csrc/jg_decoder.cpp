@@ -77,7 +77,7 @@ struct ScanPlan {
     int num_seq = 0;
     // device-side front end (jg_front.hip): tables built on the device, scratch, the job and the status word
     size_t d_segments = 0, d_chunks = 0, d_parts = 0;
-    size_t d_win_data = 0, d_win_nmark = 0, d_win_prefix = 0, d_mark_off = 0;
+    size_t d_win_data = 0, d_win_nmark = 0, d_win_bad = 0, d_win_prefix = 0, d_mark_off = 0;
     size_t d_mk_pos = 0, d_mk_g = 0, d_seg_cnt = 0, d_seg_nch = 0, d_job = 0, d_status = 0;
     uint32_t num_windows = 0;
 };
@@ -101,7 +101,7 @@ struct Decoder {
     size_t data_size    = 0;
     int subseq_bytes    = 128;
     bool parsed         = false;
-    bool device_scan    = false; // jpeggpu_ext_set_device_scan
+    int device_scan     = 0;     // jpeggpu_ext_set_device_scan: 0 off, 1 on (status via jpeggpu_ext_get_device_status), 2 on and checked by decode
 
     std::vector<ScanJob> jobs; // scratch of the last decode
 
@@ -195,6 +195,7 @@ void Decoder::make_plan()
             carve(sp.d_parts, static_cast<size_t>(sc.max_tail_parts) * sizeof(int));
             carve(sp.d_win_data, Wn * 4);
             carve(sp.d_win_nmark, Wn * 4);
+            carve(sp.d_win_bad, Wn * 4);
             carve(sp.d_win_prefix, (Wn + 1) * 4);
             carve(sp.d_mark_off, (Wn + 1) * 4);
             carve(sp.d_mk_pos, (E + 1) * 4);
@@ -414,6 +415,7 @@ jg::FrontParams front_params(const Decoder& d, void* d_tmp, jg::ScanJob* d_job)
     const auto u32    = [&](size_t off) { return reinterpret_cast<uint32_t*>(base + off); };
     P.win_data   = u32(pl.d_win_data);
     P.win_nmark  = u32(pl.d_win_nmark);
+    P.win_bad    = u32(pl.d_win_bad);
     P.win_prefix = u32(pl.d_win_prefix);
     P.mark_off   = u32(pl.d_mark_off);
     P.mk_pos     = u32(pl.d_mk_pos);
@@ -426,6 +428,20 @@ jg::FrontParams front_params(const Decoder& d, void* d_tmp, jg::ScanJob* d_job)
     P.job        = d_job;
     P.status     = u32(pl.d_status);
     return P;
+}
+
+/// The status word of the device-side front end (synchronises `stream`); SUCCESS for host-walked images.
+jpeggpu_status read_device_status(Decoder& d, const void* d_tmp, hipStream_t stream, jpeggpu_status* status)
+{
+    *status = JPEGGPU_SUCCESS;
+    if (!d.reader.s.scans[0].device_walk) return JPEGGPU_SUCCESS; // the host walk has already judged the stream
+    uint32_t word = 0;
+    const uint8_t* src = static_cast<const uint8_t*>(d_tmp) + d.plan.scan[0].d_status;
+    if (hipMemcpyAsync(&word, src, sizeof(word), hipMemcpyDeviceToHost, stream) != hipSuccess ||
+        hipStreamSynchronize(stream) != hipSuccess)
+        return JPEGGPU_INTERNAL_ERROR;
+    *status = word <= JPEGGPU_INCOMPLETE_BITSTREAM ? static_cast<jpeggpu_status>(word) : JPEGGPU_INTERNAL_ERROR;
+    return JPEGGPU_SUCCESS;
 }
 
 jpeggpu_status do_decode(Decoder& d, jpeggpu_img* img, void* d_tmp, size_t tmp_size, hipStream_t stream)
@@ -441,15 +457,23 @@ jpeggpu_status do_decode(Decoder& d, jpeggpu_img* img, void* d_tmp, size_t tmp_s
         // Device-side front end: the job lives in device memory, front_plan fills in its counts, and the
         // stages run as a one-job batch with launch extents from the header's upper bounds.
         ScanJob* d_job = reinterpret_cast<ScanJob*>(static_cast<uint8_t*>(d_tmp) + d.plan.scan[0].d_job);
-        // pageable source: the runtime stages it before returning, d.jobs may change afterwards
-        JG_CHECK_HIP(hipMemcpyAsync(d_job, d.jobs.data(), sizeof(ScanJob), hipMemcpyHostToDevice, stream));
         const FrontParams P = front_params(d, d_tmp, d_job);
-        JG_CHECK_HIP(launch_front(P, stream));
+        // the job travels as a kernel argument of the first front-end kernel, which stores it to d_job
+        JG_CHECK_HIP(launch_front(P, d.jobs[0], stream));
         JobExtent extent;
         extend(extent, d.jobs[0]);
         for (int stage = 0; stage < kNumStages; ++stage) {
             JG_CHECK_HIP(launch_stage_batch(static_cast<Stage>(stage), d_job, 1, extent, stream));
             d.mark(stage, stream);
+        }
+        if (d.device_scan == 2) {
+            // Checked mode (JPEGGPU_DEVICE_SCAN=1 in the environment of a caller that knows only the drop-in API):
+            // what the host walk would have reported from parse_header is known on the device only now. Wait for
+            // it and return it, as such a caller cannot ask for it; nothing was written to the planes if it is
+            // not success.
+            jpeggpu_status dev = JPEGGPU_SUCCESS;
+            const jpeggpu_status rc = read_device_status(d, d_tmp, stream, &dev);
+            return rc != JPEGGPU_SUCCESS ? rc : dev;
         }
         return JPEGGPU_SUCCESS;
     }
@@ -493,8 +517,9 @@ enum jpeggpu_status jpeggpu_decoder_startup(jpeggpu_decoder_t* decoder)
         const int v = std::atoi(e);
         if (jg::subseq_bytes_supported(v)) (*decoder)->d.subseq_bytes = v;
     }
-    // a caller of the drop-in API alone can opt into the device-side marker scan (jpeggpu_ext_set_device_scan)
-    if (const char* e = std::getenv("JPEGGPU_DEVICE_SCAN")) (*decoder)->d.device_scan = std::atoi(e) != 0;
+    // a caller of the drop-in API alone can opt into the device-side marker scan; such a caller cannot ask the
+    // device for its verdict on the stream, so decode waits for it and returns it (mode 2, jpeggpu_ext.h)
+    if (const char* e = std::getenv("JPEGGPU_DEVICE_SCAN")) (*decoder)->d.device_scan = std::atoi(e) != 0 ? 2 : 0;
     return JPEGGPU_SUCCESS;
 }
 
@@ -522,7 +547,7 @@ enum jpeggpu_status jpeggpu_decoder_parse_header(
     d.parsed   = false;
     jpeggpu_status st;
     try {
-        st = d.reader.parse(data, size, d.subseq_bytes, d.logger, d.device_scan);
+        st = d.reader.parse(data, size, d.subseq_bytes, d.logger, d.device_scan != 0);
     } catch (const std::bad_alloc&) {
         return JPEGGPU_OUT_OF_HOST_MEMORY;
     }
@@ -667,8 +692,8 @@ enum jpeggpu_status jpeggpu_ext_get_layout(jpeggpu_decoder_t decoder, struct jpe
 
 enum jpeggpu_status jpeggpu_ext_set_device_scan(jpeggpu_decoder_t decoder, int enable)
 {
-    if (!decoder) return JPEGGPU_INVALID_ARGUMENT;
-    decoder->d.device_scan = enable != 0;
+    if (!decoder || enable < 0 || enable > 2) return JPEGGPU_INVALID_ARGUMENT;
+    decoder->d.device_scan = enable;
     return JPEGGPU_SUCCESS;
 }
 
@@ -678,15 +703,7 @@ enum jpeggpu_status jpeggpu_ext_get_device_status(
     if (!decoder || !d_tmp || !status) return JPEGGPU_INVALID_ARGUMENT;
     Decoder& d = decoder->d;
     if (!d.parsed) return JPEGGPU_INVALID_ARGUMENT;
-    *status = JPEGGPU_SUCCESS;
-    if (!d.reader.s.scans[0].device_walk) return JPEGGPU_SUCCESS; // the host walk has already judged the stream
-    uint32_t word = 0;
-    const uint8_t* src = static_cast<const uint8_t*>(d_tmp) + d.plan.scan[0].d_status;
-    if (hipMemcpyAsync(&word, src, sizeof(word), hipMemcpyDeviceToHost, stream) != hipSuccess ||
-        hipStreamSynchronize(stream) != hipSuccess)
-        return JPEGGPU_INTERNAL_ERROR;
-    *status = word <= JPEGGPU_INCOMPLETE_BITSTREAM ? static_cast<jpeggpu_status>(word) : JPEGGPU_INTERNAL_ERROR;
-    return JPEGGPU_SUCCESS;
+    return read_device_status(d, d_tmp, stream, status);
 }
 
 struct jpeggpu_batch {

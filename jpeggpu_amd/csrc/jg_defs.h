@@ -71,6 +71,14 @@ constexpr int kHuffAuxSize = 16 + 16 + 256;
 constexpr int kDcTableSize = (2 << kLutBitsDc) + kHuffAuxSize; // 1312, plus second-level tables
 constexpr int kAcTableSize = (2 << kLutBitsAc) + kHuffAuxSize; // 4384, plus second-level tables
 
+/// Largest table pack of a scan: four DC and four AC tables with every second-level table, plus the cursor
+/// ring. Offsets into the pack are kept in 16 bits (Scan::dc_off / ac_off, the halves of CursorEntry::tabs),
+/// and on the device the kernels turn them into absolute LDS addresses that must stay below 64 KiB as well
+/// (jg_kernels.hip checks its carve bases against this constant).
+constexpr uint32_t kMaxTablePack =
+    kMaxComp * (kDcTableSize + kMaxSubTables * kSubTableSize) + kMaxComp * (kAcTableSize + kMaxSubTables * kSubTableSize) + kMaxDuPerMcu * 16;
+static_assert(kMaxTablePack < 65536, "table offsets are 16-bit");
+
 JG_HD inline uint32_t huff_entry(int codelen, uint32_t sym, bool is_dc)
 {
     // DC: sym is the category (hardened to 4 bits; valid baseline streams use 0..11).

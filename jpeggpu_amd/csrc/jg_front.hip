@@ -51,10 +51,19 @@ __device__ __forceinline__ uint32_t block_excl_scan(uint32_t v, uint32_t* s_wave
 /// Where a workgroup finds its parameters: one scan by value (the drop-in decode), or entry blockIdx.y of an
 /// array in device memory (a batch).
 struct FrontOne {
+    static constexpr bool kCarriesJob = false;
     FrontParams P;
     __device__ __forceinline__ const FrontParams& get() const { return P; }
 };
+/// front_count of a single scan also carries the scan's job and stores it to device memory (jg_front.hpp).
+struct FrontOneJob {
+    static constexpr bool kCarriesJob = true;
+    FrontParams P;
+    ScanJob job;
+    __device__ __forceinline__ const FrontParams& get() const { return P; }
+};
 struct FrontMany {
+    static constexpr bool kCarriesJob = false;
     const FrontParams* arr;
     __device__ __forceinline__ FrontParams get() const { return arr[blockIdx.y]; }
 };
@@ -69,6 +78,7 @@ struct LaneBytes {
     uint32_t word[4];
     uint32_t next;
     uint32_t data[4], mark[4]; // 0x80 domain
+    uint32_t bad[4];           // an FF behind an FF and in front of a 00: "FF FF 00" is neither fill + marker nor stuffing
     uint32_t lead;
     __device__ __forceinline__ uint32_t data_count() const
     {
@@ -84,6 +94,12 @@ struct LaneBytes {
     __device__ __forceinline__ uint32_t mark_mask() const
     {
         return collapse80(mark[0]) | collapse80(mark[1]) << 4 | collapse80(mark[2]) << 8 | collapse80(mark[3]) << 12;
+    }
+    /// Index of the first byte of the lane flagged in `bad`, or 16.
+    __device__ __forceinline__ uint32_t first_bad() const
+    {
+        const uint32_t m = collapse80(bad[0]) | collapse80(bad[1]) << 4 | collapse80(bad[2]) << 8 | collapse80(bad[3]) << 12;
+        return m ? static_cast<uint32_t>(__ffs(m) - 1) : 16u;
     }
     __device__ __forceinline__ uint32_t byte_after(int i) const
     {
@@ -135,6 +151,7 @@ __device__ __forceinline__ LaneBytes classify(const FrontParams& P, uint32_t gpo
         const uint32_t NZ = of_next_byte(Z[j], j < 3 ? Z[j + 1] : z_after);
         L.data[j]         = (PF & Z[j]) | (~(PF | F[j]) & kHi80);
         L.mark[j]         = F[j] & ~(NF | NZ);
+        L.bad[j]          = F[j] & PF & NZ;
     }
     return L;
 }
@@ -144,16 +161,31 @@ template <class FS>
 __global__ __launch_bounds__(256) void front_count(FS src)
 {
     const FrontParams P = src.get();
+    if constexpr (FS::kCarriesJob) {
+        if (blockIdx.x == 0) { // front_plan, three launches later, fills in the counts
+            static_assert(sizeof(ScanJob) % 4 == 0, "copied as dwords");
+            const uint32_t* from = reinterpret_cast<const uint32_t*>(&src.job);
+            JG_GLOBAL uint32_t* to = reinterpret_cast<JG_GLOBAL uint32_t*>(as_global(P.job));
+            for (uint32_t i = threadIdx.x; i < sizeof(ScanJob) / 4; i += blockDim.x) to[i] = from[i];
+        }
+    }
     if (blockIdx.x >= P.num_windows) return;
     __shared__ uint32_t s_wave[4];
-    const uint32_t w  = blockIdx.x;
-    const LaneBytes L = classify(P, w * kDestuffWin + threadIdx.x * 16);
+    __shared__ uint32_t s_bad;
+    if (threadIdx.x == 0) s_bad = 0xFFFFFFFFu;
+    const uint32_t w    = blockIdx.x;
+    const uint32_t gpos = w * kDestuffWin + threadIdx.x * 16;
+    const LaneBytes L   = classify(P, gpos);
     uint32_t total_data = 0, total_mark = 0;
-    block_excl_scan<4>(L.data_count(), s_wave, total_data);
+    block_excl_scan<4>(L.data_count(), s_wave, total_data); // (barriers inside: s_bad is initialised for everyone)
     block_excl_scan<4>(L.mark_count(), s_wave, total_mark);
+    const uint32_t fb = L.first_bad();
+    if (fb < 16u) atomicMin(&s_bad, gpos + fb);
+    __syncthreads();
     if (threadIdx.x == 0) {
         as_global(P.win_data)[w]  = total_data;
         as_global(P.win_nmark)[w] = total_mark;
+        as_global(P.win_bad)[w]   = s_bad;
     }
 }
 
@@ -216,7 +248,18 @@ __global__ __launch_bounds__(PL) void front_prefix(FS src)
     __shared__ uint32_t s_wave[PL / 64];
     scan_array(as_global(P.win_data), as_global(P.win_prefix), P.num_windows, s_wave);
     scan_array(as_global(P.win_nmark), as_global(P.mark_off), P.num_windows, s_wave);
-    if (threadIdx.x == 0) as_global(P.status)[7] = 0xFFFFFFFFu; // ordinal of the terminating marker (front_marks)
+    // first "FF FF 00" of the transferred bytes (the host walk refuses it inside the scan, jg_reader.cpp walk_scan)
+    __shared__ uint32_t s_bad;
+    if (threadIdx.x == 0) s_bad = 0xFFFFFFFFu;
+    __syncthreads();
+    uint32_t bad = 0xFFFFFFFFu;
+    for (uint32_t i = threadIdx.x; i < P.num_windows; i += PL) bad = min(bad, as_global(P.win_bad)[i]);
+    if (bad != 0xFFFFFFFFu) atomicMin(&s_bad, bad);
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        as_global(P.status)[6] = s_bad;
+        as_global(P.status)[7] = 0xFFFFFFFFu; // ordinal of the terminating marker (front_marks)
+    }
 }
 
 template <class FS>
@@ -237,8 +280,12 @@ __global__ __launch_bounds__(PL) void front_plan(FS src)
 
     const uint32_t T = stat[7]; // ordinal of the first marker that is not RSTn, among the first E + 1 markers
     uint32_t status  = 0;       // JPEGGPU_SUCCESS
-    if (T == 0xFFFFFFFFu) status = as_global(P.mark_off)[P.num_windows] > E ? 2u : 6u; // too many restart markers : none ends the scan
-    else if (T + 1 != E) status = 2;                                                   // JPEGGPU_INVALID_JPEG: segments do not match the geometry
+    // JPEGGPU_INVALID_JPEG, as the host walk says in each of these cases (jg_reader.cpp walk_scan): no marker ends the
+    // scan (or more restart markers than the geometry allows), segments that do not match the geometry, an
+    // "FF FF 00" in front of the terminating marker
+    if (T == 0xFFFFFFFFu) status = 2;
+    else if (T + 1 != E) status = 2;
+    else if (stat[6] < mkp[T]) status = 2;
     if (status != 0) {
         // nothing downstream may run on tables that were not built
         if (tid == 0) {
@@ -354,11 +401,11 @@ __global__ __launch_bounds__(PL) void front_plan(FS src)
 
 } // namespace
 
-hipError_t launch_front(const FrontParams& P, hipStream_t stream)
+hipError_t launch_front(const FrontParams& P, const ScanJob& job, hipStream_t stream)
 {
     if (P.num_windows == 0) return hipErrorInvalidValue;
     const FrontOne src{P};
-    front_count<<<P.num_windows, 256, 0, stream>>>(src);
+    front_count<<<P.num_windows, 256, 0, stream>>>(FrontOneJob{P, job});
     front_prefix<<<1, PL, 0, stream>>>(src);
     front_marks<<<P.num_windows, 256, 0, stream>>>(src);
     front_plan<<<1, PL, 0, stream>>>(src);

@@ -21,6 +21,7 @@ struct FrontParams {
     uint32_t max_parts;        // entries of tail_parts (parts + 1)
     uint32_t* win_data;        // [num_windows]      data bytes per window
     uint32_t* win_nmark;       // [num_windows]      markers per window
+    uint32_t* win_bad;         // [num_windows]      position of the first FF FF 00 of the window, or 0xFFFFFFFF
     uint32_t* win_prefix;      // [num_windows + 1]
     uint32_t* mark_off;        // [num_windows + 1]
     uint32_t* mk_pos;          // [expect_segments + 1]  position of the i-th marker of the scan
@@ -31,10 +32,12 @@ struct FrontParams {
     DestuffChunk* chunks;      // [max_chunks]               out
     int* tail_parts;           // [max_parts]                out
     ScanJob* job;              // the scan's job in device memory: counts are filled in
-    uint32_t* status;          // [8]: jpeggpu_status, subsequences, segments, chunks, tail parts, -, -, terminator ordinal
+    uint32_t* status;          // [8]: jpeggpu_status, subsequences, segments, chunks, tail parts, -, first FF FF 00, terminator ordinal
 };
 
-hipError_t launch_front(const FrontParams& P, hipStream_t stream);
+/// One scan, parameters by value. `job` is stored to P.job by the first kernel (a kernel argument is captured at
+/// launch, so the caller's copy may change as soon as this returns -- no staging buffer, no copy from pageable memory).
+hipError_t launch_front(const FrontParams& P, const ScanJob& job, hipStream_t stream);
 /// The same for `count` scans whose parameters sit in device memory (grid.y = scan).
 hipError_t launch_front_batch(const FrontParams* d_params, int count, uint32_t max_windows, hipStream_t stream);
 

@@ -296,7 +296,7 @@ __device__ __forceinline__ void load_tables(uint8_t* s_tab, JG_GLOBAL const uint
     for (uint32_t i = threadIdx.x; i < sp.tab_bytes / 16; i += blockDim.x) {
         uint4 v = ld_global(s + i);
         if (i >= ring) {
-            v.x += base * 0x00010001u; // LDS addresses stay below 64 KB (launch_huff checks the size)
+            v.x += base * 0x00010001u; // LDS addresses stay below 64 KiB: static_asserts at the carves, launch_huff at run time
             v.z += base;
             v.w += base;
         }
@@ -311,6 +311,9 @@ struct SeqLds {
     static constexpr uint32_t kTabs  = (kState + 6 * (T + 1) * 4 + 64 + 15) / 16 * 16; // 5 state arrays / scan scratch
     static_assert(kTabs % 16 == 0, "the table pack is read with 16-byte loads");
 };
+/// Static LDS of a kernel precedes its dynamic LDS; the Huffman kernels declare at most this much.
+constexpr uint32_t kStaticLdsSlack = 256;
+static_assert(kStaticLdsSlack + SeqLds::kTabs + kMaxTablePack <= 65536, "absolute table addresses are packed into 16 bits (load_tables)");
 
 __device__ __forceinline__ uint32_t pk_add(uint32_t a, uint32_t b) { return pk_add_u16(a, b); }
 
@@ -763,7 +766,9 @@ struct WriteLds {
     static constexpr uint32_t kRing = ((T + 8) * 4 + 15) / 16 * 16;
     static constexpr uint32_t kTabs = kRing + (kStageEntries + 1) * T * 4; // + the spare row of StreamSink::push
     static_assert(kTabs % 16 == 0, "the table pack is read with 16-byte loads");
+    static_assert(kStaticLdsSlack + kTabs + kMaxTablePack <= 65536, "absolute table addresses are packed into 16 bits (load_tables)");
 };
+static_assert(kStaticLdsSlack + 3 * kTailLanesLarge * 4 + kMaxTablePack <= 65536, "huff_sync_tail: the same bound");
 
 /// Re-decode every subsequence from its predecessor's synchronised exit state and emit the symbol
 /// stream (StreamSink). The coefficient-slot position of subsequence i inside its segment = sum of n
@@ -1201,6 +1206,8 @@ hipError_t launch_huff(Stage stage, const JS& js, const JobExtent& e, int grid_y
 {
     const size_t seq_lds = SeqLds::kTabs + e.max_tab_bytes;
     hipError_t err       = hipSuccess;
+    // the cursor ring holds absolute LDS addresses in 16 bits (load_tables): refuse rather than wrap
+    if (e.max_tab_bytes > kMaxTablePack) return hipErrorInvalidValue;
     switch (stage) {
     case kStageSyncIntra:
         if ((err = allow_lds(huff_sync_intra<W, JS>, seq_lds)) != hipSuccess) return err;

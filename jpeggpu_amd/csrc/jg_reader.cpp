@@ -422,6 +422,9 @@ jpeggpu_status Reader::read_sos(const Logger& log)
             scan.table_pack.insert(scan.table_pack.end(), ac_tab_[sc.ac_id].begin(), ac_tab_[sc.ac_id].end());
         }
     }
+    // 16-bit offsets above, 16-bit LDS addresses on the device: cannot trip while jg_defs.h's static_assert on
+    // kMaxTablePack holds, and must fail rather than wrap if a constant is ever raised without it
+    if (scan.table_pack.size() + static_cast<size_t>(kMaxDuPerMcu) * sizeof(CursorEntry) > kMaxTablePack) return JPEGGPU_INTERNAL_ERROR;
     // cursor ring behind the tables (jg_defs.h): one entry per data unit of the MCU
     scan.cursor_off = static_cast<uint32_t>(scan.table_pack.size());
     {
@@ -451,9 +454,22 @@ jpeggpu_status Reader::read_sos(const Logger& log)
         // restart markers and the end of the scan. Upper bounds: a segment of d data bytes has
         // ceil(d / subsequence) subsequences, so at most (bytes / subsequence) + segments in total; a chunk
         // is a 4 KiB window of one segment.
-        const size_t bytes    = static_cast<size_t>(end_ - base_) - scan.begin;
+        // The copy need not run to the end of the file: nothing behind the LAST end-of-image marker can belong to
+        // the scan. Found from the back -- free for a file that ends in FF D9, a sweep over the padding for one
+        // that carries zeros or a trailer behind it (reference photo: 1.17 MB of zeros) -- without touching the scan.
+        const uint8_t* stop = end_;
+        for (const uint8_t* q = end_; q - (base_ + scan.begin) >= 2;) {
+            q = static_cast<const uint8_t*>(memrchr(base_ + scan.begin + 1, 0xD9, static_cast<size_t>(q - (base_ + scan.begin + 1))));
+            if (!q) break;
+            if (q[-1] == 0xFF) {
+                stop = q + 1;
+                break;
+            }
+        }
+        const size_t file_end = static_cast<size_t>(stop - base_);
+        const size_t bytes    = file_end - scan.begin;
         const size_t segments = static_cast<size_t>(ceil_div(total_mcus, scan.mcus_per_segment));
-        const size_t windows  = (static_cast<size_t>(end_ - base_) - s.xfer_begin + kDestuffWin - 1) / kDestuffWin;
+        const size_t windows  = (file_end - s.xfer_begin + kDestuffWin - 1) / kDestuffWin;
         const size_t subseq   = bytes / static_cast<size_t>(subseq_bytes_) + segments + 1;
         if (segments <= (1u << 20) && subseq < (1u << 24) && bytes < (1u << 27)) {
             scan.device_walk     = true;
@@ -461,7 +477,7 @@ jpeggpu_status Reader::read_sos(const Logger& log)
             scan.num_subseq      = static_cast<int>(subseq);
             scan.max_chunks      = static_cast<int>(windows + segments + 1);
             scan.max_tail_parts  = static_cast<int>(subseq / kTailPartSubseq + 3);
-            scan.end             = static_cast<size_t>(end_ - base_);
+            scan.end             = file_end;
             s.xfer_end           = scan.end;
             stop_                = true;
             return JPEGGPU_SUCCESS;

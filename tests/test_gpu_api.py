@@ -413,7 +413,7 @@ def test_device_side_marker_scan(torch_cuda):
     good = m["multi_seq_dri"]
     cut = good[: len(good) * 2 // 3]                       # no terminating marker
     status, planes, _, _ = _decode_device_scan(torch, jpeggpu_amd, cut, 128)
-    assert status == Status.INCOMPLETE_BITSTREAM and all((p == 0x5A).all() for p in planes)
+    assert status == Status.INVALID_JPEG and all((p == 0x5A).all() for p in planes)  # the host walk's code for it
     sos = good.index(b"\xff\xda")
     dri = good.index(b"\xff\xdd")
     assert dri < sos
@@ -421,6 +421,48 @@ def test_device_side_marker_scan(torch_cuda):
     wrong[dri + 5] ^= 0x20                                 # a restart interval (64 -> 96 MCUs) the markers do not follow
     status, planes, _, _ = _decode_device_scan(torch, jpeggpu_amd, bytes(wrong), 128)
     assert status == Status.INVALID_JPEG and all((p == 0x5A).all() for p in planes)
+
+
+def test_device_scan_agrees_with_host_walk_on_refusals(torch_cuda, monkeypatch):
+    """What the host walk refuses at parse time gets the same status from the device: an FF FF 00 inside
+    the scan (neither fill byte + marker nor stuffing), a scan no marker ends. And the checked mode that
+    JPEGGPU_DEVICE_SCAN=1 selects for callers of the drop-in API alone: decode itself returns that status."""
+    import jpeggpu_amd
+    from jpeggpu_amd import JpegGpuError, Status
+
+    torch = torch_cuda
+    good = cases.matrix()["dri_fill"]  # restart markers with FF fill bytes in front: legal
+    rst = good.index(b"\xff\xff\xff\xd0")
+    ffzero = good[:rst] + b"\xff\xff\x00" + good[rst:]          # fill byte followed by a stuffed FF
+    cut = good[: len(good) * 2 // 3]
+    behind_eoi = good + b"\xff\xff\x00" + bytes(100)             # the same sequence behind the image: not the scan's business
+    for name, data, want in (("good", good, Status.SUCCESS), ("ffzero", ffzero, Status.INVALID_JPEG),
+                             ("cut", cut, Status.INVALID_JPEG), ("behind_eoi", behind_eoi, Status.SUCCESS)):
+        host = jpeggpu_amd.Decoder()
+        try:
+            host.parse_header(data)
+            host_status = Status.SUCCESS
+        except JpegGpuError as e:
+            host_status = e.status
+        host.cleanup()
+        assert host_status == want, (name, host_status)
+        status, planes, lay, _ = _decode_device_scan(torch, jpeggpu_amd, data, 128)
+        assert lay.scans[0].device_scan and status == want, (name, status)
+        assert want == Status.SUCCESS or all((p == 0x5A).all() for p in planes)
+        # checked mode through the environment variable, drop-in calls only
+        monkeypatch.setenv("JPEGGPU_DEVICE_SCAN", "1")
+        dec = jpeggpu_amd.Decoder()
+        monkeypatch.delenv("JPEGGPU_DEVICE_SCAN")
+        info = dec.parse_header(data)
+        n, tmp, base, pl = _alloc(torch, dec, info)
+        dec.transfer(base, n, 0)
+        try:
+            dec.decode([p.data_ptr() for p in pl], [p.stride(0) for p in pl], base, n, 0)
+            got = Status.SUCCESS
+        except JpegGpuError as e:
+            got = e.status
+        assert got == want, (name, got)
+        dec.cleanup()
 
 
 def test_batch_with_bad_device_scanned_items(torch_cuda):
@@ -437,7 +479,7 @@ def test_batch_with_bad_device_scanned_items(torch_cuda):
     cut = good[: len(good) * 2 // 3]
     wrong = bytearray(good)
     wrong[good.index(b"\xff\xdd") + 5] ^= 0x20
-    items = [("good_host", good, False, Status.SUCCESS), ("cut", cut, True, Status.INCOMPLETE_BITSTREAM),
+    items = [("good_host", good, False, Status.SUCCESS), ("cut", cut, True, Status.INVALID_JPEG),
              ("good_dev", good, True, Status.SUCCESS), ("wrong_dri", bytes(wrong), True, Status.INVALID_JPEG),
              ("other_dev", m["dri_row"], True, Status.SUCCESS), ("gray_host", m["gray"], False, Status.SUCCESS)] * 3
     keep, entries = [], []

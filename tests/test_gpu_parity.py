@@ -108,8 +108,15 @@ def test_reference_photo_full_size(gpu_lib, torch_cuda, photo_bytes):
     assert list(info.sizes_x)[:3] == [4032, 2016, 2016] and list(info.sizes_y)[:3] == [3024, 1512, 1512]
     for c in range(3):
         assert np.array_equal(got[c], ref.planes[c]), "component %d" % c
-    # the same with the marker scan on the device: the 1.17 MB behind EOI (an embedded second JPEG with its own
-    # markers) must not confuse the search for the end of the scan
-    planes, _ = jpeggpu_amd.decode_to_planes(photo_bytes, device_scan=True)
+    # the same with the marker scan on the device. The 1.17 MB of padding behind EOI is not transferred (host search
+    # for the last EOI from the back, reference src/decoder.cpp:175-180 copies the whole file) ...
+    planes, _, _tmp, _base, lay = jpeggpu_amd.decode_to_planes(photo_bytes, device_scan=True, return_tmp=True)
+    assert lay.scans[0].device_scan and lay.transferred_bytes < 2_910_000
     for c in range(3):
         assert np.array_equal(planes[c].cpu().numpy(), ref.planes[c]), "device scan, component %d" % c
+    # ... and a trailer that holds markers of its own (an appended second JPEG) must not confuse the search for the
+    # end of the scan
+    tail = photo_bytes[:20000] + b"\xff\xd9"
+    planes, _ = jpeggpu_amd.decode_to_planes(photo_bytes[:2921333] + tail, device_scan=True)
+    for c in range(3):
+        assert np.array_equal(planes[c].cpu().numpy(), ref.planes[c]), "device scan with trailer, component %d" % c
