@@ -42,9 +42,11 @@ struct jpeggpu_ext_scan_layout {
     /* byte offsets inside d_tmp */
     size_t off_segments;       /* {int subseq_offset, subseq_count}[num_segments] */
     size_t off_chunks;
-    size_t off_destuffed;      /* uint8[num_subsequences * subsequence_bytes], TILED: 32-bit word k of subsequence t
-                                  is word (t / 32) * 32 * W + k * 32 + t % 32, W = subsequence_bytes / 4; a word holds
-                                  its four stream bytes most significant first (stream byte i is byte 3 - i % 4) */
+    size_t off_destuffed;      /* destuffed bytes, TILED in rows of W + 3 words (W = subsequence_bytes / 4): slot s of
+                                  subsequence t is 32-bit word ((t / 32) * (W + 3) + s) * 32 + t % 32; slots 1..W are
+                                  the subsequence's own words, slot 0 mirrors the last word of subsequence t - 1,
+                                  slots W + 1 and W + 2 the first two of t + 1; a word holds its four stream bytes
+                                  most significant first (stream byte i is byte 3 - i % 4) */
     size_t off_segment_index;  /* int[num_subsequences] */
     size_t off_state_p;        /* int[num_subsequences] */
     size_t off_state_n;

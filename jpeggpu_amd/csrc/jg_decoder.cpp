@@ -69,7 +69,7 @@ struct StagingBuffer {
 
 struct ScanPlan {
     // offsets inside the blob (and, shifted by off_blob, inside d_tmp)
-    size_t blob_tables = 0, blob_segments = 0, blob_chunks = 0, blob_parts = 0;
+    size_t blob_tables = 0, blob_tables_sync = 0, blob_segments = 0, blob_chunks = 0, blob_parts = 0;
     // offsets inside d_tmp
     size_t destuffed = 0, seg_idx = 0, st_p = 0, st_n = 0, st_cz = 0, st_dc01 = 0, st_dc23 = 0;
     size_t tails_n = 0, tails_dc01 = 0, tails_dc23 = 0, pending = 0, flow_list = 0;
@@ -137,6 +137,8 @@ void Decoder::make_plan()
         ScanPlan& sp      = p.scan[i];
         sp.blob_tables    = b;
         b += align_up(sc.table_pack.size(), 256);
+        sp.blob_tables_sync = b;
+        b += align_up(sc.table_pack_sync.size(), 256);
         sp.blob_segments  = b;
         b += align_up(sc.segments.size() * sizeof(Segment), 256);
         sp.blob_chunks    = b;
@@ -159,7 +161,7 @@ void Decoder::make_plan()
         const size_t S = static_cast<size_t>(sc.num_subseq);
         sp.num_seq     = static_cast<int>((S + kSeqSubseq - 1) / kSeqSubseq);
         sp.destuffed   = o;
-        o += align_up((S + 2 * kTileSubseq) / kTileSubseq * kTileSubseq * subseq_bytes + 256, 256); // whole tiles, more than one spare
+        o += align_up(tiled_buffer_bytes(static_cast<uint32_t>(S), subseq_bytes, 2) + 256, 256); // whole tiles of padded rows, two spare
         sp.seg_idx = o;
         o += align_up(S * 4, 256);
         sp.st_p = o;
@@ -249,6 +251,7 @@ bool Decoder::fill_blob()
         const Scan& sc     = s.scans[i];
         const ScanPlan& sp = plan.scan[i];
         std::memcpy(blob.ptr + sp.blob_tables, sc.table_pack.data(), sc.table_pack.size());
+        std::memcpy(blob.ptr + sp.blob_tables_sync, sc.table_pack_sync.data(), sc.table_pack_sync.size());
         if (!sc.segments.empty())
             std::memcpy(blob.ptr + sp.blob_segments, sc.segments.data(), sc.segments.size() * sizeof(Segment));
         if (!sc.chunks.empty())
@@ -322,6 +325,8 @@ jpeggpu_status build_jobs(
         sp.tab_bytes        = static_cast<uint32_t>(sc.table_pack.size());
         sp.max_intra_iters  = max_intra_iters;
         sp.cursor_off       = sc.cursor_off;
+        sp.tab_bytes_sync   = static_cast<uint32_t>(sc.table_pack_sync.size());
+        sp.cursor_off_sync  = sc.cursor_off_sync;
         IdctParams& ip = job.ip;
         ip.num_du      = sc.num_du;
         ip.du_per_mcu  = sc.du_per_mcu;
@@ -355,6 +360,7 @@ jpeggpu_status build_jobs(
         job.chunks     = reinterpret_cast<const DestuffChunk*>(blob + pl.blob_chunks);
         job.segments   = reinterpret_cast<const Segment*>(blob + pl.blob_segments);
         job.tables     = blob + pl.blob_tables;
+        job.tables_sync = blob + pl.blob_tables_sync;
         job.qtables    = reinterpret_cast<const uint16_t*>(blob + plan.blob_qtables);
         job.destuffed  = base + pl.destuffed;
         job.seg_idx    = reinterpret_cast<int*>(base + pl.seg_idx);

@@ -66,18 +66,38 @@ constexpr int kLutBitsDc   = 9;
 constexpr int kLutBitsAc   = 11;
 constexpr int kSubBits     = 5;
 constexpr int kSubTableSize = 2 << kSubBits; // bytes
-constexpr int kMaxSubTables = 32;
+constexpr int kMaxSubTables = 16;
 constexpr int kHuffAuxSize = 16 + 16 + 256;
 constexpr int kDcTableSize = (2 << kLutBitsDc) + kHuffAuxSize; // 1312, plus second-level tables
 constexpr int kAcTableSize = (2 << kLutBitsAc) + kHuffAuxSize; // 4384, plus second-level tables
 
+/// A scan has TWO table packs. The write pass, which needs every symbol's magnitude, uses the pack described
+/// above. The state-only passes (speculation, flows) use the SYNC pack: the same tables with 32-bit first-level
+/// entries, low half = the entry above, high half = a MULTI-SYMBOL entry of the same shape for the same window
+/// bits:
+///     bits 0..4   total length of ALL the symbols it stands for (every code with its magnitude bits lies inside
+///                 the LB index bits)
+///     bits 5..8   zig-zag advance of all but the last of them (at most 15)
+///     bits 9..15  zig-zag advance of all of them (an end-of-block, which can only be the last, counts 64)
+/// -- as many AC symbols as fit, decoded with this same table, which is right as long as the data unit does not end
+/// in front of the last of them: the symbol loop takes the high half unless index + advance of the earlier symbols
+/// reaches 64 (jg_huff_core.h). Where no second symbol fits the high half repeats the low one (its bits 5..8 are
+/// then a category; a test that fails for it falls back to the same entry). A state-only pass then takes ~1.6
+/// symbols per step on photographic data. DC tables and the second-level tables hold single symbols only.
+constexpr int kSyncEntryBytes = 4;
+constexpr int kMultiMaxPre    = 15;
+constexpr int kDcTableSizeSync = (kSyncEntryBytes << kLutBitsDc) + kHuffAuxSize;
+constexpr int kAcTableSizeSync = (kSyncEntryBytes << kLutBitsAc) + kHuffAuxSize;
+
 /// Largest table pack of a scan: four DC and four AC tables with every second-level table, plus the cursor
 /// ring. Offsets into the pack are kept in 16 bits (Scan::dc_off / ac_off, the halves of CursorEntry::tabs),
 /// and on the device the kernels turn them into absolute LDS addresses that must stay below 64 KiB as well
-/// (jg_kernels.hip checks its carve bases against this constant).
+/// (jg_kernels.hip checks its carve bases against these constants).
 constexpr uint32_t kMaxTablePack =
     kMaxComp * (kDcTableSize + kMaxSubTables * kSubTableSize) + kMaxComp * (kAcTableSize + kMaxSubTables * kSubTableSize) + kMaxDuPerMcu * 16;
-static_assert(kMaxTablePack < 65536, "table offsets are 16-bit");
+constexpr uint32_t kMaxTablePackSync =
+    kMaxComp * (kDcTableSizeSync + kMaxSubTables * kSubTableSize) + kMaxComp * (kAcTableSizeSync + kMaxSubTables * kSubTableSize) + kMaxDuPerMcu * 16;
+static_assert(kMaxTablePack < 65536 && kMaxTablePackSync < 65536, "table offsets are 16-bit");
 
 JG_HD inline uint32_t huff_entry(int codelen, uint32_t sym, bool is_dc)
 {
@@ -89,16 +109,41 @@ JG_HD inline uint32_t huff_entry(int codelen, uint32_t sym, bool is_dc)
     return (static_cast<uint32_t>(codelen) + s) | (s << 5) | ((eob ? 64u : r + 1u) << 9);
 }
 
-/// Layout of the destuffed buffer: TILES of kTileSubseq subsequences, word-major inside a tile -- word k
-/// of subsequence t is 32-bit word (t / 32) * 32 * W + k * 32 + t % 32 (W = words per subsequence). The
-/// lanes of a wave walk 64 different subsequences at about the same pace, so their 4-byte refills fall
-/// into a few shared 128-byte lines; with the plain layout every refill touched its own line
-/// (lane stride = 128 B) and the write pass fetched 25x the bitstream (rocprofv3 FETCH_SIZE).
-constexpr int kTileSubseq = 32;
+/// Layout of the destuffed buffer: TILES of kTileSubseq subsequences, word-major inside a tile. The lanes
+/// of a wave walk 64 different subsequences at about the same pace, so their 4-byte refills fall into a few
+/// shared 128-byte lines; with the plain layout every refill touched its own line (lane stride = 128 B) and the
+/// write pass fetched 25x the bitstream (rocprofv3 FETCH_SIZE).
+///
+/// A subsequence's ROW holds its W words (W = words per subsequence) AND copies of its neighbours' words
+/// around them: slot 0 = the last word of the previous subsequence, slots 1..W = its own words, slots W+1 and
+/// W+2 = the first two words of the next subsequence. A decode of subsequence t starts at most 31 bits in
+/// front of it and looks at most 64 bits past its end (32-bit peek + one prefetched word), so every word it
+/// touches is in row t and the address of the next word is the previous one plus 128: the refill, which a
+/// wave executes in nearly every iteration of the symbol loop (some lane always needs a word), costs one
+/// add instead of the seven instructions of the general tiled address. destuff_kernel stores every word up to
+/// three times (+9 % bytes at W = 32); rows at the ends of the buffer keep slots nobody wrote, which no
+/// committed symbol depends on (jg_kernels.hip, GlobalFetch).
+///
+///   slot s of row t:  32-bit word ((t / 32) * (W + 3) + s) * 32 + t % 32
+constexpr int kTileSubseq  = 32;
+constexpr int kRowLeadWords = 1; // copies in front of the row's own words
+constexpr int kRowTailWords = 2; // copies behind them
+constexpr int kRowExtraWords = kRowLeadWords + kRowTailWords;
+/// 32-bit word index of slot `slot` of row `row`.
+JG_HD inline uint32_t tiled_slot(uint32_t row, uint32_t slot, int log2_w)
+{
+    return ((row >> 5) * ((1u << log2_w) + kRowExtraWords) + slot) * 32u + (row & 31u);
+}
+/// Word index of the MAIN copy of linear word `linear_word` of the scan.
 JG_HD inline uint32_t tiled_word(uint32_t linear_word, int log2_w)
 {
-    const uint32_t t = linear_word >> log2_w, k = linear_word & ((1u << log2_w) - 1u);
-    return ((t >> 5) << (5 + log2_w)) + (k << 5) + (t & 31u);
+    return tiled_slot(linear_word >> log2_w, (linear_word & ((1u << log2_w) - 1u)) + kRowLeadWords, log2_w);
+}
+/// Bytes of the tiled buffer for `num_subseq` subsequences plus `spare_tiles` whole tiles behind them.
+JG_HD inline uint64_t tiled_buffer_bytes(uint32_t num_subseq, int subseq_bytes, int spare_tiles)
+{
+    const uint64_t tiles = (static_cast<uint64_t>(num_subseq) + kTileSubseq - 1) / kTileSubseq + static_cast<uint64_t>(spare_tiles);
+    return tiles * kTileSubseq * (static_cast<uint64_t>(subseq_bytes) + 4u * kRowExtraWords);
 }
 
 /// Entries of the symbol stream reserved per subsequence: an emitted entry (DC, or a non-zero AC
@@ -170,8 +215,15 @@ struct ScanParams {
     int total_mcus;
     int subseq_words;     // 32-bit words per subsequence (subsequence bytes / 4)
     int max_intra_iters;  // lock-step flow iterations inside huff_sync_intra before flows are handed to huff_sync_tail
-    uint32_t tab_bytes;   // size of the scan's Huffman table pack (tables + cursor ring)
-    uint32_t cursor_off;  // byte offset of the cursor ring in the pack
+    uint32_t tab_bytes;   // size of the scan's Huffman table pack (tables + cursor ring) the kernel at hand uses
+    uint32_t cursor_off;  // byte offset of the cursor ring in that pack
+    uint32_t tab_bytes_sync, cursor_off_sync; // the same for the sync pack (state-only passes)
+    /// The state-only kernels call this on their copy of the parameters before loading the tables.
+    JG_HD inline void use_sync_pack()
+    {
+        tab_bytes  = tab_bytes_sync;
+        cursor_off = cursor_off_sync;
+    }
 };
 
 struct CursorEntry {
@@ -225,7 +277,8 @@ struct ScanJob {
     const uint8_t* bytes;        // transferred entropy-coded bytes of the image
     const DestuffChunk* chunks;
     const Segment* segments;
-    const uint8_t* tables;       // Huffman table pack of the scan
+    const uint8_t* tables;       // Huffman table pack of the scan (write pass)
+    const uint8_t* tables_sync;  // sync pack of the scan (state-only passes)
     const uint16_t* qtables;     // uint16[4][64], natural order
     uint8_t* destuffed;
     int* seg_idx;                // subsequence -> segment

@@ -47,47 +47,65 @@ JG_HD inline uint32_t pk_add_u16(uint32_t a, uint32_t b)
 #endif
 }
 
-/// MSB-first 64-bit window over 32-bit words of the segment's destuffed data. A `Fetch` walks the words in
-/// order: `start(w)` gives the position of word `w`, `load(pos)` issues the load, `advance(pos)` steps to the
-/// next word, and `cook(raw, pos)` turns the loaded value into the word as the window wants it (the host twin
-/// reads zero past the segment's padded end as the reference does, decode_huffman_reader.hpp:110-152; the device
-/// fetch does not need to, see GlobalFetch). `next_raw` always holds the word at
-/// `pos`, fetched one refill before it is cooked and shifted in: nothing touches the loaded value in between,
-/// so the load's latency is covered by the symbols decoded meanwhile.
+/// MSB-first bit window over 32-bit words of the segment's destuffed data: two consecutive words `hi`, `lo` and
+/// the number of bits `sh` by which the pair has to be shifted right for the window's 32 bits to land in the low
+/// word (0..31; the window starts 32 - sh bits into `hi`, at sh == 0 at the first bit of `lo`). Looking at the
+/// window is one funnel shift (v_alignbit_b32), consuming bits one subtraction, and a refill -- which a wave of 64
+/// lanes executes in nearly every iteration of the symbol loop, because some lane always needs one -- two moves and
+/// two adds: `hi = lo, lo = next word, sh += 32`, and the step to the following word. (A 64-bit window that ORs
+/// the shifted word in costs a 64-bit shift, two ORs and the bookkeeping of the bit count on top.)
+///
+/// A `Fetch` walks the words in order: `start(w)` gives the position of word `w` of the segment, `load(pos)`
+/// issues the load, `advance(pos)` steps to the next word, and `cook(raw, pos)` turns the loaded value into the
+/// word as the window wants it (the host twin reads zero past the segment's padded end as the reference does,
+/// decode_huffman_reader.hpp:110-152; the device fetch does not need to, see GlobalFetch). `next_raw` always holds
+/// the word at `pos`, fetched one refill before it is cooked and moved in: nothing touches the loaded value in
+/// between, so the load's latency is covered by the symbols decoded meanwhile.
 template <class Fetch>
 struct BitWindow {
-    uint64_t win;
-    int avail;
+    uint32_t hi, lo;
+    int sh;
     typename Fetch::Pos pos;
     uint32_t next_raw;
 
+    /// Window at bit `p` (>= 0) of the segment. The pair starts at the word that holds bit p - 1, so that sh stays
+    /// in 0..31; at p == 0 that is the word in front of the segment, which is loaded but never looked at.
     JG_HD inline void seek(int p, const Fetch& fetch)
     {
-        const int off = p & 31;
-        pos           = fetch.start(p >> 5);
-        const uint32_t hi = fetch.cook(fetch.load(pos), pos);
+        const int q = p - 1;
+        sh          = 31 - (q & 31);
+        pos         = fetch.start(q >> 5); // arithmetic shift: -1 for q == -1
+        hi          = fetch.cook(fetch.load(pos), pos);
         fetch.advance(pos);
-        const uint32_t lo = fetch.cook(fetch.load(pos), pos);
+        lo = fetch.cook(fetch.load(pos), pos);
         fetch.advance(pos);
-        win      = ((static_cast<uint64_t>(hi) << 32) | lo) << off;
-        avail    = 64 - off;
         next_raw = fetch.load(pos);
     }
     JG_HD inline uint32_t peek(const Fetch& fetch)
     {
-        if (avail < 32) {
-            win |= static_cast<uint64_t>(fetch.cook(next_raw, pos)) << (32 - avail);
-            avail += 32;
+        if (sh < 0) { // at most 32 bits are consumed between two looks: one step is enough
+            hi = lo;
+#if defined(__HIP_DEVICE_COMPILE__)
+            // A real move at THIS point: left to itself the register coalescer lets `lo` and `next_raw` share a
+            // register, loads the new word into a temporary and copies it over at the loop's back edge -- behind
+            // an s_waitcnt for the load issued a few instructions earlier, which exposes the whole memory latency
+            // in every iteration (measured: write pass +21 %). With the move pinned here the load below targets
+            // next_raw's own register and is waited for one refill later.
+            asm("v_mov_b32 %0, %1" : "=v"(lo) : "v"(fetch.cook(next_raw, pos)));
+#else
+            lo = fetch.cook(next_raw, pos);
+#endif
+            sh += 32;
             fetch.advance(pos);
             next_raw = fetch.load(pos);
         }
-        return static_cast<uint32_t>(win >> 32);
+#if defined(__HIP_DEVICE_COMPILE__)
+        return __builtin_amdgcn_alignbit(hi, lo, static_cast<uint32_t>(sh));
+#else
+        return static_cast<uint32_t>(((static_cast<uint64_t>(hi) << 32) | lo) >> sh);
+#endif
     }
-    JG_HD inline void skip(int len)
-    {
-        win <<= len;
-        avail -= len;
-    }
+    JG_HD inline void skip(int len) { sh -= len; }
 };
 
 /// Pointers into the scan's table pack. On the device the pack lives in LDS and the offsets a kernel hands to the
@@ -105,6 +123,7 @@ struct BitWindow {
 typedef JG_TAB_AS const uint8_t* TabPtr;
 
 JG_HD inline uint32_t ld_u16(TabPtr p) { return *reinterpret_cast<JG_TAB_AS const uint16_t*>(p); }
+JG_HD inline uint32_t ld_u32(TabPtr p) { return *reinterpret_cast<JG_TAB_AS const uint32_t*>(p); }
 
 /// Code longer than the first-level LUT: find its length by counting thresholds (all eight
 /// thresholds come from one 16-byte read), then one huffval read. Reproduces the reference's
@@ -130,10 +149,11 @@ JG_HD inline uint32_t huff_long_code(TabPtr aux, uint32_t peek, bool is_dc)
 
 /// First-level entry without a length: second-level table if the host built one for this prefix,
 /// else the long-code path.
+template <int kEntryBytes = 2>
 JG_HD inline uint32_t huff_second_level(TabPtr tab, uint32_t e, uint32_t peek, bool is_dc)
 {
     const int lb       = is_dc ? kLutBitsDc : kLutBitsAc;
-    const TabPtr aux   = tab + (is_dc ? (2 << kLutBitsDc) : (2 << kLutBitsAc));
+    const TabPtr aux   = tab + (is_dc ? (kEntryBytes << kLutBitsDc) : (kEntryBytes << kLutBitsAc));
     if (e != 0) {
         const uint32_t i2 = (peek >> (32 - kSubBits - lb)) & ((1u << kSubBits) - 1u);
         e                 = ld_u16(aux + kHuffAuxSize - kSubTableSize + (e >> 5) * kSubTableSize + 2 * i2);
@@ -280,16 +300,46 @@ JG_HD inline void decode_subsequence(
             JG_COMMIT();
         }
     } else {
-        // State-only passes: the loop is written rotated -- look the next symbol up at the END of the body, test it
-        // in the loop condition -- so that the compiler emits one compare and one conditional back edge for "does
-        // the symbol still fit" instead of an exit mask plus a guarded region (two compares of the same operands):
-        // -6 % for the sync kernels. In both forms the DC / AC choice of a symbol is the unit-end flag of the one
-        // before it, not a compare of z with 0.
-        JG_LOOKUP();
+        // State-only passes walk the SYNC pack (jg_defs.h): 32-bit first-level entries whose high half stands for
+        // as many AC symbols as lie inside the index bits. While at least 31 bits are left in front of `end_bit`
+        // whatever an entry stands for fits (a symbol takes at most 16 + 15 bits, a multi-symbol entry at most the 11
+        // index bits), so the main loop does not ask; it takes the high half unless the data unit would end in
+        // front of the last of its symbols -- index + advance of the earlier ones reaching 64: the following
+        // symbol is then a DC symbol of the next unit, not what the AC table made of those bits -- and the low
+        // half, the first symbol alone, otherwise. The symbols committed are exactly those of the one-symbol-per-
+        // step loop, which finishes the subsequence: it looks the next symbol up at the END of the body and tests
+        // it in the loop condition (one compare and one conditional back edge for "does the symbol still fit").
+        // In both loops the DC / AC choice of a symbol is the unit-end flag of the one before it.
+        while (end_bit - p >= 31) {
+            peek               = bw.peek(fetch);
+            const TabPtr tab   = JG_TAB_AT(tabs, is_dc ? (JG_CUR_TABS & 0xFFFFu) : (JG_CUR_TABS >> 16));
+            const uint32_t idx = peek >> (is_dc ? 32 - kLutBitsDc : 32 - kLutBitsAc);
+            const uint32_t e32 = ld_u32(tab + kSyncEntryBytes * idx);
+            e                  = e32 & 0xFFFFu;
+            if ((e & 31u) == 0) {
+                e = huff_second_level<kSyncEntryBytes>(tab, e, peek, is_dc);
+            } else {
+                const uint32_t m = e32 >> 16;
+                if (z + static_cast<int>((m >> 5) & 15u) < 64) e = m;
+            }
+            total = e & 31;
+            JG_COMMIT();
+        }
+#define JG_LOOKUP_SYNC()                                                                                  \
+    do {                                                                                                  \
+        peek               = bw.peek(fetch);                                                              \
+        const TabPtr tab   = JG_TAB_AT(tabs, is_dc ? (JG_CUR_TABS & 0xFFFFu) : (JG_CUR_TABS >> 16));      \
+        const uint32_t idx = peek >> (is_dc ? 32 - kLutBitsDc : 32 - kLutBitsAc);                         \
+        e                  = ld_u16(tab + kSyncEntryBytes * idx);                                         \
+        if ((e & 31u) == 0) e = huff_second_level<kSyncEntryBytes>(tab, e, peek, is_dc);                  \
+        total = e & 31;                                                                                   \
+    } while (0)
+        JG_LOOKUP_SYNC();
         while (p + total <= end_bit) {
             JG_COMMIT();
-            JG_LOOKUP();
+            JG_LOOKUP_SYNC();
         }
+#undef JG_LOOKUP_SYNC
     }
 #undef JG_LOOKUP
 #undef JG_COMMIT

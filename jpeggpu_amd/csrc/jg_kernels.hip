@@ -64,6 +64,7 @@ struct JobView {
     JG_GLOBAL const DestuffChunk* chunks;
     JG_GLOBAL const Segment* segments;
     JG_GLOBAL const uint8_t* tables;
+    JG_GLOBAL const uint8_t* tables_sync;
     JG_GLOBAL const uint16_t* qtables;
     JG_GLOBAL uint8_t* destuffed;
     JG_GLOBAL int* seg_idx;
@@ -89,7 +90,7 @@ struct JobView {
     const IdctParams& ip;
     __device__ __forceinline__ explicit JobView(const ScanJob& j)
         : bytes(as_global(j.bytes)), chunks(as_global(j.chunks)), segments(as_global(j.segments)),
-          tables(as_global(j.tables)), qtables(as_global(j.qtables)), destuffed(as_global(j.destuffed)),
+          tables(as_global(j.tables)), tables_sync(as_global(j.tables_sync)), qtables(as_global(j.qtables)), destuffed(as_global(j.destuffed)),
           seg_idx(as_global(j.seg_idx)), st_p(as_global(j.st_p)), st_n(as_global(j.st_n)), st_cz(as_global(j.st_cz)),
           st_dc01(as_global(j.st_dc01)), st_dc23(as_global(j.st_dc23)), pending(as_global(j.pending)),
           flow_list(as_global(j.flow_list)), tail_parts(as_global(j.tail_parts)), num_tail_parts(j.num_tail_parts),
@@ -202,23 +203,42 @@ __global__ __launch_bounds__(256) void destuff_kernel(JS js)
     __syncthreads();
 
     // write-out into the tiled layout (jg_defs.h): 4-byte words, byte stores at the two ragged ends
-    // (neighbouring chunks own the other bytes of those words)
+    // (neighbouring chunks own the other bytes of those words). A word also goes into the slots of the
+    // neighbouring rows that mirror it: the first two words of a subsequence behind the previous row, the last
+    // one in front of the next row -- whoever stores a word stores all its copies, so no slot has two writers.
     const int log2w          = 31 - __clz(J.sp.subseq_words);
+    const uint32_t wmask     = static_cast<uint32_t>(J.sp.subseq_words) - 1u;
     JG_GLOBAL uint32_t* const dst32 = reinterpret_cast<JG_GLOBAL uint32_t*>(dst);
+    // up to three slots (32-bit word indices) of linear word lw; returns how many
+    const auto slots_of = [&](uint32_t lw, uint32_t (&at)[3]) -> int {
+        const uint32_t row = lw >> log2w, k = lw & wmask;
+        int n   = 0;
+        at[n++] = tiled_slot(row, k + kRowLeadWords, log2w);
+        if (k < static_cast<uint32_t>(kRowTailWords) && row > 0) at[n++] = tiled_slot(row - 1, wmask + 1u + kRowLeadWords + k, log2w);
+        if (k == wmask) at[n++] = tiled_slot(row + 1, 0, log2w); // the row behind the last subsequence is spare space
+        return n;
+    };
     const uint32_t word0     = (ck.dst_off - phase) >> 2; // linear word of s_out[0]
     const uint32_t lo = phase, hi = phase + total;        // valid LDS byte range
     for (uint32_t g = t; g * 4 < hi; g += 256) {
         const uint32_t b0 = g * 4;
-        const uint32_t tw = tiled_word(word0 + g, log2w);
+        uint32_t at[3];
+        const int n = slots_of(word0 + g, at);
         if (b0 >= lo && b0 + 4 <= hi) {
-            dst32[tw] = __builtin_bswap32(*reinterpret_cast<const uint32_t*>(s_out + b0)); // most significant byte first
+            const uint32_t v = __builtin_bswap32(*reinterpret_cast<const uint32_t*>(s_out + b0)); // most significant byte first
+            for (int i = 0; i < n; ++i) dst32[at[i]] = v;
         } else {
-            for (uint32_t b = b0 > lo ? b0 : lo; b < b0 + 4 && b < hi; ++b) dst[tw * 4 + (3u - (b & 3))] = s_out[b];
+            for (uint32_t b = b0 > lo ? b0 : lo; b < b0 + 4 && b < hi; ++b)
+                for (int i = 0; i < n; ++i) dst[at[i] * 4 + (3u - (b & 3))] = s_out[b];
         }
     }
     // zero the tail of the segment up to its subsequence-aligned end
     if (ck.pad_end) {
-        for (uint32_t b = ck.dst_off + total + t; b < ck.pad_end; b += 256) dst[tiled_word(b >> 2, log2w) * 4 + (3u - (b & 3))] = 0;
+        for (uint32_t b = ck.dst_off + total + t; b < ck.pad_end; b += 256) {
+            uint32_t at[3];
+            const int n = slots_of(b >> 2, at);
+            for (int i = 0; i < n; ++i) dst[at[i] * 4 + (3u - (b & 3))] = 0;
+        }
     }
     // subsequences that start inside this chunk's destination range belong to this segment
     if (total) {
@@ -235,7 +255,15 @@ __global__ __launch_bounds__(256) void destuff_kernel(JS js)
 /// Words of the tiled destuffed buffer (jg_defs.h); destuff_kernel stores every word most significant byte
 /// first, so a loaded word goes into the bit window as it is, one refill after its load was issued. The lanes of
 /// a wave walk neighbouring subsequences at about the same pace, so their refills share 128-byte lines and hit
-/// L1; nothing is staged in LDS, which keeps eight workgroups of the sync kernel on a CU.
+/// L1; nothing is staged in LDS, which keeps the workgroups of the sync kernel on a CU many.
+///
+/// A decode of subsequence t works in ROW t of the tiled buffer (set_row), which also mirrors the neighbouring
+/// subsequences' words it can touch (jg_defs.h): the window starts at most 31 bits in front of the subsequence
+/// (slot 0) and a state-only pass looks at most one 32-bit peek plus one prefetched word past its end (slots
+/// W + 1, W + 2; one more, never used, is loaded from whatever follows the row). The position is therefore ONE
+/// byte offset and the step to the next word is `+= 128`. Only the write pass, whose lanes run on until the data
+/// unit they started is complete, can leave the row (kCrossRows): it then continues at the third word of the next
+/// row, a rare branch.
 ///
 /// Reads are not clamped into the segment and nothing is zeroed behind its end (the reference's reader does
 /// both, decode_huffman_reader.hpp:110-152). A lane never commits a symbol that uses a bit past the end of its
@@ -243,38 +271,43 @@ __global__ __launch_bounds__(256) void destuff_kernel(JS js)
 /// code), and the write pass stops at the segment's data-unit quota -- so what lies behind the end cannot
 /// change p, c, z, n, the DC sums or an emitted coefficient. On a corrupt stream a lane of the write pass may
 /// run up to one data unit (64 symbols of at most 27 bits: 54 words, plus the window's 3) past its
-/// subsequence: the buffer carries more than one spare tile of subsequence slots behind the last one
-/// (jg_decoder.cpp), whatever they hold.
-///
-/// The position is kept as two running byte offsets (4 and 128 times the linear word index): a wave executes
-/// the refill block in nearly every iteration of the symbol loop -- some lane always needs a word -- so its
-/// address arithmetic is paid per symbol, and the tiled offset from those two is three ANDs, a shift and an
-/// OR3, mostly on the fast integer path, instead of the shifts, bit-field extract and 64-bit add
-/// of tiled_word().
-template <int W>
+/// subsequence: the buffer carries more than one spare tile of rows behind the last one (jg_decoder.cpp),
+/// whatever they hold.
+template <int W, bool kCrossRows = false>
 struct GlobalFetch {
     static constexpr int kLog2W = W == 8 ? 3 : W == 16 ? 4 : W == 32 ? 5 : 6;
     static_assert((1 << kLog2W) == W, "subsequence words must be 8, 16, 32 or 64");
+    static constexpr uint32_t kRowBytes = 128u * (W + kRowExtraWords); // slot 0 of a row to slot 0 of the same row of the next tile
     JG_GLOBAL const uint32_t* scan32; // the scan's destuffed buffer (tiled): the same for every lane (scalar base address)
-    int seg_word0;                    // first (linear) word of the lane's segment
+    uint32_t row0;                    // byte offset of slot 0 of the row the decode works in
+    int row_word0;                    // segment-relative index of that row's first own word (slot 1)
     struct Pos {
-        uint32_t lw4, lw128; // 4 x and 128 x the linear word index in the scan; the latter may wrap, only its low bits count
+        uint32_t off; // byte offset of the word in the tiled buffer
+        uint32_t end; // kCrossRows: offset one slot past the row's last one
     };
+    /// Work in the row of subsequence `sub` of the scan, which is subsequence `rel` of its segment.
+    __device__ __forceinline__ void set_row(int sub, int rel)
+    {
+        const uint32_t u = static_cast<uint32_t>(sub);
+        row0             = (u >> 5) * kRowBytes + (u & 31u) * 4u;
+        row_word0        = rel * W;
+    }
     __device__ __forceinline__ Pos start(int w) const
     {
-        const uint32_t lw = static_cast<uint32_t>(seg_word0 + w);
-        return Pos{lw * 4u, lw * 128u};
+        return Pos{row0 + static_cast<uint32_t>(w - row_word0 + kRowLeadWords) * 128u, row0 + kRowBytes};
     }
     __device__ __forceinline__ void advance(Pos& q) const
     {
-        q.lw4 += 4u;
-        q.lw128 += 128u;
+        q.off += 128u;
+        if (kCrossRows && q.off == q.end) { // behind slot W + 2: the stream goes on at slot 3 of the next row
+            const uint32_t step = (q.off & 127u) == 124u ? kRowBytes - 124u : 4u; // last row of a tile: on to the next tile
+            q.off               = q.off - W * 128u + step;
+            q.end += step;
+        }
     }
     __device__ __forceinline__ uint32_t load(const Pos& q) const
     {
-        // byte offset of tiled_word(lw): tile | word within the subsequence | subsequence within the tile
-        const uint32_t off = (q.lw4 & ~(128u * W - 1u)) | (q.lw128 & ((W - 1u) << 7)) | ((q.lw4 >> kLog2W) & (31u << 2));
-        return *reinterpret_cast<JG_GLOBAL const uint32_t*>(reinterpret_cast<JG_GLOBAL const uint8_t*>(scan32) + off);
+        return *reinterpret_cast<JG_GLOBAL const uint32_t*>(reinterpret_cast<JG_GLOBAL const uint8_t*>(scan32) + q.off);
     }
     __device__ __forceinline__ uint32_t cook(uint32_t v, const Pos&) const { return v; }
 };
@@ -313,7 +346,7 @@ struct SeqLds {
 };
 /// Static LDS of a kernel precedes its dynamic LDS; the Huffman kernels declare at most this much.
 constexpr uint32_t kStaticLdsSlack = 256;
-static_assert(kStaticLdsSlack + SeqLds::kTabs + kMaxTablePack <= 65536, "absolute table addresses are packed into 16 bits (load_tables)");
+static_assert(kStaticLdsSlack + SeqLds::kTabs + kMaxTablePackSync <= 65536, "absolute table addresses are packed into 16 bits (load_tables)");
 
 __device__ __forceinline__ uint32_t pk_add(uint32_t a, uint32_t b) { return pk_add_u16(a, b); }
 
@@ -346,13 +379,14 @@ __global__ __launch_bounds__(T) void huff_sync_intra(JS js)
     const JobView J(js.get());
     if (static_cast<int>(blockIdx.x) >= J.num_seq) return;
     ScanParams sp = J.sp;
+    sp.use_sync_pack();
     const int t         = threadIdx.x;
     s_pend[t]           = 0;
     const int first_sub = blockIdx.x * SEQ;                  // first subsequence this workgroup owns
     const int img_first = first_sub - OV;                    // subsequence of lane 0
     const int img_end   = min(T, sp.num_subseq - img_first); // lanes below this have a subsequence
 
-    load_tables(s_tab, J.tables, sp);
+    load_tables(s_tab, J.tables_sync, sp);
     __syncthreads();
 
     constexpr int kBits = W * 32;
@@ -360,15 +394,15 @@ __global__ __launch_bounds__(T) void huff_sync_intra(JS js)
     const bool active   = sub >= 0 && t < img_end;
     LaneState st{};
     BitWindow<GlobalFetch<W>> bw{};
-    GlobalFetch<W> fetch{reinterpret_cast<JG_GLOBAL const uint32_t*>(J.destuffed), 0};
+    GlobalFetch<W> fetch{reinterpret_cast<JG_GLOBAL const uint32_t*>(J.destuffed), 0, 0};
     Segment seg{0, 0};
     int rel = 0;
     if (active) {
         // speculative pass: the own subsequence from the guessed state (c, z) = (0, 0), exit state only
-        seg             = ld_global(J.segments + J.seg_idx[sub]);
-        rel             = sub - seg.subseq_offset;
-        fetch.seg_word0 = seg.subseq_offset * W;
-        st.p            = rel * kBits;
+        seg  = ld_global(J.segments + J.seg_idx[sub]);
+        rel  = sub - seg.subseq_offset;
+        st.p = rel * kBits;
+        fetch.set_row(sub, rel);
         bw.seek(st.p, fetch);
         if (JS::kSpeculateStateOnly) {
             SpecSink none;
@@ -390,19 +424,15 @@ __global__ __launch_bounds__(T) void huff_sync_intra(JS js)
     // which is known, not guessed -- so that every subsequence gets its n and DC sums from a decode
     // that started in a real state; otherwise the speculative pass of such a j was already exact.
     bool flowing = JS::kSpeculateStateOnly ? t + 1 < img_end && img_first + t + 1 >= 0 : active;
-    int end_bit  = 0;
     int lim      = 0; // flows stay below this lane index: end of the segment or of the image
     if (flowing) {
         const int sub_j = img_first + t + 1;
         if (JS::kSpeculateStateOnly && (!active || rel + 1 == seg.subseq_count)) { // j opens the next segment
-            seg             = ld_global(J.segments + J.seg_idx[sub_j]);
-            rel             = -1;
-            fetch.seg_word0 = seg.subseq_offset * W;
-            st              = LaneState{};
-            bw.seek(0, fetch);
+            seg = ld_global(J.segments + J.seg_idx[sub_j]);
+            rel = -1;
+            st  = LaneState{};
         }
-        lim     = min(img_end, seg.subseq_offset + seg.subseq_count - img_first);
-        end_bit = (rel + 1) * kBits;
+        lim = min(img_end, seg.subseq_offset + seg.subseq_count - img_first);
     }
     NoSink sink;
     int iter = 0;
@@ -412,8 +442,11 @@ __global__ __launch_bounds__(T) void huff_sync_intra(JS js)
             st.n    = 0;
             st.dc01 = 0;
             st.dc23 = 0;
-            end_bit += kBits;
-            decode_subsequence(st, bw, fetch, end_bit, s_tab, sp, sink);
+            // every decode works in the row of its subsequence (GlobalFetch): the window is set up again from p
+            ++rel;
+            fetch.set_row(img_first + j, rel);
+            bw.seek(st.p, fetch);
+            decode_subsequence(st, bw, fetch, (rel + 1) * kBits, s_tab, sp, sink);
             const int cz = st.c | (st.z << 8);
             if (st.p == s_p[j] && cz == s_cz[j]) flowing = false; // synchronised; still store n / dc
             s_p[j]    = st.p;
@@ -502,11 +535,12 @@ __global__ __launch_bounds__(TL) void huff_sync_tail(JS js)
     const JobView J(js.get());
     if (static_cast<int>(blockIdx.x) >= J.num_tail_parts) return;
     ScanParams sp          = J.sp;
+    sp.use_sync_pack();
     JG_GLOBAL const uint32_t* scan32 = reinterpret_cast<JG_GLOBAL const uint32_t*>(J.destuffed);
     const int lo           = J.tail_parts[blockIdx.x];
     const int hi           = J.tail_parts[blockIdx.x + 1];
     const int tid          = threadIdx.x;
-    load_tables(s_tab, J.tables, sp);
+    load_tables(s_tab, J.tables_sync, sp);
 
     // ordered list of flow origins in [lo, hi)
     int count = 0;
@@ -538,7 +572,8 @@ __global__ __launch_bounds__(TL) void huff_sync_tail(JS js)
                 const Segment seg = ld_global(J.segments + J.seg_idx[j - 1]);
                 const int lim     = seg.subseq_offset + seg.subseq_count;
                 if (j < lim) {
-                    GlobalFetch<W> fetch{scan32, seg.subseq_offset * W};
+                    GlobalFetch<W> fetch{scan32, 0, 0};
+                    fetch.set_row(j, j - seg.subseq_offset);
                     LaneState st{};
                     st.p = p;
                     st.c = cz & 0xFF;
@@ -768,7 +803,7 @@ struct WriteLds {
     static_assert(kTabs % 16 == 0, "the table pack is read with 16-byte loads");
     static_assert(kStaticLdsSlack + kTabs + kMaxTablePack <= 65536, "absolute table addresses are packed into 16 bits (load_tables)");
 };
-static_assert(kStaticLdsSlack + 3 * kTailLanesLarge * 4 + kMaxTablePack <= 65536, "huff_sync_tail: the same bound");
+static_assert(kStaticLdsSlack + 3 * kTailLanesLarge * 4 + kMaxTablePackSync <= 65536, "huff_sync_tail: the same bound");
 
 /// Re-decode every subsequence from its predecessor's synchronised exit state and emit the symbol
 /// stream (StreamSink). The coefficient-slot position of subsequence i inside its segment = sum of n
@@ -875,8 +910,9 @@ __global__ __launch_bounds__(T) void huff_write(JS js)
         st.z         = cz >> 8;
     }
     sink.started = st.z == 0;
-    GlobalFetch<W> fetch{reinterpret_cast<JG_GLOBAL const uint32_t*>(J.destuffed), seg.subseq_offset * W};
-    BitWindow<GlobalFetch<W>> bw{};
+    GlobalFetch<W, true> fetch{reinterpret_cast<JG_GLOBAL const uint32_t*>(J.destuffed), 0, 0};
+    fetch.set_row(sub, rel);
+    BitWindow<GlobalFetch<W, true>> bw{};
     bw.seek(st.p, fetch);
     decode_subsequence(st, bw, fetch, (rel + 1) * (W * 32), s_tab, sp, sink);
     sink.finish();
@@ -1204,10 +1240,10 @@ hipError_t allow_lds(K kernel, size_t bytes)
 template <int W, class JS>
 hipError_t launch_huff(Stage stage, const JS& js, const JobExtent& e, int grid_y, hipStream_t stream)
 {
-    const size_t seq_lds = SeqLds::kTabs + e.max_tab_bytes;
+    const size_t seq_lds = SeqLds::kTabs + e.max_tab_bytes_sync;
     hipError_t err       = hipSuccess;
     // the cursor ring holds absolute LDS addresses in 16 bits (load_tables): refuse rather than wrap
-    if (e.max_tab_bytes > kMaxTablePack) return hipErrorInvalidValue;
+    if (e.max_tab_bytes > kMaxTablePack || e.max_tab_bytes_sync > kMaxTablePackSync) return hipErrorInvalidValue;
     switch (stage) {
     case kStageSyncIntra:
         if ((err = allow_lds(huff_sync_intra<W, JS>, seq_lds)) != hipSuccess) return err;
@@ -1218,10 +1254,10 @@ hipError_t launch_huff(Stage stage, const JS& js, const JobExtent& e, int grid_y
         {
             if (e.max_tail_part >= kTailLargeFrom) {
                 constexpr int TL = kTailLanesLarge;
-                huff_sync_tail<W, TL, JS><<<dim3(e.max_tail_parts, grid_y), TL, 3 * TL * 4 + e.max_tab_bytes, stream>>>(js);
+                huff_sync_tail<W, TL, JS><<<dim3(e.max_tail_parts, grid_y), TL, 3 * TL * 4 + e.max_tab_bytes_sync, stream>>>(js);
             } else {
                 constexpr int TL = kTailLanesSmall;
-                huff_sync_tail<W, TL, JS><<<dim3(e.max_tail_parts, grid_y), TL, 3 * TL * 4 + e.max_tab_bytes, stream>>>(js);
+                huff_sync_tail<W, TL, JS><<<dim3(e.max_tail_parts, grid_y), TL, 3 * TL * 4 + e.max_tab_bytes_sync, stream>>>(js);
             }
         }
         break;
@@ -1277,6 +1313,7 @@ void extend(JobExtent& e, const ScanJob& job)
     const int blocks  = (job.ip.num_du + kIdctDuPerWg - 1) / kIdctDuPerWg;
     e.max_idct_blocks = blocks > e.max_idct_blocks ? blocks : e.max_idct_blocks;
     e.max_tab_bytes   = job.sp.tab_bytes > e.max_tab_bytes ? job.sp.tab_bytes : e.max_tab_bytes;
+    e.max_tab_bytes_sync = job.sp.tab_bytes_sync > e.max_tab_bytes_sync ? job.sp.tab_bytes_sync : e.max_tab_bytes_sync;
     e.subseq_words    = job.sp.subseq_words;
     e.max_tail_parts  = job.num_tail_parts > e.max_tail_parts ? job.num_tail_parts : e.max_tail_parts;
     e.max_tail_part   = job.max_tail_part > e.max_tail_part ? job.max_tail_part : e.max_tail_part;

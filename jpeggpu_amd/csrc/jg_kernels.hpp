@@ -31,7 +31,8 @@ struct JobExtent {
     int max_tail_part   = 0; // subsequences in the largest tail part of any job
     int max_idct_blocks = 0;
     int subseq_words    = 0; // identical for every job of a launch
-    uint32_t max_tab_bytes = 0;
+    uint32_t max_tab_bytes = 0;      // largest write-pass table pack
+    uint32_t max_tab_bytes_sync = 0; // largest sync pack
 };
 void extend(JobExtent& e, const ScanJob& job);
 

@@ -147,6 +147,40 @@ void build_huff_table(
     }
 }
 
+void widen_huff_table(const std::vector<uint8_t>& t, bool is_dc, std::vector<uint8_t>& out)
+{
+    const int lb          = is_dc ? kLutBitsDc : kLutBitsAc;
+    const uint32_t n      = 1u << lb;
+    const uint16_t* lut   = reinterpret_cast<const uint16_t*>(t.data());
+    const size_t rest     = t.size() - 2u * n;
+    out.assign(static_cast<size_t>(kSyncEntryBytes) * n + rest, 0);
+    uint32_t* wide = reinterpret_cast<uint32_t*>(out.data());
+    for (uint32_t idx = 0; idx < n; ++idx) {
+        const uint32_t single = lut[idx];
+        uint32_t multi        = single; // no second symbol: the high half repeats the low one
+        if (!is_dc && (single & 31u) != 0) {
+            // Decode greedily inside the lb index bits: a symbol counts if its code AND its magnitude bits lie
+            // inside them (its first-level entry then does not depend on the bits behind the index).
+            uint32_t bits = 0, pre = 0, total_adv = 0;
+            int count = 0;
+            while (true) {
+                const uint32_t e   = lut[(idx << bits) & (n - 1u)];
+                const uint32_t len = e & 31u, adv = e >> 9;
+                if (len == 0 || bits + len > static_cast<uint32_t>(lb)) break;
+                if (count > 0 && total_adv > static_cast<uint32_t>(kMultiMaxPre)) break; // the earlier symbols' advance has four bits
+                pre = total_adv;
+                total_adv += adv;
+                bits += len;
+                ++count;
+                if (adv == 64u) break; // end of block: whatever follows belongs to the next data unit
+            }
+            if (count >= 2) multi = bits | pre << 5 | total_adv << 9;
+        }
+        wide[idx] = single | multi << 16;
+    }
+    std::memcpy(out.data() + static_cast<size_t>(kSyncEntryBytes) * n, t.data() + 2u * n, rest);
+}
+
 jpeggpu_status Reader::read_sof(const Logger& log)
 {
     if (remaining() < 2) return JPEGGPU_INVALID_JPEG;
@@ -251,13 +285,19 @@ jpeggpu_status Reader::read_dht(const Logger& log)
             code <<= 1;
         }
         log.log("\t%s Huffman table index %d\n", tc == 0 ? "DC" : "AC", th);
-        if (tc == 0) {
-            build_huff_table(dc_tab_[th], num_codes, cur_, count, true);
-            dc_defined_[th] = true;
-        } else {
-            build_huff_table(ac_tab_[th], num_codes, cur_, count, false);
-            ac_defined_[th] = true;
+        // A decoder parses image after image, nearly always with the same tables: the device forms are rebuilt only
+        // when the DHT payload (16 counts + the values) differs from the one they were built from.
+        std::vector<uint8_t>& key = dht_key_[tc][th];
+        const uint8_t* payload    = cur_ - 16;
+        const size_t payload_len  = 16u + static_cast<size_t>(count);
+        const bool same = key.size() == payload_len && std::memcmp(key.data(), payload, payload_len) == 0;
+        if (!same) {
+            std::vector<uint8_t>& tab = tc == 0 ? dc_tab_[th] : ac_tab_[th];
+            build_huff_table(tab, num_codes, cur_, count, tc == 0);
+            widen_huff_table(tab, tc == 0, tc == 0 ? dc_tab_sync_[th] : ac_tab_sync_[th]);
+            key.assign(payload, payload + payload_len);
         }
+        (tc == 0 ? dc_defined_ : ac_defined_)[th] = true;
         cur_ += count;
         rem -= count;
     }
@@ -401,48 +441,55 @@ jpeggpu_status Reader::read_sos(const Logger& log)
     u8(); // spectral selection end (63)
     u8(); // successive approximation (0)
 
-    // pack the tables in force for this scan; components that select the same table share it
-    for (int a = 0; a < ns; ++a) {
-        const ScanComponent& sc = scan.comp[a];
-        int same_dc = -1, same_ac = -1;
-        for (int b = 0; b < a; ++b) {
-            if (scan.comp[b].dc_id == sc.dc_id) same_dc = b;
-            if (scan.comp[b].ac_id == sc.ac_id) same_ac = b;
+    // pack the tables in force for this scan, once in each form (jg_defs.h); components that select the same
+    // table share it; the cursor ring sits behind the tables: one entry per data unit of the MCU
+    const auto build_pack = [&](const std::vector<uint8_t> (&dc_tabs)[4], const std::vector<uint8_t> (&ac_tabs)[4],
+                                std::vector<uint8_t>& pack, uint32_t& cursor_off, uint32_t limit) -> bool {
+        uint32_t dc_off[kMaxComp], ac_off[kMaxComp];
+        pack.clear();
+        for (int a = 0; a < ns; ++a) {
+            const ScanComponent& sc = scan.comp[a];
+            int same_dc = -1, same_ac = -1;
+            for (int b = 0; b < a; ++b) {
+                if (scan.comp[b].dc_id == sc.dc_id) same_dc = b;
+                if (scan.comp[b].ac_id == sc.ac_id) same_ac = b;
+            }
+            if (same_dc >= 0) {
+                dc_off[a] = dc_off[same_dc];
+            } else {
+                dc_off[a] = static_cast<uint32_t>(pack.size());
+                pack.insert(pack.end(), dc_tabs[sc.dc_id].begin(), dc_tabs[sc.dc_id].end());
+            }
+            if (same_ac >= 0) {
+                ac_off[a] = ac_off[same_ac];
+            } else {
+                ac_off[a] = static_cast<uint32_t>(pack.size());
+                pack.insert(pack.end(), ac_tabs[sc.ac_id].begin(), ac_tabs[sc.ac_id].end());
+            }
         }
-        if (same_dc >= 0) {
-            scan.dc_off[a] = scan.dc_off[same_dc];
-        } else {
-            scan.dc_off[a] = static_cast<uint16_t>(scan.table_pack.size());
-            scan.table_pack.insert(scan.table_pack.end(), dc_tab_[sc.dc_id].begin(), dc_tab_[sc.dc_id].end());
-        }
-        if (same_ac >= 0) {
-            scan.ac_off[a] = scan.ac_off[same_ac];
-        } else {
-            scan.ac_off[a] = static_cast<uint16_t>(scan.table_pack.size());
-            scan.table_pack.insert(scan.table_pack.end(), ac_tab_[sc.ac_id].begin(), ac_tab_[sc.ac_id].end());
-        }
-    }
-    // 16-bit offsets above, 16-bit LDS addresses on the device: cannot trip while jg_defs.h's static_assert on
-    // kMaxTablePack holds, and must fail rather than wrap if a constant is ever raised without it
-    if (scan.table_pack.size() + static_cast<size_t>(kMaxDuPerMcu) * sizeof(CursorEntry) > kMaxTablePack) return JPEGGPU_INTERNAL_ERROR;
-    // cursor ring behind the tables (jg_defs.h): one entry per data unit of the MCU
-    scan.cursor_off = static_cast<uint32_t>(scan.table_pack.size());
-    {
+        // 16-bit offsets in the ring, 16-bit LDS addresses on the device: cannot trip while the static_assert on
+        // the pack sizes in jg_defs.h holds, and must fail rather than wrap if a constant is ever raised without it
+        if (pack.size() + static_cast<size_t>(kMaxDuPerMcu) * sizeof(CursorEntry) > limit) return false;
+        cursor_off = static_cast<uint32_t>(pack.size());
         std::vector<CursorEntry> ring;
         for (int a = 0; a < ns; ++a) {
             for (int k = 0; k < scan.comp[a].h * scan.comp[a].v; ++k) {
                 CursorEntry ce;
                 const uint32_t du = static_cast<uint32_t>(ring.size());
-                ce.tabs = scan.dc_off[a] | static_cast<uint32_t>(scan.ac_off[a]) << 16;
+                ce.tabs = dc_off[a] | ac_off[a] << 16;
                 ce.meta = 16u * a | du << 8;
-                ce.self = scan.cursor_off + 16u * du;
-                ce.next = scan.cursor_off + 16u * (static_cast<int>(du) + 1 == scan.du_per_mcu ? 0u : du + 1u);
+                ce.self = cursor_off + 16u * du;
+                ce.next = cursor_off + 16u * (static_cast<int>(du) + 1 == scan.du_per_mcu ? 0u : du + 1u);
                 ring.push_back(ce);
             }
         }
         const uint8_t* rb = reinterpret_cast<const uint8_t*>(ring.data());
-        scan.table_pack.insert(scan.table_pack.end(), rb, rb + ring.size() * sizeof(CursorEntry));
-    }
+        pack.insert(pack.end(), rb, rb + ring.size() * sizeof(CursorEntry));
+        return true;
+    };
+    if (!build_pack(dc_tab_, ac_tab_, scan.table_pack, scan.cursor_off, kMaxTablePack) ||
+        !build_pack(dc_tab_sync_, ac_tab_sync_, scan.table_pack_sync, scan.cursor_off_sync, kMaxTablePackSync))
+        return JPEGGPU_INTERNAL_ERROR;
     const int total_mcus  = scan.mcus_x * scan.mcus_y;
     scan.mcus_per_segment = s.restart_interval ? s.restart_interval : total_mcus;
     scan.num_du           = total_mcus * scan.du_per_mcu;
@@ -636,6 +683,7 @@ jpeggpu_status Reader::parse(const uint8_t* data, size_t size, int subseq_bytes,
         Scan keep[kMaxScans];
         for (int i = 0; i < kMaxScans; ++i) {
             keep[i].table_pack.swap(s.scans[i].table_pack);
+            keep[i].table_pack_sync.swap(s.scans[i].table_pack_sync);
             keep[i].segments.swap(s.scans[i].segments);
             keep[i].chunks.swap(s.scans[i].chunks);
             keep[i].tail_parts.swap(s.scans[i].tail_parts);
@@ -643,10 +691,12 @@ jpeggpu_status Reader::parse(const uint8_t* data, size_t size, int subseq_bytes,
         s = Stream{};
         for (int i = 0; i < kMaxScans; ++i) {
             keep[i].table_pack.clear();
+            keep[i].table_pack_sync.clear();
             keep[i].segments.clear();
             keep[i].chunks.clear();
             keep[i].tail_parts.clear();
             s.scans[i].table_pack.swap(keep[i].table_pack);
+            s.scans[i].table_pack_sync.swap(keep[i].table_pack_sync);
             s.scans[i].segments.swap(keep[i].segments);
             s.scans[i].chunks.swap(keep[i].chunks);
             s.scans[i].tail_parts.swap(keep[i].tail_parts);

@@ -59,10 +59,9 @@ struct Scan {
     int mcus_per_segment = 0;
     int num_subseq = 0;
     int num_du = 0;
-    std::vector<uint8_t> table_pack; // tables in force at SOS that this scan's components select
-    uint16_t dc_off[kMaxComp] = {};  // byte offset in table_pack per scan component
-    uint16_t ac_off[kMaxComp] = {};
-    uint32_t cursor_off = 0;         // byte offset of the cursor ring in table_pack
+    std::vector<uint8_t> table_pack;      // tables in force at SOS that this scan's components select (write pass)
+    std::vector<uint8_t> table_pack_sync; // the same tables in the form of the state-only passes (jg_defs.h)
+    uint32_t cursor_off = 0, cursor_off_sync = 0; // byte offset of the cursor ring in each pack
     std::vector<Segment> segments;
     std::vector<DestuffChunk> chunks;
     std::vector<int> tail_parts; // subsequence ranges [parts[i], parts[i+1]) cut at segment starts
@@ -103,7 +102,9 @@ struct Reader {
     bool found_sof_      = false;
     bool qt_defined_[4]{};
     bool dc_defined_[4]{}, ac_defined_[4]{};
-    std::vector<uint8_t> dc_tab_[4], ac_tab_[4]; // device-format tables by table id (T.81 Th)
+    std::vector<uint8_t> dc_tab_[4], ac_tab_[4];           // device-format tables by table id (T.81 Th)
+    std::vector<uint8_t> dc_tab_sync_[4], ac_tab_sync_[4]; // their sync-pack form
+    std::vector<uint8_t> dht_key_[2][4];                   // DHT payload each table was built from (class, id)
     bool comp_in_scan_[kMaxComp]{};
     bool device_scan_ = false;
     bool stop_        = false; // device mode: nothing behind the scan header is parsed on the host
@@ -128,6 +129,9 @@ struct Reader {
 /// (reference compute_huffman_table, src/reader.cpp:186-224).
 void build_huff_table(
     std::vector<uint8_t>& t, const uint8_t (&num_codes)[16], const uint8_t* huffval, int count, bool is_dc);
+/// The sync-pack form of a table built by build_huff_table: 32-bit first-level entries with multi-symbol high
+/// halves (jg_defs.h), everything behind the first level unchanged.
+void widen_huff_table(const std::vector<uint8_t>& t, bool is_dc, std::vector<uint8_t>& out);
 
 } // namespace jg
 

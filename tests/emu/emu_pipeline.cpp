@@ -24,7 +24,7 @@ struct HostFetch {
     void advance(Pos& q) const { ++q; }
     uint32_t load(const Pos& w) const
     {
-        if (w >= seg_words) return 0;
+        if (w < 0 || w >= seg_words) return 0; // the window starts one word early at bit 0 (BitWindow::seek)
         const uint8_t* p = seg + static_cast<size_t>(w) * 4;
         return static_cast<uint32_t>(p[0]) << 24 | p[1] << 16 | p[2] << 8 | p[3];
     }
@@ -137,7 +137,12 @@ int emu_decode_scan(
     sp.subseq_words     = subseq_bytes / 4;
     sp.tab_bytes        = static_cast<uint32_t>(sc.table_pack.size());
     sp.cursor_off       = sc.cursor_off;
-    const uint8_t* tabs = sc.table_pack.data();
+    sp.tab_bytes_sync   = static_cast<uint32_t>(sc.table_pack_sync.size());
+    sp.cursor_off_sync  = sc.cursor_off_sync;
+    const uint8_t* tabs = sc.table_pack.data();           // write pass
+    const uint8_t* tabs_sync = sc.table_pack_sync.data(); // state-only passes (multi-symbol entries)
+    ScanParams sp_sync  = sp;
+    sp_sync.use_sync_pack();
 
     const int S    = sc.num_subseq;
     const int T    = kSeqSubseq;
@@ -168,7 +173,7 @@ int emu_decode_scan(
         BitWindow<HostFetch> bw;
         bw.seek(ls.p, f);
         SpecSink spec_sink;
-        decode_subsequence(ls, bw, f, (rel + 1) * bits, tabs, sp, spec_sink);
+        decode_subsequence(ls, bw, f, (rel + 1) * bits, tabs_sync, sp_sync, spec_sink);
         st[sub].p  = ls.p;
         st[sub].cz = ls.c | (ls.z << 8);
     }
@@ -210,7 +215,7 @@ int emu_decode_scan(
                     L.s.n = 0;
                     L.s.dc01 = L.s.dc23 = 0;
                     L.end_bit += bits;
-                    decode_subsequence(L.s, L.bw, L.f, L.end_bit, tabs, sp, nosink);
+                    decode_subsequence(L.s, L.bw, L.f, L.end_bit, tabs_sync, sp_sync, nosink);
                     St& o        = st[first + j];
                     const int cz = L.s.c | (L.s.z << 8);
                     if (L.s.p == o.p && cz == o.cz) L.flowing = false;
@@ -266,7 +271,7 @@ int emu_decode_scan(
                         L.s.n = 0;
                         L.s.dc01 = L.s.dc23 = 0;
                         L.end_bit += bits;
-                        decode_subsequence(L.s, L.bw, L.f, L.end_bit, tabs, sp, nosink);
+                        decode_subsequence(L.s, L.bw, L.f, L.end_bit, tabs_sync, sp_sync, nosink);
                         St& o        = st[j];
                         const int cz = L.s.c | (L.s.z << 8);
                         if (L.s.p == o.p && cz == o.cz) L.flowing = false;

@@ -74,10 +74,15 @@ def test_stage_parity(gpu_lib, torch_cuda, inputs, name, subseq_bytes, device_sc
             assert not device_scan or lay.num_scans > 1
         assert S == tw.num_subseq and G == tw.num_segments and sl.num_data_units == tw.num_du
         # the device keeps the destuffed bytes in tiles of 32 subsequences, word-major, every 32-bit word most
-        # significant byte first (jpeggpu_ext.h)
+        # significant byte first; a subsequence's row holds, around its own W words, the last word of the
+        # previous subsequence (slot 0) and the first two of the next one (slots W + 1, W + 2) (jg_defs.h)
         W, tiles = subseq_bytes // 4, (S + 31) // 32
-        tiled = _tmp_view(torch, tmp, base, sl.off_destuffed, tiles * 32 * subseq_bytes, torch.uint8)
-        dst = tiled.reshape(tiles, W, 32, 4)[..., ::-1].transpose(0, 2, 1, 3).reshape(-1)[:S * subseq_bytes]
+        tiled = _tmp_view(torch, tmp, base, sl.off_destuffed, tiles * 32 * (subseq_bytes + 12), torch.uint8)
+        rows = tiled.reshape(tiles, W + 3, 32, 4)[..., ::-1].transpose(0, 2, 1, 3).reshape(tiles * 32, W + 3, 4)[:S]
+        dst = rows[:, 1:W + 1].reshape(-1)
+        if S > 1:
+            assert np.array_equal(rows[1:, 0], rows[:-1, W]), "slot 0 mirrors the previous row's last word"
+            assert np.array_equal(rows[:-1, W + 1:W + 3], rows[1:, 1:3]), "slots W+1, W+2 mirror the next row's first words"
         assert np.array_equal(dst, tw.destuffed), "destuffed bytes"
         seg = _tmp_view(torch, tmp, base, sl.off_segment_index, S, torch.int32)
         assert np.array_equal(seg, tw.seg_index), "segment index"
