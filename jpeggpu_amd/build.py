@@ -20,22 +20,36 @@ def _stale() -> bool:
     return any(os.path.getmtime(d) > t for d in deps)
 
 
-def build(force: bool = False, verbose: bool = False) -> str:
-    """hipcc --offload-arch=gfx950 -> jpeggpu_amd/lib/libjpeggpu.so (cross-compiles without a GPU)."""
+def build(force: bool = False, verbose: bool = False, out: str = None, extra_flags=()) -> str:
+    """hipcc --offload-arch=gfx950 -> jpeggpu_amd/lib/libjpeggpu.so (cross-compiles without a GPU).
+    `out` / `extra_flags`: experimental builds for in-run A/B comparisons (tools/probe/ab.sh, JPEGGPU_LIB)."""
+    if out is not None:
+        return _compile(out, verbose, extra_flags)
     if not force and not _stale():
         return LIB_PATH
+    return _compile(LIB_PATH, verbose, extra_flags)
+
+
+def _compile(lib_path, verbose, extra_flags):
     os.makedirs(LIB_DIR, exist_ok=True)
     hipcc = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
     # -fwrapv: the reference's GPU integer arithmetic wraps; signed overflow must not be undefined (same flag as the oracle)
     cmd = [hipcc, "-O3", "-std=c++17", "-fwrapv", "--offload-arch=gfx950", "-fPIC", "-shared",
            "-I" + os.path.join(ROOT, "include"), "-I" + CSRC]
+    cmd += list(extra_flags)
     cmd += [os.path.join(CSRC, s) for s in SOURCES]
-    cmd += ["-o", LIB_PATH]
+    cmd += ["-o", lib_path]
     if verbose:
         print(" ".join(cmd))
     subprocess.check_call(cmd)
-    return LIB_PATH
+    return lib_path
 
 
 if __name__ == "__main__":
-    print(build(force=True, verbose=True))
+    import sys
+
+    # python jpeggpu_amd/build.py [out.so [extra hipcc flags...]]
+    if len(sys.argv) > 1:
+        print(build(out=os.path.abspath(sys.argv[1]), extra_flags=sys.argv[2:], verbose=True))
+    else:
+        print(build(force=True, verbose=True))

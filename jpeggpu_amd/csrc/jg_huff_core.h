@@ -80,6 +80,14 @@ struct BitWindow {
         lo = fetch.cook(fetch.load(pos), pos);
         fetch.advance(pos);
         next_raw = fetch.load(pos);
+#if defined(__HIP_DEVICE_COMPILE__)
+        // `hi` and `lo` must have ARRIVED before the symbol loop starts. Left in flight, the compiler's wait for
+        // them lands on their first use inside the loop -- an s_waitcnt vmcnt(1) in every iteration, which also
+        // waits for whatever the iteration before stored (gfx9 has one counter for loads and stores): the write
+        // pass then sat out the full latency of its ring flushes (measured: a third of its time). Two moves the
+        // compiler cannot look through make it wait here, once.
+        asm volatile("v_mov_b32 %0, %0\n\tv_mov_b32 %1, %1" : "+v"(hi), "+v"(lo));
+#endif
     }
     JG_HD inline uint32_t peek(const Fetch& fetch)
     {
@@ -252,6 +260,10 @@ JG_HD inline void decode_subsequence(
 #define JG_LOOKUP()                                                                                       \
     do {                                                                                                  \
         peek               = bw.peek(fetch);                                                              \
+        /* the sink's periodic flush goes right behind the refill: a refill waits for every memory operation  \
+           in flight (one counter for loads and stores on gfx9), so the stores get a whole iteration before   \
+           the next one asks -- at the end of the body they were waited for a few instructions later */       \
+        if (Sink::kWrite) sink.tick();                                                                    \
         const TabPtr tab   = JG_TAB_AT(tabs, is_dc ? (JG_CUR_TABS & 0xFFFFu) : (JG_CUR_TABS >> 16));      \
         const uint32_t idx = peek >> (is_dc ? 32 - kLutBitsDc : 32 - kLutBitsAc);                         \
         e                  = ld_u16(tab + 2 * idx);                                                       \
@@ -288,7 +300,6 @@ JG_HD inline void decode_subsequence(
         z = du_end ? 0 : z1;                                                                              \
         if (Sink::kWrite || Sink::kSums) units += du_end ? 1 : 0;                                         \
         cur = JG_LOAD_CURSOR(du_end ? JG_CUR_NEXT : JG_CUR_SELF);                                         \
-        if (Sink::kWrite) sink.tick(); /* once per iteration, whatever the symbol was */                  \
         is_dc = du_end;                /* a unit just ended <=> the next symbol is a DC symbol */         \
     } while (0)
     if (Sink::kWrite) {
