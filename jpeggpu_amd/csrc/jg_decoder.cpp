@@ -99,7 +99,10 @@ struct Decoder {
     Plan plan;
     const uint8_t* data = nullptr;
     size_t data_size    = 0;
-    int subseq_bytes    = 128;
+    // Default of a decoder nobody configured: the best size for ONE image at a time, from 0.08 to 12 MP
+    // (tools/probe/latency_by_size.py; a shorter subsequence is a shorter serial chain per lane). Callers that put many
+    // images into one launch ask for 128 (jpeggpu_ext_set_subsequence_bytes; bench.py).
+    int subseq_bytes    = 64;
     bool parsed         = false;
     int device_scan     = 0;     // jpeggpu_ext_set_device_scan: 0 off, 1 on (status via jpeggpu_ext_get_device_status), 2 on and checked by decode
 

@@ -36,7 +36,7 @@ def test_emulated_photo(photo_bytes):
         assert r.max_flow_iters >= 1
 
 
-@pytest.mark.parametrize("simd", ["auto", "sse2", "scalar"])
+@pytest.mark.parametrize("simd", ["auto", "avx2", "sse2", "scalar"])
 def test_marker_walk_at_every_alignment(simd, monkeypatch):
     """The host walk scans 64-byte blocks on the destuff-window grid (jg_reader.cpp, scan_window):
     shift the entropy-coded bytes through every position of a block (a COM segment of growing length

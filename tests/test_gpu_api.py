@@ -604,3 +604,76 @@ def test_baseline_configs_full_size(torch_cuda, cfg):
         assert info.num_components == ref.ncomp
         for c in range(ref.ncomp):
             assert np.array_equal(planes[c].cpu().numpy(), ref.planes[c]), (cfg, c, device_scan)
+
+
+def test_config3_batch_of_64_twelve_megapixel_images(torch_cuda):
+    """BASELINE.json configs[2] on one GPU: 64 x 12 MP 4:2:0 (8 distinct seeds) through jpeggpu_ext_decode_batch in one
+    call, plane hashes against the oracle. (Across GPUs the same batch is sharded by image: bench.py's `gather`.)"""
+    import hashlib
+
+    import jpeggpu_amd
+    from oracle import oracle
+    from tools import jpegsynth
+
+    torch = torch_cuda
+    datas = [jpegsynth.config(2, seed=100 + s) for s in range(8)]
+    want = []
+    for d in datas:
+        ref = oracle.decode(d)
+        want.append([hashlib.sha256(p.tobytes()).hexdigest() for p in ref.planes])
+    keep, entries = [], []
+    for i in range(64):
+        dec = jpeggpu_amd.Decoder(jpeggpu_amd.BATCH_SUBSEQ_BYTES)
+        if i % 2:
+            dec.set_device_scan(True)
+        info = dec.parse_header(datas[i % 8])
+        n, tmp, base, planes = _alloc(torch, dec, info)
+        dec.transfer(base, n, 0)
+        keep.append((dec, tmp, planes))
+        entries.append((dec, [p.data_ptr() for p in planes], [p.stride(0) for p in planes], base, n))
+    batch = jpeggpu_amd.Batch(64)
+    scratch = torch.empty(batch.scratch_size, dtype=torch.uint8, device="cuda:0")
+    batch.set_items(entries)
+    batch.set_overlap(4)
+    batch.decode(scratch.data_ptr(), 0)
+    torch.cuda.synchronize()
+    bad = []
+    for i, (dec, _tmp, planes) in enumerate(keep):
+        got = [hashlib.sha256(p.cpu().numpy().tobytes()).hexdigest() for p in planes]
+        if got != want[i % 8]:
+            bad.append(i)
+        dec.cleanup()
+    batch.destroy()
+    assert not bad, bad
+
+
+def test_bench_multi_rank_control_flow_over_gloo(torch_cuda):
+    """bench.py's own N > 1 path -- sharding by rank, max-over-ranks timing, oracle verification reduced over the
+    ranks, the configs[2] leg with its gather -- as two ranks on this one GPU (JPEGGPU_BENCH_BACKEND=gloo: the
+    collectives run on CPU tensors; the driver's multi-GPU runs use RCCL)."""
+    import json
+    import os
+    import socket
+    import subprocess
+    import sys
+
+    from tests.conftest import ROOT
+
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    env = dict(os.environ, JPEGGPU_BENCH_BACKEND="gloo", HSA_ENABLE_IPC_MODE_LEGACY="0")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
+           "--master-port", str(port), os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "2", "--warmup", "1",
+           "--batch", "8", "--rounds", "1", "--unique", "2", "--latency-iters", "0", "--no-cpu", "--e2e-rounds", "0",
+           "--roofline-launches", "2", "--gather-rounds", "2"]
+    r = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stderr[-3000:]
+    line = [ln for ln in r.stdout.splitlines() if ln.startswith("{")][-1]
+    d = json.loads(line)
+    assert d["n_gpus"] == 2 and d["verified"] is True and d["verified_images"] == 2
+    assert d["config"]["images_per_step"] == 16 and d["value"] > 0
+    g = d["gather"]
+    assert g["images_per_round"] == 64 or g["images_per_round"] == 16  # 64 // 2 per rank, capped by the batch
+    assert g["gathered_buffers_match_senders"] is True and g["value"] > 0
+    assert d["roofline"]["frac"] > 0
