@@ -1004,40 +1004,26 @@ template <class JS>
 __global__ __launch_bounds__(256) void idct_kernel(JS js)
 {
     __shared__ __attribute__((aligned(16))) int16_t s_blk[kIdctDuPerBlock][kIdctDuStride]; // [unit][col * 8 + row]
-    __shared__ uint32_t s_zq[4 * 64]; // [quantisation table][zig-zag index]: transposed slot | q << 8 (q up to 16 bits)
+    // [quantisation table][zig-zag index]: byte offset of the coefficient's transposed slot in a staged block (low
+    // byte) and the quantiser (high half, up to 16 bits): both sit where an SDWA operand can pick them up
+    __shared__ uint32_t s_zq[4 * 64];
     __shared__ uint2 s_px[2][kIdctDuPerBlock][9]; // finished pixel rows, [buffer][unit][row] (+1: bank spread)
-    // Geometry of the k-th data unit of an MCU, staged once: the job lives in global memory (batch
-    // API), and indexing its small arrays per lane would be a chain of dependent L2 round trips.
-    struct UnitDesc {
-        JG_GLOBAL uint8_t* plane;
-        int pitch, size_x, size_y, h, v, dx, dy, qoff;
+    // Where the pixels of each of the workgroup's data units go, worked out ONCE per unit by lane = unit (reference
+    // decode_transpose.cu:65-131 walks the same geometry): address of the unit's top-left pixel, pitch, how many of
+    // its 8 columns / rows are inside the plane (0..8), and its quantisation table. The per-iteration code reads
+    // 16 bytes instead of redoing two divisions and a dozen multiply-adds per lane and unit row.
+    struct UnitGeo {
+        uint32_t addr_lo, addr_hi;
+        int pitch;
+        uint32_t vis; // visible columns | visible rows << 4 | quantisation table << 8
     };
-    __shared__ UnitDesc s_desc[kMaxDuPerMcu];
+    __shared__ __attribute__((aligned(16))) UnitGeo s_geo[kIdctDuPerWg];
 
     const JobView J(js.get());
     const IdctParams& ip = J.ip;
     const int du0        = blockIdx.x * kIdctDuPerWg;
     const int num_du     = ip.num_du;
-    const int du_per_mcu = ip.du_per_mcu;
-    const int mcus_x     = ip.mcus_x;
-    const uint32_t dpm_mul = ip.du_per_mcu_mul, dpm_shift = ip.du_per_mcu_shift;
-    const uint32_t mx_mul = ip.mcus_x_mul, mx_shift = ip.mcus_x_shift;
     if (du0 >= num_du) return;
-    if (threadIdx.x < static_cast<unsigned>(du_per_mcu)) {
-        const int k  = threadIdx.x;
-        const int sc = ip.du_comp[k];
-        UnitDesc d;
-        d.plane  = as_global(ip.plane[sc]);
-        d.pitch  = ip.pitch[sc];
-        d.size_x = ip.size_x[sc];
-        d.size_y = ip.size_y[sc];
-        d.h      = ip.comp_h[sc];
-        d.v      = ip.comp_v[sc];
-        d.dx     = ip.du_dx[k];
-        d.dy     = ip.du_dy[k];
-        d.qoff   = ip.qidx[sc] * 64;
-        s_desc[k] = d;
-    }
 
     const int t  = threadIdx.x;
     const int r  = t & 7;  // column (pass 1) or row (pass 2) handled by this lane
@@ -1047,10 +1033,29 @@ __global__ __launch_bounds__(256) void idct_kernel(JS js)
         // natural index = row * 8 + col -> transposed slot col * 8 + row; unsigned q (Appendix B-3)
         constexpr uint8_t nat[64] = JG_ORDER_NATURAL;
         const int n               = nat[t & 63];
-        s_zq[t] = static_cast<uint32_t>((n & 7) * 8 + (n >> 3)) | static_cast<uint32_t>(J.qtables[(t & ~63) + n]) << 8;
+        s_zq[t] = static_cast<uint32_t>(((n & 7) * 8 + (n >> 3)) * 2) | static_cast<uint32_t>(J.qtables[(t & ~63) + n]) << 16;
+    }
+    {
+        const int du = du0 + t;
+        UnitGeo g{0u, 0u, 0, 0u};
+        if (du < num_du) {
+            const int mcu = static_cast<int>(magic_quot(du, ip.du_per_mcu_mul, ip.du_per_mcu_shift));
+            const int k   = du - mcu * ip.du_per_mcu;
+            const int sc  = ip.du_comp[k];
+            const int my  = static_cast<int>(magic_quot(mcu, ip.mcus_x_mul, ip.mcus_x_shift));
+            const int mx  = mcu - my * ip.mcus_x;
+            const int x0  = (mx * ip.comp_h[sc] + ip.du_dx[k]) * 8;
+            const int y0  = (my * ip.comp_v[sc] + ip.du_dy[k]) * 8;
+            const int vx  = min(max(ip.size_x[sc] - x0, 0), 8), vy = min(max(ip.size_y[sc] - y0, 0), 8);
+            const uint64_t a = reinterpret_cast<uint64_t>(ip.plane[sc]) + static_cast<uint64_t>(y0) * static_cast<uint32_t>(ip.pitch[sc]) + static_cast<uint32_t>(x0);
+            g = UnitGeo{static_cast<uint32_t>(a), static_cast<uint32_t>(a >> 32), ip.pitch[sc],
+                        static_cast<uint32_t>(vx) | static_cast<uint32_t>(vy) << 4 | static_cast<uint32_t>(ip.qidx[sc]) << 8};
+        }
+        s_geo[t] = g;
     }
     int16_t* blk = s_blk[dl];
-    __syncthreads(); // s_zq, s_desc are loaded
+    uint8_t* const blk_bytes = reinterpret_cast<uint8_t*>(blk);
+    __syncthreads(); // s_zq, s_geo are loaded
 
     // table entries of all iterations (independent loads, one latency); a table entry that was never
     // written (corrupt stream) must not lead out of the buffer
@@ -1067,38 +1072,43 @@ __global__ __launch_bounds__(256) void idct_kernel(JS js)
 #ifndef JG_IDCT_PREFETCH
 #define JG_IDCT_PREFETCH 4
 #endif
+
     constexpr int kAhead = JG_IDCT_PREFETCH; // entries per lane fetched one iteration ahead (8 lanes: kAhead * 8 per unit)
     uint32_t nx[kAhead];
+    // Entries r, r + 8, r + 16, ...: eight entries further is the same slot of the next sector. The loads stay
+    // predicated on the unit's entry count: fetching the sectors behind a unit's last entry without asking (no
+    // compare, no branch) was measured 5 % slower -- this kernel waits for memory, not for instruction issue
+    // (15 % fewer vector instructions from the geometry table bought 3 %).
+    // (scalar base + 32-bit byte offset + immediate: one address register for all of a unit's sectors)
+    const auto sym_at_bytes = [&](uint32_t byte_off) -> uint32_t {
+        return *reinterpret_cast<JG_GLOBAL const uint32_t*>(reinterpret_cast<JG_GLOBAL const uint8_t*>(J.sym) + byte_off);
+    };
     {
-        // entries r, r + 8, r + 16, ...: eight entries further is the same slot of the next sector
-        const uint32_t p0 = sym_advance(toff[0], r);
+        const uint32_t p0 = sym_advance(toff[0], r) * 4u;
 #pragma unroll
-        for (int k = 0; k < kAhead; ++k) nx[k] = r + 8 * k < tcnt[0] ? J.sym[p0 + k * kSymSectorStride] : 0u;
+        for (int k = 0; k < kAhead; ++k) nx[k] = r + 8 * k < tcnt[0] ? sym_at_bytes(p0 + k * kSymSectorStride * 4u) : 0u;
     }
 
 #pragma unroll
     for (int it = 0; it < kIdctIters; ++it) {
-        const int du  = du0 + it * kIdctDuPerBlock + dl;
         uint32_t ex[kAhead];
 #pragma unroll
         for (int k = 0; k < kAhead; ++k) ex[k] = nx[k];
         if (it + 1 < kIdctIters) { // next iteration's first entries are in flight while this one computes
-            const uint32_t p0 = sym_advance(toff[it + 1], r);
+            const uint32_t p0 = sym_advance(toff[it + 1], r) * 4u;
 #pragma unroll
-            for (int k = 0; k < kAhead; ++k) nx[k] = r + 8 * k < tcnt[it + 1] ? J.sym[p0 + k * kSymSectorStride] : 0u;
+            for (int k = 0; k < kAhead; ++k) nx[k] = r + 8 * k < tcnt[it + 1] ? sym_at_bytes(p0 + k * kSymSectorStride * 4u) : 0u;
         }
         // The 8 lanes of a data unit sit in one wave and LDS executes a wave's instructions in order,
         // so the phases below need no workgroup barrier among themselves; only the pixel re-mapping
         // at the end crosses waves (one barrier per iteration, buffers alternate).
         *reinterpret_cast<uint4*>(blk + r * 8) = make_uint4(0, 0, 0, 0);
 
-        // < du_per_mcu even for lanes past the last unit
-        const int k        = du - static_cast<int>(magic_quot(du, dpm_mul, dpm_shift)) * du_per_mcu;
-        const uint32_t* zq = s_zq + s_desc[k].qoff;
+        const uint32_t* zq = s_zq + ((s_geo[it * kIdctDuPerBlock + dl].vis >> 8) & 3u) * 64;
         const auto put = [&](uint32_t v) {
             const uint32_t e = zq[(v >> 16) & 63];
             const int c      = static_cast<int16_t>(v & 0xFFFFu);
-            blk[e & 0xFFu]   = static_cast<int16_t>(c * static_cast<int>(e >> 8));
+            *reinterpret_cast<int16_t*>(blk_bytes + (e & 0xFFu)) = static_cast<int16_t>(c * static_cast<int>(e >> 16));
         };
         const uint32_t cnt = tcnt[it];
 #pragma unroll
@@ -1126,26 +1136,20 @@ __global__ __launch_bounds__(256) void idct_kernel(JS js)
         s_px[it & 1][dl][r] = o;
         __syncthreads();
         {
-            const int r2  = t >> 5;
-            const int j   = t & 31;
-            const int du2 = du0 + it * kIdctDuPerBlock + j;
-            if (du2 < num_du) {
-                const uint2 w    = s_px[it & 1][j][r2];
-                const int mcu2   = static_cast<int>(magic_quot(du2, dpm_mul, dpm_shift));
-                const UnitDesc d = s_desc[du2 - mcu2 * du_per_mcu];
-                const int my     = static_cast<int>(magic_quot(mcu2, mx_mul, mx_shift));
-                const int mx     = mcu2 - my * mcus_x;
-                const int x0 = (mx * d.h + d.dx) * 8;
-                const int y  = (my * d.v + d.dy) * 8 + r2;
-                if (y < d.size_y && x0 < d.size_x) {
-                    JG_GLOBAL uint8_t* row = d.plane + static_cast<size_t>(y) * d.pitch + x0;
-                    if (x0 + 8 <= d.size_x && (reinterpret_cast<uintptr_t>(row) & 7) == 0) {
-                        st_global(reinterpret_cast<JG_GLOBAL uint2*>(row), w);
-                    } else {
+            const int r2      = t >> 5;
+            const int j       = t & 31;
+            const UnitGeo g   = s_geo[it * kIdctDuPerBlock + j]; // all zero behind the last unit: nothing visible
+            const int vx = g.vis & 15, vy = (g.vis >> 4) & 15;
+            if (r2 < vy && vx > 0) {
+                const uint2 w = s_px[it & 1][j][r2];
+                JG_GLOBAL uint8_t* row = reinterpret_cast<JG_GLOBAL uint8_t*>(
+                    ((static_cast<uint64_t>(g.addr_hi) << 32) | g.addr_lo) + static_cast<uint64_t>(static_cast<uint32_t>(r2) * static_cast<uint32_t>(g.pitch)));
+                if (vx == 8 && (reinterpret_cast<uintptr_t>(row) & 7) == 0) {
+                    st_global(reinterpret_cast<JG_GLOBAL uint2*>(row), w);
+                } else {
 #pragma unroll
-                        for (int i = 0; i < 8; ++i) {
-                            if (x0 + i < d.size_x) row[i] = static_cast<uint8_t>((i < 4 ? w.x >> (8 * i) : w.y >> (8 * (i - 4))) & 0xFFu);
-                        }
+                    for (int i = 0; i < 8; ++i) {
+                        if (i < vx) row[i] = static_cast<uint8_t>((i < 4 ? w.x >> (8 * i) : w.y >> (8 * (i - 4))) & 0xFFu);
                     }
                 }
             }

@@ -677,3 +677,23 @@ def test_bench_multi_rank_control_flow_over_gloo(torch_cuda):
     assert g["images_per_round"] == 64 or g["images_per_round"] == 16  # 64 // 2 per rank, capped by the batch
     assert g["gathered_buffers_match_senders"] is True and g["value"] > 0
     assert d["roofline"]["frac"] > 0
+
+
+def test_scan_larger_than_16_mib(torch_cuda):
+    """one scan of 19.4 MiB in ONE restart segment -- 158 632 subsequences of 128
+    bytes, more than the 131 072 one block of the reference's inter-sequence kernel covers (its supersequences are
+    not synchronised with each other, src/decode_huffman.cu:548-558). Planes bit-exact vs the oracle, host walk and
+    device scan."""
+    import jpeggpu_amd
+    from oracle import oracle
+    from tools import jpegsynth
+
+    data = jpegsynth.encode(7216, 5408, ((1, 1), (1, 1), (1, 1)), True, 0, quality=93, noise=10, seed=3)
+    lay = oracle.scan_info(data, 0, 128)
+    assert lay.scan_end - lay.scan_begin > (16 << 20) and lay.num_segments == 1 and lay.num_subseq > 131072
+    ref = oracle.decode(data)
+    for device_scan in (False, True):
+        planes, _info = jpeggpu_amd.decode_to_planes(data, subseq_bytes=128, device_scan=device_scan)
+        for c in range(3):
+            assert np.array_equal(planes[c].cpu().numpy(), ref.planes[c]), (device_scan, c)
+        del planes
