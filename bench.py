@@ -60,6 +60,9 @@ def parse_args():
                     help="flow iterations inside the sequence kernel in batch mode (0 = library default, 1)")
     ap.add_argument("--gather-rounds", type=int, default=10,
                     help="N > 1: rounds of the configs[2] leg (64 images over the ranks + RCCL gather to rank 0); 0 = skip")
+    ap.add_argument("--segment-shard-rounds", type=int, default=5,
+                    help="N > 1: rounds of the restart-interval-sharding leg (ONE 39 MP image, every rank decodes its share of "
+                         "the restart segments, bands gathered on rank 0); 0 = skip")
     ap.add_argument("--latency-iters", type=int, default=200,
                     help="iterations of the reference's own protocol (1 warm-up + 200, benchmark_common.hpp:39); 0 = skip")
     ap.add_argument("--device-scan", type=int, default=0,
@@ -485,6 +488,56 @@ def main():
                   "backend": backend, "gathered_buffers_match_senders": ok}
         bt.destroy()
 
+    # Restart-interval sharding of ONE large image (second bullet): 39 MP 4:2:0 (the size of
+    # BASELINE.json configs[3]) with one restart interval per MCU row; rank r decodes segments [r n / N, (r + 1) n / N)
+    # into its band of the planes (jpeggpu_ext_set_segment_shard), bands gathered on rank 0.
+    segment_shard = None
+    if world > 1 and args.segment_shard_rounds > 0:
+        from tools import jpegsynth
+
+        big = jpegsynth.encode(7216, 5408, ((2, 2), (1, 1), (1, 1)), True, (7216 + 15) // 16, quality=88, noise=9, seed=4242)
+        dec = jp.Decoder(jp.BATCH_SUBSEQ_BYTES)
+        dec.set_segment_shard(rank, world)
+        info = dec.parse_header(big)
+        n = dec.get_buffer_size()
+        tmp = torch.empty(n + 256, dtype=torch.uint8, device=device)
+        base = (tmp.data_ptr() + 255) // 256 * 256
+        shapes = [(info.sizes_y[c], info.sizes_x[c]) for c in range(info.num_components)]
+        full = [torch.zeros(h, w, dtype=torch.uint8, device=device) for h, w in shapes]
+        rows = [dec.shard_rows(c) for c in range(info.num_components)]
+        st = streams[0]
+        on_gpu = backend == "nccl"
+        dec.transfer(base, n, st.cuda_stream)
+        all_rows = [None] * world
+        dist.all_gather_object(all_rows, rows)
+
+        def shard_round():
+            with torch.cuda.stream(st):
+                dec.decode([p.data_ptr() for p in full], [p.stride(0) for p in full], base, n, st.cuda_stream)
+                band = torch.cat([full[c][a:a + k].reshape(-1) for c, (a, k) in enumerate(rows)])
+                return shard.gather_bands(band if on_gpu else band.cpu(), rank, world, dst=0)
+
+        bands = shard_round()
+        torch.cuda.synchronize()
+        barrier()
+        t1 = time.perf_counter()
+        for _ in range(args.segment_shard_rounds):
+            bands = shard_round()
+        torch.cuda.synchronize()
+        barrier()
+        dt = max_over_ranks(time.perf_counter() - t1)
+        ok = None
+        if rank == 0:  # the assembled image against this GPU's own decode of the whole file
+            got = shard.assemble_bands(bands, all_rows, shapes)
+            whole, _ = jp.decode_to_planes(big, device=str(device), subseq_bytes=jp.BATCH_SUBSEQ_BYTES)
+            ok = all(bool(torch.equal(got[c].to(device), whole[c])) for c in range(len(shapes)))
+        segment_shard = {"what": "ONE 7216x5408 4:2:0 image (39 MP, DRI = one MCU row) over the ranks by restart segments, "
+                                 "bands gathered on rank 0", "file_bytes": len(big), "rounds": args.segment_shard_rounds,
+                         "value": args.segment_shard_rounds / dt, "unit": "images/s", "ms_per_image": dt / args.segment_shard_rounds * 1e3,
+                         "rows_of_plane_0_per_rank": [r[0] for r in all_rows], "backend": backend,
+                         "assembled_equals_whole_decode": ok}
+        dec.cleanup()
+
     out = None
     if rank == 0:
         ab = algorithmic_bytes(slots[0])
@@ -558,6 +611,8 @@ def main():
         }
         if gather is not None:
             out["gather"] = gather
+        if segment_shard is not None:
+            out["segment_shard"] = segment_shard
         if args.latency_iters > 0:
             out["latency_ms"] = latency_probe(args, torch, jp, slots[0].data, device, streams[0], device_scan=False)
             out["latency_ms_device_scan"] = latency_probe(args, torch, jp, slots[0].data, device, streams[0], device_scan=True)

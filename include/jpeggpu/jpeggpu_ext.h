@@ -5,6 +5,7 @@
  *   jpeggpu_ext_set_subsequence_bytes  tuning knob the reference leaves as a compile-time constant
  *                                      (src/decoder_defs.hpp:28-34 `chunk_size`)
  *   jpeggpu_ext_get_layout             where the intermediate buffers of the last parsed image sit
+ *   jpeggpu_ext_set_segment_shard      decode a share of one image's restart segments (one image over several GPUs)
  *                                      inside d_tmp, for stage-level parity tests and profiling
  *   jpeggpu_ext_set_profiling /        per-stage device time of a decode from HIP events recorded on the
  *   jpeggpu_ext_get_stage_ms           caller's stream (the reference has wall-clock timing only,
@@ -80,6 +81,17 @@ struct jpeggpu_ext_layout {
 };
 
 enum jpeggpu_status jpeggpu_ext_get_layout(jpeggpu_decoder_t decoder, struct jpeggpu_ext_layout* layout);
+
+/* Restart-interval sharding of ONE image (one large image over the GPUs of a node): after
+ * jpeggpu_ext_set_segment_shard(decoder, rank, world) -- before parse_header -- the decoder transfers and decodes only
+ * restart segments [rank * n / world, (rank + 1) * n / world) of the n the scan has, and writes only the rows of each
+ * plane that those segments cover (jpeggpu_ext_get_shard_rows, after parse_header); `world` decoders, on `world`
+ * devices or one, write disjoint bands that together are the image. Segments are independent for the Huffman decode
+ * and for DC prediction (reference src/decode_dc.cu:119-144). parse_header returns JPEGGPU_NOT_SUPPORTED unless the
+ * file has one scan with a restart interval of whole MCU rows; the host walk is used (no device scan).
+ * world = 1 switches it off. */
+enum jpeggpu_status jpeggpu_ext_set_segment_shard(jpeggpu_decoder_t decoder, int rank, int world);
+enum jpeggpu_status jpeggpu_ext_get_shard_rows(jpeggpu_decoder_t decoder, int component, int* first_row, int* num_rows);
 
 /* Device-side front end (enable != 0, before parse_header): for a file whose first scan holds every component,
  * parse_header stops at the scan header instead of walking the entropy-coded bytes for restart markers (the

@@ -124,6 +124,8 @@ def lib():
     L.jpeggpu_ext_batch_get_stage_ms.argtypes = [C.c_void_p, C.POINTER(C.c_float)]
     L.jpeggpu_ext_upsample_planes.argtypes = [
         C.POINTER(ImgInfo), C.POINTER(Img), C.POINTER(Img), C.c_int, C.c_int, C.c_void_p]
+    L.jpeggpu_ext_set_segment_shard.argtypes = [dec, C.c_int, C.c_int]
+    L.jpeggpu_ext_get_shard_rows.argtypes = [dec, C.c_int, C.POINTER(C.c_int), C.POINTER(C.c_int)]
     L.jpeggpu_ext_set_device_scan.argtypes = [dec, C.c_int]
     L.jpeggpu_ext_get_device_status.argtypes = [dec, C.c_void_p, C.c_void_p, C.POINTER(C.c_int)]
     L.jpeggpu_ext_parse_headers.argtypes = [C.POINTER(ParseItem), C.c_int, C.c_int, C.POINTER(C.c_int)]
@@ -187,6 +189,16 @@ class Decoder:
         """False / 0: host walk; True / 1: marker scan on the device, status via device_status(); 2: checked --
         decode() waits for the stream and raises the device's status (what JPEGGPU_DEVICE_SCAN=1 selects)."""
         _check(lib().jpeggpu_ext_set_device_scan(self._h, int(on)), "jpeggpu_ext_set_device_scan")
+
+    def set_segment_shard(self, rank: int, world: int):
+        """Decode only restart segments [rank * n / world, (rank + 1) * n / world) of the next parsed images."""
+        _check(lib().jpeggpu_ext_set_segment_shard(self._h, rank, world), "jpeggpu_ext_set_segment_shard")
+
+    def shard_rows(self, component: int):
+        """(first_row, num_rows) of the plane rows this decoder writes."""
+        a, n = C.c_int(), C.c_int()
+        _check(lib().jpeggpu_ext_get_shard_rows(self._h, component, C.byref(a), C.byref(n)), "jpeggpu_ext_get_shard_rows")
+        return a.value, n.value
 
     def device_status(self, d_tmp: int, stream: int = 0) -> Status:
         st = C.c_int()

@@ -104,6 +104,7 @@ struct Decoder {
     // images into one launch ask for 128 (jpeggpu_ext_set_subsequence_bytes; bench.py).
     int subseq_bytes    = 64;
     bool parsed         = false;
+    int shard_rank = 0, shard_world = 1; // jpeggpu_ext_set_segment_shard
     int device_scan     = 0;     // jpeggpu_ext_set_device_scan: 0 off, 1 on (status via jpeggpu_ext_get_device_status), 2 on and checked by decode
 
     std::vector<ScanJob> jobs; // scratch of the last decode
@@ -323,7 +324,7 @@ jpeggpu_status build_jobs(
         sp.du_per_mcu       = sc.du_per_mcu;
         sp.num_comp         = sc.num_comp;
         sp.mcus_per_segment = sc.mcus_per_segment;
-        sp.total_mcus       = sc.mcus_x * sc.mcus_y;
+        sp.total_mcus       = sc.shard_mcus ? sc.shard_mcus : sc.mcus_x * sc.mcus_y; // of this decoder's share
         sp.subseq_words     = d.subseq_bytes / 4;
         sp.tab_bytes        = static_cast<uint32_t>(sc.table_pack.size());
         sp.max_intra_iters  = max_intra_iters;
@@ -334,6 +335,7 @@ jpeggpu_status build_jobs(
         ip.num_du      = sc.num_du;
         ip.du_per_mcu  = sc.du_per_mcu;
         ip.mcus_x      = sc.mcus_x;
+        ip.first_mcu   = sc.first_mcu;
         {
             const MagicDiv a = magic_div(static_cast<uint32_t>(sc.du_per_mcu)), b = magic_div(static_cast<uint32_t>(sc.mcus_x));
             ip.du_per_mcu_mul = a.mul, ip.du_per_mcu_shift = a.shift;
@@ -556,7 +558,7 @@ enum jpeggpu_status jpeggpu_decoder_parse_header(
     d.parsed   = false;
     jpeggpu_status st;
     try {
-        st = d.reader.parse(data, size, d.subseq_bytes, d.logger, d.device_scan != 0);
+        st = d.reader.parse(data, size, d.subseq_bytes, d.logger, d.device_scan != 0, d.shard_rank, d.shard_world);
     } catch (const std::bad_alloc&) {
         return JPEGGPU_OUT_OF_HOST_MEMORY;
     }
@@ -615,6 +617,36 @@ enum jpeggpu_status jpeggpu_ext_set_subsequence_bytes(jpeggpu_decoder_t decoder,
     if (!decoder || !jg::subseq_bytes_supported(subseq_bytes)) return JPEGGPU_INVALID_ARGUMENT;
     decoder->d.subseq_bytes = subseq_bytes;
     decoder->d.parsed       = false;
+    return JPEGGPU_SUCCESS;
+}
+
+enum jpeggpu_status jpeggpu_ext_set_segment_shard(jpeggpu_decoder_t decoder, int rank, int world)
+{
+    if (!decoder || world < 1 || rank < 0 || rank >= world) return JPEGGPU_INVALID_ARGUMENT;
+    decoder->d.shard_rank  = rank;
+    decoder->d.shard_world = world;
+    decoder->d.parsed      = false;
+    return JPEGGPU_SUCCESS;
+}
+
+enum jpeggpu_status jpeggpu_ext_get_shard_rows(jpeggpu_decoder_t decoder, int component, int* first_row, int* num_rows)
+{
+    if (!decoder || !first_row || !num_rows) return JPEGGPU_INVALID_ARGUMENT;
+    const Decoder& d = decoder->d;
+    if (!d.parsed) return JPEGGPU_INVALID_ARGUMENT;
+    const jg::Stream& s = d.reader.s;
+    if (component < 0 || component >= s.num_comp) return JPEGGPU_INVALID_ARGUMENT;
+    const jg::Component& fc = s.comp[component];
+    *first_row = 0;
+    *num_rows  = fc.size_y;
+    const jg::Scan& sc = s.scans[0];
+    if (sc.total_segments == 0) return JPEGGPU_SUCCESS; // no shard: every row
+    int v = 1;
+    for (int a = 0; a < sc.num_comp; ++a)
+        if (sc.comp[a].comp_idx == component) v = sc.comp[a].v;
+    const int row0 = sc.first_mcu / sc.mcus_x * 8 * v, row1 = (sc.first_mcu + sc.shard_mcus) / sc.mcus_x * 8 * v;
+    *first_row = std::min(row0, fc.size_y);
+    *num_rows  = std::min(row1, fc.size_y) - *first_row;
     return JPEGGPU_SUCCESS;
 }
 

@@ -237,9 +237,10 @@ static_assert(sizeof(CursorEntry) == 16, "read with one 16-byte load");
 /// Geometry for dequant + IDCT reading the stream-order coefficient buffer (replaces the reference's
 /// separate transpose pass, src/decode_transpose.cu:41-132, plus src/idct.cu:146-223).
 struct IdctParams {
-    int num_du;     // data units in the scan (< 2^31)
+    int num_du;     // data units in the scan (< 2^31), or in this decoder's share of its restart segments
     int du_per_mcu;
     int mcus_x;
+    int first_mcu;  // MCU of the frame that data unit 0 belongs to (non-zero for a segment shard, jpeggpu_ext.h)
     // n / d for n < 2^31 as (mulhi(n, mul) >> shift); mul == 0 stands for d == 1 (jg_defs.h, magic_div)
     uint32_t du_per_mcu_mul, du_per_mcu_shift;
     uint32_t mcus_x_mul, mcus_x_shift;

@@ -1039,9 +1039,10 @@ __global__ __launch_bounds__(256) void idct_kernel(JS js)
         const int du = du0 + t;
         UnitGeo g{0u, 0u, 0, 0u};
         if (du < num_du) {
-            const int mcu = static_cast<int>(magic_quot(du, ip.du_per_mcu_mul, ip.du_per_mcu_shift));
-            const int k   = du - mcu * ip.du_per_mcu;
+            const int rel = static_cast<int>(magic_quot(du, ip.du_per_mcu_mul, ip.du_per_mcu_shift));
+            const int k   = du - rel * ip.du_per_mcu;
             const int sc  = ip.du_comp[k];
+            const int mcu = rel + ip.first_mcu;
             const int my  = static_cast<int>(magic_quot(mcu, ip.mcus_x_mul, ip.mcus_x_shift));
             const int mx  = mcu - my * ip.mcus_x;
             const int x0  = (mx * ip.comp_h[sc] + ip.du_dx[k]) * 8;

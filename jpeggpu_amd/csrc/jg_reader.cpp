@@ -686,8 +686,75 @@ jpeggpu_status Reader::walk_scan(Scan& scan, const Logger& log)
     return JPEGGPU_SUCCESS;
 }
 
-jpeggpu_status Reader::parse(const uint8_t* data, size_t size, int subseq_bytes, const Logger& log, bool device_scan)
+/// Keep only this decoder's share of the scan's restart segments (segments are independent for the
+/// Huffman decode and for DC prediction, reference src/decode_dc.cu:119-144): segments [rank * n / world,
+/// (rank + 1) * n / world), renumbered from 0, with the destuff work list, the transferred byte range and the tail
+/// parts cut to them. Needs a single scan whose restart interval is a whole number of MCU rows, so that a run of
+/// segments is a horizontal band of every plane.
+jpeggpu_status Reader::apply_segment_shard(int rank, int world, const Logger& log)
 {
+    if (s.num_scans != 1 || s.restart_interval == 0) {
+        log.log("\tsegment shard needs one scan with restart markers\n");
+        return JPEGGPU_NOT_SUPPORTED;
+    }
+    Scan& scan = s.scans[0];
+    if (scan.mcus_per_segment % scan.mcus_x != 0) {
+        log.log("\tsegment shard needs a restart interval of whole MCU rows\n");
+        return JPEGGPU_NOT_SUPPORTED;
+    }
+    const int n = static_cast<int>(scan.segments.size());
+    const int a = static_cast<int>(static_cast<long long>(n) * rank / world);
+    const int b = static_cast<int>(static_cast<long long>(n) * (rank + 1) / world);
+    const int total_mcus = scan.mcus_x * scan.mcus_y;
+    scan.first_segment   = a;
+    scan.total_segments  = n;
+    scan.first_mcu       = a * scan.mcus_per_segment;
+    scan.shard_mcus      = std::min(b * scan.mcus_per_segment, total_mcus) - std::min(a * scan.mcus_per_segment, total_mcus);
+    scan.num_du          = scan.shard_mcus * scan.du_per_mcu;
+    if (a == b) { // more ranks than segments: nothing to do on this one
+        scan.segments.clear();
+        scan.chunks.clear();
+        scan.tail_parts.assign(1, 0);
+        scan.num_subseq = 0;
+        s.xfer_end      = s.xfer_begin;
+        return JPEGGPU_SUCCESS;
+    }
+    const uint32_t first_sub = static_cast<uint32_t>(scan.segments[a].subseq_offset);
+    const uint32_t dst_shift = first_sub * static_cast<uint32_t>(subseq_bytes_);
+    std::vector<Segment> segs(scan.segments.begin() + a, scan.segments.begin() + b);
+    for (Segment& g : segs) g.subseq_offset -= static_cast<int>(first_sub);
+    std::vector<DestuffChunk> chunks;
+    for (const DestuffChunk& c : scan.chunks)
+        if (c.seg >= a && c.seg < b) chunks.push_back(c);
+    // the window grid of the destuff kernel starts at offset 0 of the transferred bytes: shift by whole windows
+    const uint32_t win_shift = chunks.front().win_off;
+    uint32_t last_end        = 0;
+    for (DestuffChunk& c : chunks) {
+        c.win_off -= win_shift;
+        c.begin -= win_shift;
+        c.end -= win_shift;
+        c.dst_off -= dst_shift;
+        if (c.pad_end) c.pad_end -= dst_shift;
+        c.seg -= a;
+        last_end = std::max(last_end, c.end);
+    }
+    s.xfer_begin += win_shift;
+    s.xfer_end = s.xfer_begin + last_end;
+    scan.segments.swap(segs);
+    scan.chunks.swap(chunks);
+    scan.num_subseq = scan.segments.back().subseq_offset + scan.segments.back().subseq_count;
+    scan.tail_parts.clear();
+    scan.tail_parts.push_back(0);
+    for (const Segment& seg : scan.segments)
+        if (seg.subseq_offset - scan.tail_parts.back() >= kTailPartSubseq) scan.tail_parts.push_back(seg.subseq_offset);
+    scan.tail_parts.push_back(scan.num_subseq);
+    return JPEGGPU_SUCCESS;
+}
+
+jpeggpu_status Reader::parse(const uint8_t* data, size_t size, int subseq_bytes, const Logger& log, bool device_scan,
+                             int shard_rank, int shard_world)
+{
+    if (shard_world > 1) device_scan = false; // the share is cut out of the host walk's tables
     device_scan_ = device_scan;
     stop_        = false;
     {
@@ -787,6 +854,7 @@ jpeggpu_status Reader::parse(const uint8_t* data, size_t size, int subseq_bytes,
             return JPEGGPU_INVALID_JPEG;
         }
     }
+    if (shard_world > 1) return apply_segment_shard(shard_rank, shard_world, log);
     return JPEGGPU_SUCCESS;
 }
 

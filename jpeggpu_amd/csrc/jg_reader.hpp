@@ -59,6 +59,12 @@ struct Scan {
     int mcus_per_segment = 0;
     int num_subseq = 0;
     int num_du = 0;
+    // Segment shard (jpeggpu_ext_set_segment_shard): the tables below describe only this decoder's share of the
+    // scan's restart segments, renumbered from 0; data unit 0 of the share lies in MCU `first_mcu` of the frame and
+    // the share holds `shard_mcus` MCUs (0: no shard, the whole scan).
+    int first_mcu  = 0;
+    int shard_mcus = 0;
+    int first_segment = 0, total_segments = 0;
     std::vector<uint8_t> table_pack;      // tables in force at SOS that this scan's components select (write pass)
     std::vector<uint8_t> table_pack_sync; // the same tables in the form of the state-only passes (jg_defs.h)
     uint32_t cursor_off = 0, cursor_off_sync = 0; // byte offset of the cursor ring in each pack
@@ -90,7 +96,8 @@ struct Stream {
 struct Reader {
     /// `device_scan`: a file whose first scan holds every component is not walked on the host (jg_front.hip
     /// does it on the device); parsing stops at that scan's first entropy-coded byte.
-    jpeggpu_status parse(const uint8_t* data, size_t size, int subseq_bytes, const Logger& log, bool device_scan = false);
+    jpeggpu_status parse(const uint8_t* data, size_t size, int subseq_bytes, const Logger& log, bool device_scan = false,
+                         int shard_rank = 0, int shard_world = 1);
 
     Stream s;
 
@@ -123,6 +130,7 @@ struct Reader {
     jpeggpu_status read_sos(const Logger& log);
     jpeggpu_status walk_scan(Scan& scan, const Logger& log);
     jpeggpu_status skip_segment(const Logger& log);
+    jpeggpu_status apply_segment_shard(int rank, int world, const Logger& log);
 };
 
 /// Build the device form of one Huffman table from a DHT payload

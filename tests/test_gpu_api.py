@@ -666,7 +666,7 @@ def test_bench_multi_rank_control_flow_over_gloo(torch_cuda):
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
            "--master-port", str(port), os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "2", "--warmup", "1",
            "--batch", "8", "--rounds", "1", "--unique", "2", "--latency-iters", "0", "--no-cpu", "--e2e-rounds", "0",
-           "--roofline-launches", "2", "--gather-rounds", "2"]
+           "--roofline-launches", "2", "--gather-rounds", "2", "--segment-shard-rounds", "2"]
     r = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=600)
     assert r.returncode == 0, r.stderr[-3000:]
     line = [ln for ln in r.stdout.splitlines() if ln.startswith("{")][-1]
@@ -677,6 +677,8 @@ def test_bench_multi_rank_control_flow_over_gloo(torch_cuda):
     assert g["images_per_round"] == 64 or g["images_per_round"] == 16  # 64 // 2 per rank, capped by the batch
     assert g["gathered_buffers_match_senders"] is True and g["value"] > 0
     assert d["roofline"]["frac"] > 0
+    sh = d["segment_shard"]  # one 39 MP image over the two ranks by restart segments
+    assert sh["assembled_equals_whole_decode"] is True and len(sh["rows_of_plane_0_per_rank"]) == 2 and sh["value"] > 0
 
 
 def test_scan_larger_than_16_mib(torch_cuda):
@@ -697,3 +699,47 @@ def test_scan_larger_than_16_mib(torch_cuda):
         for c in range(3):
             assert np.array_equal(planes[c].cpu().numpy(), ref.planes[c]), (device_scan, c)
         del planes
+
+
+def test_segment_shard_bands_make_the_image(torch_cuda):
+    """jpeggpu_ext_set_segment_shard: `world` decoders each take a share of the restart segments and write only their
+    band of every plane; together the bands are the oracle's image, and nothing outside a band is touched."""
+    import jpeggpu_amd
+    from jpeggpu_amd import JpegGpuError, Status
+    from oracle import oracle
+    from tools import jpegsynth
+
+    torch = torch_cuda
+    m = cases.matrix()
+    inputs = {"dri_row": m["dri_row"], "cfg2_small": m["cfg2_small"], "gray_rows": jpegsynth.encode(200, 152, ((1, 1),), restart_interval=50, seed=77),
+              "two_rows": jpegsynth.encode(333, 251, cases.S420, restart_interval=42, seed=78)}
+    for name, data in inputs.items():
+        ref = oracle.decode(data)
+        for world in (2, 3, 7):
+            planes = [torch.full(p.shape, 0xAB, dtype=torch.uint8, device="cuda:0") for p in ref.planes]
+            for rank in range(world):
+                dec = jpeggpu_amd.Decoder(32 if rank % 2 else 64)
+                dec.set_segment_shard(rank, world)
+                info = dec.parse_header(data)
+                n = dec.get_buffer_size()
+                tmp = torch.empty(n + 256, dtype=torch.uint8, device="cuda:0")
+                base = (tmp.data_ptr() + 255) // 256 * 256
+                before = [p.clone() for p in planes]
+                dec.transfer(base, n, 0)
+                dec.decode([p.data_ptr() for p in planes], [p.stride(0) for p in planes], base, n, 0)
+                torch.cuda.synchronize()
+                for c in range(info.num_components):
+                    a, cnt = dec.shard_rows(c)
+                    assert torch.equal(planes[c][:a], before[c][:a]) and torch.equal(planes[c][a + cnt:], before[c][a + cnt:]), (name, world, rank, c)
+                    assert np.array_equal(planes[c][a:a + cnt].cpu().numpy(), ref.planes[c][a:a + cnt]), (name, world, rank, c)
+                dec.cleanup()
+            for c in range(ref.ncomp):
+                assert np.array_equal(planes[c].cpu().numpy(), ref.planes[c]), (name, world, c)
+    # what cannot be cut into bands says so at parse time
+    for name in ("dri_7", "multi_seq_nodri", "ni_420_dri"):
+        dec = jpeggpu_amd.Decoder()
+        dec.set_segment_shard(0, 2)
+        with pytest.raises(JpegGpuError) as e:
+            dec.parse_header(m[name])
+        assert e.value.status == Status.NOT_SUPPORTED
+        dec.cleanup()

@@ -69,3 +69,50 @@ def test_two_rank_gather_over_gloo():
         p.join(120)
         assert p.exitcode == 0
     assert result.get() is True
+
+
+def _band_worker(rank, world, port, result):
+    """Restart-interval sharding of one image: the library's host parse says which rows a rank owns; the oracle's
+    rows stand in for the device decode; rank 0 gathers the bands and puts the image back together."""
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        import jpeggpu_amd
+        from oracle import oracle
+        from tests import cases
+
+        data = cases.matrix()["dri_row"]
+        ref = oracle.decode(data)
+        dec = jpeggpu_amd.Decoder()
+        dec.set_segment_shard(rank, world)
+        info = dec.parse_header(data)
+        rows = [dec.shard_rows(c) for c in range(info.num_components)]
+        dec.cleanup()
+        band = torch.from_numpy(np.concatenate([ref.planes[c][a:a + n].reshape(-1) for c, (a, n) in enumerate(rows)]))
+        all_rows = [None] * world
+        dist.all_gather_object(all_rows, rows)
+        bands = shard.gather_bands(band, rank, world, dst=0)
+        if rank == 0:
+            planes = shard.assemble_bands(bands, all_rows, [p.shape for p in ref.planes])
+            result.put(all(np.array_equal(planes[c].numpy(), ref.planes[c]) for c in range(ref.ncomp)))
+        else:
+            assert bands is None
+        dist.barrier()
+    finally:
+        dist.destroy_process_group()
+
+
+def test_two_rank_segment_bands_over_gloo():
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    ctx = mp.get_context("spawn")
+    result = ctx.SimpleQueue()
+    procs = [ctx.Process(target=_band_worker, args=(r, 2, port, result)) for r in range(2)]
+    for p in procs:
+        p.start()
+    for p in procs:
+        p.join(120)
+        assert p.exitcode == 0
+    assert result.get() is True
