@@ -696,12 +696,15 @@ struct StreamSink {
     int du;       // next data unit this lane starts
     int quota;    // first data unit past the segment
     int ticks;
-    // Data-unit records wait here until the next common flush point: a lane's units are consecutive in the
-    // table and contiguous in its region, so the table index and the offset of the first waiting one, plus
-    // packed entry counts, describe up to four.
+    // Data-unit records {first entry, count} wait here until FOUR of them fill a 32-byte sector of the table: a
+    // lane's units are consecutive in the table and contiguous in its region, so the table index and the offset of
+    // the first waiting one, plus packed entry counts (up to eight, one byte each), describe them. Stored one by
+    // one as they completed, every 8-byte record became a memory write of its own -- the line it belongs to takes a
+    // lane ~16 units to fill and does not live that long in L2: 11.5 MB of HBM writes per 12 MP image for a 2.3 MB
+    // table (rocprofv3 WRITE_SIZE).
     uint32_t rec_off;   // region-relative offset of the first unit whose record has not been stored
     int rec_du;         // its index in the data-unit table
-    uint32_t pend_cnts;
+    uint32_t pend_lo, pend_hi; // counts of waiting units 0..3 and 4..7
     int pend_n;
     bool started; // false while the first symbols finish the predecessor's data unit
     __device__ __forceinline__ bool full() const { return du >= quota; }
@@ -717,25 +720,47 @@ struct StreamSink {
         const uint32_t slot = emit ? (emitted & (kStageEntries - 1)) : kStageEntries;
         ring[slot * T]      = entry;
         emitted += emit ? 1u : 0u;
-        // A store per finished unit would be issued by the wave in almost every iteration for a lane or two
-        // (80 % of the kernel's store instructions, 145 of its 690 us per 32 images): the record is kept
-        // and leaves with the next common flush. A unit takes at least two symbols, so at most four finish
-        // between two flush points.
-        const bool done = unit_end && started;
-        pend_cnts |= done ? (emitted - du_off) << (8 * pend_n) : 0u;
+        // A unit takes at least two symbols, so at most four finish between two flush points (8 iterations); a
+        // flush leaves at most three waiting: eight slots are enough.
+        const bool done    = unit_end && started;
+        const uint32_t cnt = (emitted - du_off) << (8 * (pend_n & 3));
+        pend_lo |= done && pend_n < 4 ? cnt : 0u;
+        pend_hi |= done && pend_n >= 4 ? cnt : 0u;
         pend_n += done ? 1 : 0;
+    }
+    /// Store the first `n` waiting records (1..4) and move the others down.
+    __device__ __forceinline__ void store_units(int n)
+    {
+        uint2_t rec[4];
+        uint32_t off = rec_off;
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            const uint32_t cnt = (pend_lo >> (8 * k)) & 0xFFu;
+            rec[k]             = uint2_t{sym_at(base, off), cnt};
+            off += k < n ? cnt : 0u;
+        }
+        JG_GLOBAL uint2_t* dst = du_tab + rec_du;
+        if (n == 4 && (rec_du & 3) == 0) { // a whole, aligned sector of the table
+            st_global(reinterpret_cast<JG_GLOBAL uint4*>(dst), make_uint4(rec[0].x, rec[0].y, rec[1].x, rec[1].y));
+            st_global(reinterpret_cast<JG_GLOBAL uint4*>(dst) + 1, make_uint4(rec[2].x, rec[2].y, rec[3].x, rec[3].y));
+        } else {
+#pragma unroll
+            for (int k = 0; k < 4; ++k)
+                if (k < n) st_global(dst + k, rec[k]);
+        }
+        rec_off = off;
+        rec_du += n;
+        pend_n -= n;
+        // the counts move down by n bytes (n == 4: the high word becomes the low one)
+        const uint64_t both = ((static_cast<uint64_t>(pend_hi) << 32) | pend_lo) >> (8 * n);
+        pend_lo = static_cast<uint32_t>(both);
+        pend_hi = static_cast<uint32_t>(both >> 32);
     }
     __device__ __forceinline__ void flush_units()
     {
-#pragma unroll
-        for (int k = 0; k < 4; ++k) {
-            const uint32_t cnt = (pend_cnts >> (8 * k)) & 0xFFu;
-            if (k < pend_n) st_global(du_tab + rec_du + k, uint2_t{sym_at(base, rec_off), cnt});
-            rec_off += cnt; // zero beyond pend_n
-        }
-        rec_du += pend_n;
-        pend_n    = 0;
-        pend_cnts = 0;
+        // up to the next sector boundary of the table; from then on the lane stores whole sectors (a second round
+        // only right after the lane's first, shorter store: at most three records stay behind)
+        while (pend_n >= 4) store_units(4 - (rec_du & 3));
     }
     /// kFlushEntries entries from the ring to memory; `flushed` is a multiple of kFlushEntries.
     __device__ __forceinline__ void flush_sector()
@@ -762,7 +787,7 @@ struct StreamSink {
     __device__ __forceinline__ void finish()
     {
         while (flushed < emitted) flush_sector();
-        flush_units();
+        while (pend_n > 0) store_units(pend_n < 4 ? pend_n : 4);
     }
 };
 
@@ -897,7 +922,8 @@ __global__ __launch_bounds__(T) void huff_write(JS js)
     sink.ticks          = 0;
     sink.rec_off        = 0;
     sink.rec_du         = sink.du; // the first unit this lane starts
-    sink.pend_cnts      = 0;
+    sink.pend_lo        = 0;
+    sink.pend_hi        = 0;
     sink.pend_n         = 0;
 
     LaneState st{};
