@@ -15,7 +15,7 @@ from . import build as _build
 MAX_COMP = 4
 # Subsequence size the benchmark and the batch examples ask for (jpeggpu_ext_set_subsequence_bytes) when many images
 # share a launch; a decoder left alone uses the library's default, chosen for a lone decode.
-BATCH_SUBSEQ_BYTES = 128
+BATCH_SUBSEQ_BYTES = 256
 STAGES = ("front", "destuff", "sync_intra", "sync_inter", "tails", "write", "idct")
 
 

@@ -101,7 +101,7 @@ struct Decoder {
     size_t data_size    = 0;
     // Default of a decoder nobody configured: the best size for ONE image at a time, from 0.08 to 12 MP
     // (tools/probe/latency_by_size.py; a shorter subsequence is a shorter serial chain per lane). Callers that put many
-    // images into one launch ask for 128 (jpeggpu_ext_set_subsequence_bytes; bench.py).
+    // images into one launch ask for 256 (jpeggpu_ext_set_subsequence_bytes; bench.py).
     int subseq_bytes    = 64;
     bool parsed         = false;
     int shard_rank = 0, shard_world = 1; // jpeggpu_ext_set_segment_shard
