@@ -24,7 +24,7 @@ def main():
     rng = np.random.default_rng(int(sys.argv[2]) if len(sys.argv) > 2 else 1)
     samplings = [((1, 1),) * 3, ((2, 2), (1, 1), (1, 1)), ((2, 1), (1, 1), (1, 1)), ((1, 2), (1, 1), (1, 1)),
                  ((4, 1), (1, 1), (1, 1)), ((1, 1),), ((2, 1), (1, 1), (1, 1), (2, 1)), ((2, 2), (1, 1))]
-    t0, rounds, images = time.time(), 0, 0
+    t0, rounds, images, sharded = time.time(), 0, 0, 0
     while time.time() - t0 < budget:
         sb = int(rng.choice([32, 64, 128, 256]))
         items, refs, keep = [], [], []
@@ -67,12 +67,34 @@ def main():
                 assert np.array_equal(planes[c].cpu().numpy(), ref.planes[c]), ("batch", rounds, len(data), c)
                 planes[c].fill_(0x3C)
         # the same images through the drop-in call, half of them with the device-side marker scan
-        singles = []
+        singles, shard_keep = [], []
         for (dec, tmp, planes, data), ref, it in zip(keep, refs, items):
             dec.cleanup()
             dec2 = jp.Decoder(sb)
             dev = bool(rng.integers(2))
             dec2.set_device_scan(dev)
+            world = int(rng.choice([1, 1, 2, 3, 5]))
+            if world > 1:
+                # restart-interval sharding (jpeggpu_ext_set_segment_shard): the first world - 1 shares through
+                # decoders of their own, the last one through dec2 below; files that cannot be cut say so
+                try:
+                    shares = []
+                    for r in range(world - 1):
+                        d3 = jp.Decoder(sb)
+                        d3.set_segment_shard(r, world)
+                        d3.parse_header(data)
+                        n3 = d3.get_buffer_size()
+                        tmp3 = torch.empty(n3 + 256, dtype=torch.uint8, device="cuda:0")
+                        base3 = (tmp3.data_ptr() + 255) // 256 * 256
+                        d3.transfer(base3, n3, 0)
+                        d3.decode(it[1], it[2], base3, n3, 0)
+                        shares.append((d3, tmp3))
+                    shard_keep.extend(shares)
+                    dec2.set_segment_shard(world - 1, world)
+                    sharded += 1
+                except jp.JpegGpuError as e:
+                    assert e.status == jp.Status.NOT_SUPPORTED, e.status
+                    dec2.set_segment_shard(0, 1)
             dec2.parse_header(data)
             n2 = dec2.get_buffer_size()
             tmp2 = torch.empty(n2 + 256, dtype=torch.uint8, device="cuda:0")
@@ -87,12 +109,14 @@ def main():
             for c in range(ref.ncomp):
                 assert np.array_equal(planes[c].cpu().numpy(), ref.planes[c]), ("single", rounds, len(data), c)
             dec2.cleanup()
+        for d3, _ in shard_keep:
+            d3.cleanup()
         batch.destroy()
         rounds += 1
         images += len(keep)
         if rounds % 20 == 0:  # a run that stays silent for minutes is taken to be hung on the GPU pool
             print("  %d rounds, %d images, %.0f s" % (rounds, images, time.time() - t0), flush=True)
-    print("soak ok: %d rounds, %d images, %.0f s" % (rounds, images, time.time() - t0))
+    print("soak ok: %d rounds, %d images (%d of them also decoded as restart-segment shares), %.0f s" % (rounds, images, sharded, time.time() - t0))
 
 
 if __name__ == "__main__":
