@@ -214,7 +214,7 @@ void Decoder::make_plan()
     }
     for (int i = 0; i < s.num_scans; ++i) {
         p.scan[i].sym = o; // symbol stream: a fixed region per subsequence
-        o += align_up(sym_buffer_entries(static_cast<uint32_t>(s.scans[i].num_subseq), sym_region_entries(subseq_bytes)) * 4 + 256, 256);
+        o += align_up(sym_buffer_entries(static_cast<uint32_t>(s.scans[i].num_subseq), sym_region_entries(subseq_bytes)) * 2 + 256, 256);
         p.scan[i].du_tab = o;
         o += align_up(static_cast<size_t>(s.scans[i].num_du) * sizeof(uint2_t), 256);
     }
@@ -384,7 +384,7 @@ jpeggpu_status build_jobs(
         job.tails_n    = reinterpret_cast<int*>(base + pl.tails_n);
         job.tails_dc01 = reinterpret_cast<uint32_t*>(base + pl.tails_dc01);
         job.tails_dc23 = reinterpret_cast<uint32_t*>(base + pl.tails_dc23);
-        job.sym         = reinterpret_cast<uint32_t*>(base + pl.sym);
+        job.sym         = reinterpret_cast<uint16_t*>(base + pl.sym);
         job.du_tab      = reinterpret_cast<uint2_t*>(base + pl.du_tab);
         job.sym_region  = sym_region_entries(d.subseq_bytes);
         job.sym_entries = sym_buffer_entries(static_cast<uint32_t>(sc.num_subseq), job.sym_region);

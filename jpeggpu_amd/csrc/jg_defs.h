@@ -150,10 +150,20 @@ JG_HD inline uint64_t tiled_buffer_bytes(uint32_t num_subseq, int subseq_bytes, 
     return tiles * kTileSubseq * (static_cast<uint64_t>(subseq_bytes) + 4u * kRowExtraWords);
 }
 
-/// Entries of the symbol stream reserved per subsequence: an emitted entry (DC, or a non-zero AC
-/// coefficient with its magnitude bits) takes at least 2 bits of the stream on average over a data
-/// unit, plus up to one data unit of overrun (a lane finishes the unit it started).
-JG_HD inline uint32_t sym_region_entries(int subseq_bytes) { return static_cast<uint32_t>(subseq_bytes) * 4u + 64u + 8u; } // + a sector of flush slack; a multiple of 8
+/// The SYMBOL STREAM the write pass emits and the IDCT gathers: 16-bit entries, contiguous per data unit.
+///   * a unit's FIRST entry is its DC coefficient, absolute (the predictor is already added), 16 bits;
+///   * every other entry is a non-zero AC coefficient: zig-zag index (1..63) << 10 | value & 0x3FF, value in
+///     -512..511 as a 10-bit two's complement number;
+///   * an AC coefficient outside that range (magnitude category 10 and above: quantisers of 1 at best) is followed by an
+///     ESCAPE entry, zig-zag field 0: its low bits are value >> 10, so value = int16(escape << 10 | low 10 bits).
+/// Half the bytes of a 32-bit entry (index << 16 | value) -- the stream is most of what the write pass stores and the
+/// IDCT fetches: with every other sector left out (timing only) the write pass ran 15 % and a batch 11 % faster.
+///
+/// Entries reserved per subsequence: an emitted entry takes at least 2 bits of the stream on average over a data
+/// unit (an escaped coefficient two entries for 12 bits or more), plus up to one data unit of overrun (a lane
+/// finishes the unit it started).
+constexpr uint32_t kSymSectorEntries = 16; // entries a lane flushes at a time: one 32-byte sector
+JG_HD inline uint32_t sym_region_entries(int subseq_bytes) { return static_cast<uint32_t>(subseq_bytes) * 4u + 64u + 16u; } // + a sector of flush slack; a multiple of 16
 
 struct uint2_t {
     uint32_t x, y;
@@ -161,31 +171,35 @@ struct uint2_t {
 
 /// Placement of the symbol stream in memory. Logically every subsequence has a region of
 /// sym_region_entries() entries; physically the regions of 64 consecutive subsequences are interleaved
-/// sector by sector (a sector = 8 entries = 32 bytes, the unit a lane flushes): sector j of subsequence s sits
-/// at entry ((s / 64) * R + j) * 512 + (s % 64) * 8, R = sectors per region. The 64 lanes of a wave flush
-/// together, so the four sectors of a 128-byte line come from four neighbouring lanes at the same time;
-/// with plain regions (2.3 KB apart) a line got its sectors from ONE lane over ~32 iterations and was
-/// evicted from L2 partially written in between (as for the bitstream: tiled_word above).
+/// sector by sector: sector j of subsequence s sits at entry ((s / 64) * R + j) * 1024 + (s % 64) * 16, R = sectors
+/// per region. The 64 lanes of a wave flush together, so the four sectors of a 128-byte line come from four
+/// neighbouring lanes at the same time; with plain regions a line got its sectors from ONE lane over ~32 iterations
+/// and was evicted from L2 partially written in between (as for the bitstream: tiled_word above).
 constexpr uint32_t kSymTileSubseq = 64;
-constexpr uint32_t kSymSectorStride = kSymTileSubseq * 8; // entries between consecutive sectors of one region
+constexpr uint32_t kSymSectorStride = kSymTileSubseq * kSymSectorEntries; // entries between consecutive sectors of one region
 JG_HD inline uint32_t sym_region_base(uint32_t sub, uint32_t region_entries)
 {
-    return (sub / kSymTileSubseq) * (region_entries / 8u) * kSymSectorStride + (sub % kSymTileSubseq) * 8u;
+    return (sub / kSymTileSubseq) * (region_entries / kSymSectorEntries) * kSymSectorStride + (sub % kSymTileSubseq) * kSymSectorEntries;
 }
 /// Physical index of logical entry `e` of the region that starts at physical `base`.
-JG_HD inline uint32_t sym_at(uint32_t base, uint32_t e) { return base + (e >> 3) * kSymSectorStride + (e & 7u); }
+JG_HD inline uint32_t sym_at(uint32_t base, uint32_t e)
+{
+    return base + (e / kSymSectorEntries) * kSymSectorStride + (e % kSymSectorEntries);
+}
 /// Physical index of the k-th entry after the entry at physical index `first` (same region).
 JG_HD inline uint32_t sym_advance(uint32_t first, uint32_t k)
 {
-    const uint32_t w = (first & 7u) + k;
-    return (first & ~7u) + (w >> 3) * kSymSectorStride + (w & 7u);
+    const uint32_t w = (first % kSymSectorEntries) + k;
+    return (first & ~(kSymSectorEntries - 1u)) + (w / kSymSectorEntries) * kSymSectorStride + (w % kSymSectorEntries);
 }
-/// Entries of the whole stream buffer, with room for a 64-entry gather starting at any clamped index.
+/// Entries of the whole stream buffer, with room for a 128-entry gather starting at any clamped index.
 JG_HD inline uint64_t sym_buffer_entries(uint32_t num_subseq, uint32_t region_entries)
 {
     const uint64_t tiles = (static_cast<uint64_t>(num_subseq) + kSymTileSubseq - 1) / kSymTileSubseq;
-    return tiles * (region_entries / 8u) * kSymSectorStride + 16u * kSymSectorStride;
+    return tiles * (region_entries / kSymSectorEntries) * kSymSectorStride + 16u * kSymSectorStride;
 }
+/// Most entries a data unit can have: 64 coefficients, every AC one escaped.
+constexpr uint32_t kMaxUnitEntries = 64 + 63;
 
 /// One restart segment of a scan inside the destuffed buffer (reference src/reader.hpp:38-43).
 struct Segment {
@@ -300,7 +314,7 @@ struct ScanJob {
     int* tails_n;                // per-sequence aggregates used to place the write pass
     uint32_t* tails_dc01;
     uint32_t* tails_dc23;
-    uint32_t* sym;               // symbol stream: one region of `sym_region` entries per subsequence, interleaved (above)
+    uint16_t* sym;               // symbol stream: one region of `sym_region` 16-bit entries per subsequence, interleaved (above)
     uint2_t* du_tab;             // per data unit (stream order): {physical index of the first entry, number of entries}
     uint32_t sym_region;         // entries per subsequence region
     uint64_t sym_entries;        // entries of the buffer (sym_buffer_entries)

@@ -193,7 +193,7 @@ struct NoSink {
     static constexpr bool kWholeUnits = false;
     static constexpr bool kSums       = true;
     JG_HD inline bool full() const { return false; }
-    JG_HD inline void symbol(bool, bool, uint32_t, bool) {}
+    JG_HD inline void symbol(bool, bool, int, int, bool) {}
     JG_HD inline void tick() {}
 };
 
@@ -203,12 +203,11 @@ struct SpecSink : NoSink {
     static constexpr bool kSums = false;
 };
 
-/// One entry of the symbol stream the write pass emits: a non-zero coefficient (or the absolute DC)
-/// of a data unit, zig-zag position in bits 16..21, 16-bit value in the low half.
-JG_HD inline uint32_t sym_entry(int zpos, int value)
-{
-    return (static_cast<uint32_t>(zpos) << 16) | (static_cast<uint32_t>(value) & 0xFFFFu);
-}
+/// Entries of the symbol stream the write pass emits (jg_defs.h): the AC entry of a coefficient at zig-zag index
+/// `zpos` (the low 10 bits of its value), and the escape entry that follows it if the value does not fit them.
+JG_HD inline uint32_t sym_entry_ac(int zpos, int value) { return (static_cast<uint32_t>(zpos) << 10) | (static_cast<uint32_t>(value) & 0x3FFu); }
+JG_HD inline uint32_t sym_entry_escape(int value) { return (static_cast<uint32_t>(value) >> 10) & 0x3Fu; }
+JG_HD inline bool sym_needs_escape(int value) { return static_cast<uint32_t>(value + 512) > 1023u; }
 
 /// Decode from `st` up to bit `end_bit` of the segment, committing symbols that end at or before it.
 /// `st.n`, `st.dc01`, `st.dc23` accumulate (not with SpecSink). `tabs` is the scan's table pack (LDS on
@@ -289,7 +288,7 @@ JG_HD inline void decode_subsequence(
             /* the component's running sum is the absolute DC value, 16-bit wrap like the reference's   \
                int16 prefix sum (decode_dc.cu:129-155); an AC coefficient sits at zig-zag index z1 - 1 */ \
             const int absdc = static_cast<int>(((static_cast<uint64_t>(dc23) << 32) | dc01) >> sh);       \
-            sink.symbol(is_dc, s != 0, sym_entry(z1 - 1, is_dc ? absdc : v), du_end);                     \
+            sink.symbol(is_dc, s != 0, z1 - 1, is_dc ? absdc : v, du_end);                                \
         } else if (Sink::kSums && is_dc) {                                                                \
             const int s      = (e >> 5) & 15;                                                             \
             const int v      = extend_magnitude(bits_field(peek, total, s), s);                           \

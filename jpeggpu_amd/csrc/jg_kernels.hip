@@ -80,7 +80,7 @@ struct JobView {
     JG_GLOBAL int* tails_n;
     JG_GLOBAL uint32_t* tails_dc01;
     JG_GLOBAL uint32_t* tails_dc23;
-    JG_GLOBAL uint32_t* sym;
+    JG_GLOBAL uint16_t* sym;
     JG_GLOBAL uint2_t* du_tab;
     uint32_t sym_region;
     uint64_t sym_entries;
@@ -663,33 +663,31 @@ __global__ __launch_bounds__(T) void huff_seq_tails(JS js)
 // Huffman: write pass
 // ------------------------------------------------------------------------------------------------
 
-#ifndef JG_RING_ENTRIES
-#define JG_RING_ENTRIES 16
-#endif
-constexpr int kStageEntries = JG_RING_ENTRIES;   // entries of a lane's write-combining ring (a power of two)
-constexpr int kFlushEntries = kStageEntries / 2; // entries per flush: 8 = one 32-byte sector
+constexpr int kRingWords    = 16;                         // 32-bit words of a lane's write-combining ring: two entries each
+constexpr int kStageEntries = 2 * kRingWords;             // entries the ring holds (a power of two)
+constexpr int kFlushEntries = kSymSectorEntries;          // entries per flush: 16 = one 32-byte sector
+constexpr int kFlushPeriod  = 8;                          // iterations between two flush points
 
-/// Sink of the write pass: a compact symbol stream instead of a dense coefficient buffer. Every lane
-/// appends one 32-bit entry per non-zero coefficient (zig-zag position | value, DC already absolute)
-/// to its own region, contiguous per data unit, and records {first entry, count} per data unit when
-/// the unit completes. A lane owns whole data units (jg_huff_core.h, kWholeUnits), so a unit's entries
-/// never span two regions. Compared with scattered 2-byte stores into a pre-zeroed buffer (reference
+/// Sink of the write pass: a compact symbol stream instead of a dense coefficient buffer (jg_defs.h). Every lane
+/// appends 16-bit entries to its own region, contiguous per data unit, and records {first entry, count} per
+/// data unit when the unit completes. A lane owns whole data units (jg_huff_core.h, kWholeUnits), so a unit's
+/// entries never span two regions. Compared with scattered 2-byte stores into a pre-zeroed buffer (reference
 /// decode_huffman.cu:360-371 + decoder.cpp:256-263) this needs no zero-fill and writes each byte once.
 ///
-/// A lane's 4-byte appends must not go to memory one by one: with many images in flight the ~200 k
-/// open lines do not fit in L2 and every append becomes its own 32-byte sector write (measured: 122 MB
-/// of HBM writes per 12 MP image for a 20 MB stream). Entries are therefore collected in a 16-entry
-/// ring per lane in LDS ([slot][lane], conflict-free) and every 8 iterations ALL lanes flush whole
-/// 32-byte sectors together: at most 7 entries stay behind, at most 8 arrive in between.
+/// A lane's appends must not go to memory one by one: with many images in flight the ~200 k open lines do not fit
+/// in L2 and every append becomes its own 32-byte sector write. Entries are therefore collected in a ring per lane
+/// in LDS ([word][lane], conflict-free; 16 words = 32 entries) and every 8 iterations ALL lanes that have 16 or
+/// more waiting flush one whole 32-byte sector: an iteration adds at most two entries (a coefficient and its
+/// escape), so at most 15 stay behind and at most 16 arrive in between.
 struct StreamSink {
     static constexpr bool kWrite      = true;
     static constexpr bool kWholeUnits = true;
     static constexpr bool kSums       = true;
-    JG_GLOBAL uint32_t* sym;
+    JG_GLOBAL uint16_t* sym;
     JG_GLOBAL uint2_t* du_tab;
-    uint32_t* ring;     // &s_ring[lane]; slot k at ring[k * T]
+    uint32_t ring;      // LDS byte address of word 0 of the lane's ring; word k at ring + k * T * 4
     uint32_t base;      // physical index of the region's first entry (jg_defs.h, sym_region_base)
-    uint32_t flushed;   // entries of this lane already in memory (a multiple of 8), region-relative like the next three
+    uint32_t flushed;   // entries of this lane already in memory (a multiple of 16), region-relative like the next three
     uint32_t emitted;   // entries produced so far
     uint32_t cur_end;   // entries a region holds
     uint32_t du_off;
@@ -708,18 +706,31 @@ struct StreamSink {
     int pend_n;
     bool started; // false while the first symbols finish the predecessor's data unit
     __device__ __forceinline__ bool full() const { return du >= quota; }
-    /// One call per decoded symbol, branch-free. `entry` is the stream entry of a DC symbol (absolute
-    /// value, index 0) or of an AC symbol; zero AC coefficients, symbols that finish the predecessor's
+    /// 16-bit store into the lane's ring: entry n sits in half n & 1 of word (n / 2) % 16; `keep` false sends it to
+    /// the spare row behind the ring instead.
+    __device__ __forceinline__ void put(uint32_t n, uint32_t entry, bool keep)
+    {
+        typedef __attribute__((address_space(3))) uint16_t LdsHalf;
+        const uint32_t word = keep ? (n >> 1) & (kRingWords - 1) : static_cast<uint32_t>(kRingWords);
+        *reinterpret_cast<LdsHalf*>(static_cast<uintptr_t>(ring + word * (T * 4) + (n & 1u) * 2u)) = static_cast<uint16_t>(entry);
+    }
+    /// One call per decoded symbol. `value` is the absolute DC value of a DC symbol (zig-zag index 0) or the
+    /// coefficient of an AC symbol at index `zpos`; zero AC coefficients, symbols that finish the predecessor's
     /// unit, and anything past the region on a corrupt stream go to the spare ring row.
-    __device__ __forceinline__ void symbol(bool is_dc, bool nonzero, uint32_t entry, bool unit_end)
+    __device__ __forceinline__ void symbol(bool is_dc, bool nonzero, int zpos, int value, bool unit_end)
     {
         du_off = is_dc ? emitted : du_off;
         du += is_dc ? 1 : 0;
-        started             = started || is_dc;
-        const bool emit     = started && (is_dc || nonzero) && emitted < cur_end;
-        const uint32_t slot = emit ? (emitted & (kStageEntries - 1)) : kStageEntries;
-        ring[slot * T]      = entry;
+        started         = started || is_dc;
+        const bool emit = started && (is_dc || nonzero) && emitted < cur_end;
+        put(emitted, is_dc ? static_cast<uint32_t>(value) : sym_entry_ac(zpos, value), emit);
         emitted += emit ? 1u : 0u;
+        // a coefficient that does not fit 10 bits (no photograph has one) takes a second entry
+        if (__builtin_expect(emit && !is_dc && sym_needs_escape(value), 0)) {
+            const bool room = emitted < cur_end;
+            put(emitted, sym_entry_escape(value), room);
+            emitted += room ? 1u : 0u;
+        }
         // A unit takes at least two symbols, so at most four finish between two flush points (8 iterations); a
         // flush leaves at most three waiting: eight slots are enough.
         const bool done    = unit_end && started;
@@ -762,23 +773,24 @@ struct StreamSink {
         // only right after the lane's first, shorter store: at most three records stay behind)
         while (pend_n >= 4) store_units(4 - (rec_du & 3));
     }
-    /// kFlushEntries entries from the ring to memory; `flushed` is a multiple of kFlushEntries.
+    /// One sector (16 entries = 8 ring words) from the ring to memory; `flushed` is a multiple of 16.
     __device__ __forceinline__ void flush_sector()
     {
-        uint32_t e[kFlushEntries];
-        const uint32_t* r = ring + (flushed & (kStageEntries - 1)) * T; // no wrap inside a flush unit
+        typedef __attribute__((address_space(3))) uint32_t LdsWord;
+        uint32_t e[kFlushEntries / 2];
+        const uint32_t r = ring + ((flushed >> 1) & (kRingWords - 1)) * (T * 4); // no wrap inside a sector
 #pragma unroll
-        for (int k = 0; k < kFlushEntries; ++k) e[k] = r[k * T];
-        static_assert(kFlushEntries == 8, "a flush is one sector of the interleaved stream");
+        for (int k = 0; k < kFlushEntries / 2; ++k) e[k] = *reinterpret_cast<const LdsWord*>(static_cast<uintptr_t>(r + k * (T * 4)));
+        static_assert(kFlushEntries == 16, "a flush is one sector of the interleaved stream");
         JG_GLOBAL uint4* dst = reinterpret_cast<JG_GLOBAL uint4*>(sym + sym_at(base, flushed));
-#pragma unroll
-        for (int k = 0; k < kFlushEntries / 4; ++k) st_global(dst + k, make_uint4(e[4 * k], e[4 * k + 1], e[4 * k + 2], e[4 * k + 3]));
+        st_global(dst, make_uint4(e[0], e[1], e[2], e[3]));
+        st_global(dst + 1, make_uint4(e[4], e[5], e[6], e[7]));
         flushed += kFlushEntries;
     }
     __device__ __forceinline__ void tick()
     {
-        if ((++ticks & (kFlushEntries - 1)) == 0) { // the same iteration for every lane of the wave
-            if (emitted - flushed >= kFlushEntries) flush_sector();
+        if ((++ticks & (kFlushPeriod - 1)) == 0) { // the same iteration for every lane of the wave
+            if (emitted - flushed >= static_cast<uint32_t>(kFlushEntries)) flush_sector();
             flush_units();
         }
     }
@@ -824,7 +836,7 @@ __device__ __forceinline__ uint32_t pk_sub(uint32_t a, uint32_t b) { return pk_a
 struct WriteLds {
     static constexpr uint32_t kScan = 0;                                   // T + 1 + 4 + 3 words
     static constexpr uint32_t kRing = ((T + 8) * 4 + 15) / 16 * 16;
-    static constexpr uint32_t kTabs = kRing + (kStageEntries + 1) * T * 4; // + the spare row of StreamSink::push
+    static constexpr uint32_t kTabs = kRing + (kRingWords + 1) * T * 4; // + the spare row of StreamSink::put
     static_assert(kTabs % 16 == 0, "the table pack is read with 16-byte loads");
     static_assert(kStaticLdsSlack + kTabs + kMaxTablePack <= 65536, "absolute table addresses are packed into 16 bits (load_tables)");
 };
@@ -895,7 +907,7 @@ __global__ __launch_bounds__(T) void huff_write(JS js)
     StreamSink sink;
     sink.sym     = J.sym;
     sink.du_tab  = J.du_tab;
-    sink.ring    = s_ring + t;
+    sink.ring    = lds_address(s_ring + t);
     int nprefix  = 0;
     uint32_t pred01 = 0, pred23 = 0; // DC predictors at the lane's first symbol: sums over the segment so far
     {
@@ -1087,34 +1099,30 @@ __global__ __launch_bounds__(256) void idct_kernel(JS js)
     // table entries of all iterations (independent loads, one latency); a table entry that was never
     // written (corrupt stream) must not lead out of the buffer
     uint32_t toff[kIdctIters], tcnt[kIdctIters];
-    const uint64_t limit = J.sym_entries - 10 * kSymSectorStride; // a 64-entry gather from here stays inside
+    const uint64_t limit = J.sym_entries - 10 * kSymSectorStride; // a 128-entry gather from here stays inside
 #pragma unroll
     for (int it = 0; it < kIdctIters; ++it) {
         const int du = du0 + it * kIdctDuPerBlock + dl;
         uint2_t e{0u, 0u};
         if (du < num_du) e = ld_global(J.du_tab + du);
-        tcnt[it] = e.y < 64u ? e.y : 64u;
+        tcnt[it] = e.y < kMaxUnitEntries ? e.y : kMaxUnitEntries;
         toff[it] = static_cast<uint32_t>(e.x < limit ? e.x : limit);
     }
 #ifndef JG_IDCT_PREFETCH
 #define JG_IDCT_PREFETCH 4
 #endif
-
     constexpr int kAhead = JG_IDCT_PREFETCH; // entries per lane fetched one iteration ahead (8 lanes: kAhead * 8 per unit)
     uint32_t nx[kAhead];
-    // Entries r, r + 8, r + 16, ...: eight entries further is the same slot of the next sector. The loads stay
+    // Entries r, r + 8, r + 16, ...: sixteen entries further is the same slot of the next sector. The loads stay
     // predicated on the unit's entry count: fetching the sectors behind a unit's last entry without asking (no
     // compare, no branch) was measured 5 % slower -- this kernel waits for memory, not for instruction issue
     // (15 % fewer vector instructions from the geometry table bought 3 %).
-    // (scalar base + 32-bit byte offset + immediate: one address register for all of a unit's sectors)
-    const auto sym_at_bytes = [&](uint32_t byte_off) -> uint32_t {
-        return *reinterpret_cast<JG_GLOBAL const uint32_t*>(reinterpret_cast<JG_GLOBAL const uint8_t*>(J.sym) + byte_off);
+    // (scalar base + 32-bit byte offset: one address computation per entry, no 64-bit arithmetic)
+    const auto entry_at = [&](uint32_t index) -> uint32_t {
+        return *reinterpret_cast<JG_GLOBAL const uint16_t*>(reinterpret_cast<JG_GLOBAL const uint8_t*>(J.sym) + index * 2u);
     };
-    {
-        const uint32_t p0 = sym_advance(toff[0], r) * 4u;
 #pragma unroll
-        for (int k = 0; k < kAhead; ++k) nx[k] = r + 8 * k < tcnt[0] ? sym_at_bytes(p0 + k * kSymSectorStride * 4u) : 0u;
-    }
+    for (int k = 0; k < kAhead; ++k) nx[k] = r + 8 * k < tcnt[0] ? entry_at(sym_advance(toff[0], r + 8 * k)) : 0u;
 
 #pragma unroll
     for (int it = 0; it < kIdctIters; ++it) {
@@ -1122,9 +1130,8 @@ __global__ __launch_bounds__(256) void idct_kernel(JS js)
 #pragma unroll
         for (int k = 0; k < kAhead; ++k) ex[k] = nx[k];
         if (it + 1 < kIdctIters) { // next iteration's first entries are in flight while this one computes
-            const uint32_t p0 = sym_advance(toff[it + 1], r) * 4u;
 #pragma unroll
-            for (int k = 0; k < kAhead; ++k) nx[k] = r + 8 * k < tcnt[it + 1] ? sym_at_bytes(p0 + k * kSymSectorStride * 4u) : 0u;
+            for (int k = 0; k < kAhead; ++k) nx[k] = r + 8 * k < tcnt[it + 1] ? entry_at(sym_advance(toff[it + 1], r + 8 * k)) : 0u;
         }
         // The 8 lanes of a data unit sit in one wave and LDS executes a wave's instructions in order,
         // so the phases below need no workgroup barrier among themselves; only the pixel re-mapping
@@ -1132,16 +1139,54 @@ __global__ __launch_bounds__(256) void idct_kernel(JS js)
         *reinterpret_cast<uint4*>(blk + r * 8) = make_uint4(0, 0, 0, 0);
 
         const uint32_t* zq = s_zq + ((s_geo[it * kIdctDuPerBlock + dl].vis >> 8) & 3u) * 64;
-        const auto put = [&](uint32_t v) {
-            const uint32_t e = zq[(v >> 16) & 63];
-            const int c      = static_cast<int16_t>(v & 0xFFFFu);
-            *reinterpret_cast<int16_t*>(blk_bytes + (e & 0xFFu)) = static_cast<int16_t>(c * static_cast<int>(e >> 16));
+        // dequantise and place one coefficient: zig-zag index, value (its low 16 bits count, reference idct.cu:178-180)
+        const auto put = [&](uint32_t zz, uint32_t value) {
+            const uint32_t e = zq[zz];
+            *reinterpret_cast<int16_t*>(blk_bytes + (e & 0xFFu)) = static_cast<int16_t>(value * (e >> 16));
         };
         const uint32_t cnt = tcnt[it];
+        // Entry j of the unit (jg_defs.h): j == 0 is the DC value; an AC entry holds index << 10 | low 10 bits of the
+        // value; an entry with index 0 behind one is the ESCAPE that carries the value's high bits. No photograph
+        // has one, so the wave first asks whether any of its lanes holds an escape at all.
+        bool have_escape = false;
 #pragma unroll
-        for (int k = 0; k < kAhead; ++k)
-            if (r + 8 * k < cnt) put(ex[k]);
-        for (uint32_t i = r + 8 * kAhead; i < cnt; i += 8) put(J.sym[sym_advance(toff[it], i)]); // dense units only
+        for (int k = 0; k < kAhead; ++k) have_escape |= r + 8 * k < cnt && r + 8 * k > 0 && (ex[k] >> 10) == 0;
+        if (__builtin_expect(__ballot(have_escape) == 0, 1)) {
+#pragma unroll
+            for (int k = 0; k < kAhead; ++k) {
+                if (r + 8 * k < cnt) {
+                    const uint32_t e = ex[k];
+                    if (k == 0 && r == 0) put(0, e);
+                    else put(e >> 10, static_cast<uint32_t>(static_cast<int32_t>(e << 22) >> 22));
+                }
+            }
+        } else {
+            // the entry behind a lane's own: the right neighbour's of the same round, or, for the last lane of the
+            // unit, the first lane's of the next round (row_shl:1 / row_shr:7 stay inside a row of 16 lanes)
+#pragma unroll
+            for (int k = 0; k < kAhead; ++k) {
+                const uint32_t right = static_cast<uint32_t>(__builtin_amdgcn_update_dpp(0, static_cast<int>(ex[k]), 0x101, 0xF, 0xF, false));
+                uint32_t wrap        = 1u << 10; // behind the last prefetched entry: looked up below
+                if (k + 1 < kAhead) wrap = static_cast<uint32_t>(__builtin_amdgcn_update_dpp(0, static_cast<int>(ex[k + 1]), 0x117, 0xF, 0xF, false));
+                uint32_t next = r == 7 ? wrap : right;
+                const uint32_t j = r + 8 * k;
+                if (k + 1 == kAhead && r == 7 && j + 1 < cnt) next = entry_at(sym_advance(toff[it], j + 1));
+                if (j + 1 >= cnt) next = 1u << 10; // nothing behind the unit's last entry
+                if (j < cnt) {
+                    const uint32_t e = ex[k];
+                    if (j == 0) put(0, e);
+                    else if ((e >> 10) != 0) {
+                        const bool esc = (next >> 10) == 0;
+                        put(e >> 10, esc ? (next << 10) | (e & 0x3FFu) : static_cast<uint32_t>(static_cast<int32_t>(e << 22) >> 22));
+                    }
+                }
+            }
+        }
+        for (uint32_t i = r + 8 * kAhead; i < cnt; i += 8) { // dense units only
+            const uint32_t e    = entry_at(sym_advance(toff[it], i));
+            const uint32_t next = i + 1 < cnt ? entry_at(sym_advance(toff[it], i + 1)) : 1u << 10;
+            if ((e >> 10) != 0) put(e >> 10, (next >> 10) == 0 ? (next << 10) | (e & 0x3FFu) : static_cast<uint32_t>(static_cast<int32_t>(e << 22) >> 22));
+        }
         __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
         int v[8];
         unpack8(*reinterpret_cast<const uint4*>(blk + r * 8), v); // column r

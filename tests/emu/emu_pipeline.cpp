@@ -31,27 +31,30 @@ struct HostFetch {
     uint32_t cook(uint32_t v, const Pos&) const { return v; }
 };
 
-/// Host twin of the write pass's sink (StreamSink in jg_kernels.hip): symbol stream + data-unit table.
+/// Host twin of the write pass's sink (StreamSink in jg_kernels.hip): symbol stream (jg_defs.h: 16-bit entries,
+/// escapes behind coefficients that do not fit 10 bits) + data-unit table.
 struct HostSink {
     static constexpr bool kWrite      = true;
     static constexpr bool kWholeUnits = true;
     static constexpr bool kSums       = true;
-    uint32_t* sym;
+    uint16_t* sym;
     uint2_t* du_tab;
     uint32_t cur, cur_end, du_off;
     int du_index;
     int du, quota; // next data unit to start, first data unit past the segment
     bool started;
     bool full() const { return du >= quota; }
-    /// `entry` of a DC symbol (absolute value, index 0) or of an AC symbol (zero coefficients emit nothing)
-    void symbol(bool is_dc, bool nonzero, uint32_t entry, bool unit_end)
+    void symbol(bool is_dc, bool nonzero, int zpos, int value, bool unit_end)
     {
         if (is_dc) {
             started  = true;
             du_off   = cur;
             du_index = du++;
         }
-        if ((is_dc || (started && nonzero)) && cur < cur_end) sym[cur++] = entry;
+        if ((is_dc || (started && nonzero)) && cur < cur_end) {
+            sym[cur++] = static_cast<uint16_t>(is_dc ? static_cast<uint32_t>(value) : sym_entry_ac(zpos, value));
+            if (!is_dc && sym_needs_escape(value) && cur < cur_end) sym[cur++] = static_cast<uint16_t>(sym_entry_escape(value));
+        }
         if (unit_end && started) du_tab[du_index] = uint2_t{du_off, cur - du_off};
     }
     void tick() {}
@@ -306,7 +309,7 @@ int emu_decode_scan(
 
     // ---- write pass (huff_write): symbol stream + data-unit table, then gather like the IDCT does ----
     const uint32_t region = sym_region_entries(subseq_bytes);
-    std::vector<uint32_t> sym(static_cast<size_t>(S) * region, 0xDEADBEEFu);
+    std::vector<uint16_t> sym(static_cast<size_t>(S) * region, 0xDEADu);
     std::vector<uint2_t> du_tab(sc.num_du, uint2_t{0xFFFFFFFFu, 0xFFFFFFFFu});
     for (int b = 0; b < num_seq; ++b) {
         const int first = b * T, nsub = std::min(T, S - first);
@@ -366,10 +369,15 @@ int emu_decode_scan(
         std::memset(coef, 0, static_cast<size_t>(sc.num_du) * 128);
         for (int d = 0; d < sc.num_du; ++d) {
             const uint2_t e = du_tab[d];
-            if (e.y > 64 || static_cast<size_t>(e.x) + e.y > sym.size()) return JPEGGPU_INTERNAL_ERROR; // table entry never written
-            for (uint32_t k = 0; k < e.y; ++k) {
+            if (e.y > kMaxUnitEntries || e.y < 1 || static_cast<size_t>(e.x) + e.y > sym.size()) return JPEGGPU_INTERNAL_ERROR; // table entry never written
+            coef[static_cast<size_t>(d) * 64] = static_cast<int16_t>(sym[e.x]); // the first entry is the DC value
+            for (uint32_t k = 1; k < e.y; ++k) {
                 const uint32_t v = sym[e.x + k];
-                coef[static_cast<size_t>(d) * 64 + nat[(v >> 16) & 63]] = static_cast<int16_t>(v & 0xFFFF);
+                if ((v >> 10) == 0) continue; // an escape: taken with the entry in front of it
+                const uint32_t nx = k + 1 < e.y ? sym[e.x + k + 1] : 1u << 10;
+                const int16_t val = (nx >> 10) == 0 ? static_cast<int16_t>((nx << 10) | (v & 0x3FFu))
+                                                    : static_cast<int16_t>(static_cast<int32_t>(v << 22) >> 22);
+                coef[static_cast<size_t>(d) * 64 + nat[v >> 10]] = val;
             }
         }
     }
