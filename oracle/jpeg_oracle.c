@@ -18,14 +18,17 @@
  * non-interleaved scans have one data unit per MCU, B-3 quantiser values are unsigned unless
  * JO_QUIRK_SIGNED_Q is passed).
  *
- * Pinning: the reference cannot be built in this environment (it needs nvcc and the CUDA runtime
+ * Pinning: the reference as a whole cannot be built in this environment (it needs nvcc and the CUDA runtime
  * headers), and its own tests hold no golden outputs. This oracle is pinned by
+ *   (0) the IDCT below == the reference's OWN idct_vector / idct_col / idct_row (src/idct.cu:43-144, compiled from
+ *       the reference's source by line range, oracle/ref_lift/build.sh) on 4 672 vectors and 6 144 blocks:
+ *       tests/golden/idct_kats.npz, tests/test_idct_kats.py,
  *   (1) quantised coefficients == IJG libjpeg 9d jpeg_read_coefficients on every fixture,
  *   (2) planes within the accuracy band the reference's README states against a standard decoder
  *       (README.md:76,81: MSE 0.15-0.23) -- checked as MSE <= 0.25, max |diff| <= 2 vs libjpeg islow,
  *   (3) the launch shape the reference's README prints for its bundled photo (README.md:37-38:
  *       89 sequences of 256 subsequences of 128 bytes),
- * recorded in tests/golden/ by oracle/pin/make_golden.py.
+ * recorded in tests/golden/ by oracle/pin/make_golden.py and oracle/ref_lift/make_idct_kats.py.
  *
  * Build: gcc -O2 -fwrapv -shared -fPIC (see oracle/Makefile). -fwrapv: the reference's GPU integer
  * arithmetic wraps; signed overflow must not be undefined here.
