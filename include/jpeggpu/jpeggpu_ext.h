@@ -56,14 +56,14 @@ struct jpeggpu_ext_scan_layout {
                                   components 0 (low half) and 1 (high half) */
     size_t off_state_dc23;     /* same for scan components 2 and 3 */
     size_t off_symbols;        /* uint16 entries, contiguous per data unit: the unit's DC value (absolute) first, then
-                                  one entry per non-zero AC coefficient, zig-zag index << 10 | value & 0x3FF (value in
+                                  one entry per non-zero AC coefficient, value << 6 | zig-zag index (value in
                                   -512..511); a coefficient outside that range is followed by an escape entry with
-                                  index 0 holding value >> 10. Logically one region of symbol_region_entries per
+                                  index 0 holding value >> 10 in its high bits. Logically one region of symbol_region_entries per
                                   subsequence; physically the regions of 64 consecutive subsequences are interleaved
                                   in sectors of 16 entries: sector j of subsequence s starts at entry
                                   ((s / 64) * (symbol_region_entries / 16) + j) * 1024 + (s % 64) * 16 */
-    size_t off_du_table;       /* {uint32 physical index of the first entry, uint32 count}[num_data_units], stream
-                                  order; entry k of a unit: w = (first & 15) + k -> (first & ~15) + (w >> 4) * 1024 + (w & 15) */
+    size_t off_du_table;       /* {uint32 physical index of the first entry, uint32 count (| 128 if the unit holds an
+                                  escape)}[num_data_units], stream order; entry k of a unit: w = (first & 15) + k -> (first & ~15) + (w >> 4) * 1024 + (w & 15) */
     int symbol_region_entries;
     /* jpeggpu_ext_set_device_scan: num_subsequences / num_segments / num_chunks above are then capacities from the
      * header; the real counts are uint32 words 1.. at off_device_status (status, subsequences, segments, chunks,

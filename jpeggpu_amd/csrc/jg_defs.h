@@ -152,10 +152,11 @@ JG_HD inline uint64_t tiled_buffer_bytes(uint32_t num_subseq, int subseq_bytes, 
 
 /// The SYMBOL STREAM the write pass emits and the IDCT gathers: 16-bit entries, contiguous per data unit.
 ///   * a unit's FIRST entry is its DC coefficient, absolute (the predictor is already added), 16 bits;
-///   * every other entry is a non-zero AC coefficient: zig-zag index (1..63) << 10 | value & 0x3FF, value in
-///     -512..511 as a 10-bit two's complement number;
+///   * every other entry is a non-zero AC coefficient: value << 6 | zig-zag index (1..63), value in -512..511 as a
+///     10-bit two's complement number in the high bits;
 ///   * an AC coefficient outside that range (magnitude category 10 and above: quantisers of 1 at best) is followed by an
-///     ESCAPE entry, zig-zag field 0: its low bits are value >> 10, so value = int16(escape << 10 | low 10 bits).
+///     ESCAPE entry, index field 0, whose high bits are value >> 10: value = int16((escape >> 6) << 10 | entry >> 6).
+///     The count of a unit that holds an escape has bit 7 set in the data-unit table (a count is at most 127).
 /// Half the bytes of a 32-bit entry (index << 16 | value) -- the stream is most of what the write pass stores and the
 /// IDCT fetches: with every other sector left out (timing only) the write pass ran 15 % and a batch 11 % faster.
 ///

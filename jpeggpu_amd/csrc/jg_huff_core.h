@@ -204,10 +204,17 @@ struct SpecSink : NoSink {
 };
 
 /// Entries of the symbol stream the write pass emits (jg_defs.h): the AC entry of a coefficient at zig-zag index
-/// `zpos` (the low 10 bits of its value), and the escape entry that follows it if the value does not fit them.
-JG_HD inline uint32_t sym_entry_ac(int zpos, int value) { return (static_cast<uint32_t>(zpos) << 10) | (static_cast<uint32_t>(value) & 0x3FFu); }
-JG_HD inline uint32_t sym_entry_escape(int value) { return (static_cast<uint32_t>(value) >> 10) & 0x3Fu; }
+/// `zpos` (value in the high 10 bits, index in the low 6: the store keeps 16 bits, so no mask is needed), the escape
+/// entry that follows it if the value does not fit (index 0, the value's bits 10.. in the high bits), and the two
+/// ways back.
+JG_HD inline uint32_t sym_entry_ac(int zpos, int value) { return (static_cast<uint32_t>(value) << 6) | static_cast<uint32_t>(zpos); }
+JG_HD inline uint32_t sym_entry_escape(int value) { return (static_cast<uint32_t>(value) >> 10) << 6; }
 JG_HD inline bool sym_needs_escape(int value) { return static_cast<uint32_t>(value + 512) > 1023u; }
+JG_HD inline uint32_t sym_entry_index(uint32_t e) { return e & 63u; }
+JG_HD inline int sym_entry_value(uint32_t e) { return static_cast<int16_t>(e) >> 6; }
+JG_HD inline int sym_entry_value(uint32_t e, uint32_t escape) { return static_cast<int16_t>(((escape >> 6) << 10) | ((e & 0xFFFFu) >> 6)); }
+/// Bit of a data-unit record's count that says "this unit holds an escape" (a count is at most 127).
+constexpr uint32_t kUnitHasEscape = 0x80u;
 
 /// Decode from `st` up to bit `end_bit` of the segment, committing symbols that end at or before it.
 /// `st.n`, `st.dc01`, `st.dc23` accumulate (not with SpecSink). `tabs` is the scan's table pack (LDS on

@@ -704,14 +704,16 @@ struct StreamSink {
     int rec_du;         // its index in the data-unit table
     uint32_t pend_lo, pend_hi; // counts of waiting units 0..3 and 4..7
     int pend_n;
+    uint32_t unit_esc; // kUnitHasEscape once the unit being decoded has taken an escape entry
     bool started; // false while the first symbols finish the predecessor's data unit
     __device__ __forceinline__ bool full() const { return du >= quota; }
-    /// 16-bit store into the lane's ring: entry n sits in half n & 1 of word (n / 2) % 16; `keep` false sends it to
-    /// the spare row behind the ring instead.
-    __device__ __forceinline__ void put(uint32_t n, uint32_t entry, bool keep)
+    /// 16-bit store into the lane's ring: entry n sits in half n & 1 of word (n / 2) % 16. A lane that has nothing
+    /// to keep stores all the same, into the slot its next kept entry will overwrite (at most 31 entries wait, so
+    /// slot n is free): no select, no spare row.
+    __device__ __forceinline__ void put(uint32_t n, uint32_t entry)
     {
         typedef __attribute__((address_space(3))) uint16_t LdsHalf;
-        const uint32_t word = keep ? (n >> 1) & (kRingWords - 1) : static_cast<uint32_t>(kRingWords);
+        const uint32_t word = (n >> 1) & (kRingWords - 1);
         *reinterpret_cast<LdsHalf*>(static_cast<uintptr_t>(ring + word * (T * 4) + (n & 1u) * 2u)) = static_cast<uint16_t>(entry);
     }
     /// One call per decoded symbol. `value` is the absolute DC value of a DC symbol (zig-zag index 0) or the
@@ -719,22 +721,23 @@ struct StreamSink {
     /// unit, and anything past the region on a corrupt stream go to the spare ring row.
     __device__ __forceinline__ void symbol(bool is_dc, bool nonzero, int zpos, int value, bool unit_end)
     {
-        du_off = is_dc ? emitted : du_off;
+        du_off   = is_dc ? emitted : du_off;
+        unit_esc = is_dc ? 0u : unit_esc;
         du += is_dc ? 1 : 0;
         started         = started || is_dc;
         const bool emit = started && (is_dc || nonzero) && emitted < cur_end;
-        put(emitted, is_dc ? static_cast<uint32_t>(value) : sym_entry_ac(zpos, value), emit);
+        put(emitted, is_dc ? static_cast<uint32_t>(value) : sym_entry_ac(zpos, value));
         emitted += emit ? 1u : 0u;
         // a coefficient that does not fit 10 bits (no photograph has one) takes a second entry
         if (__builtin_expect(emit && !is_dc && sym_needs_escape(value), 0)) {
-            const bool room = emitted < cur_end;
-            put(emitted, sym_entry_escape(value), room);
-            emitted += room ? 1u : 0u;
+            put(emitted, sym_entry_escape(value));
+            emitted += emitted < cur_end ? 1u : 0u;
+            unit_esc = kUnitHasEscape;
         }
         // A unit takes at least two symbols, so at most four finish between two flush points (8 iterations); a
         // flush leaves at most three waiting: eight slots are enough.
         const bool done    = unit_end && started;
-        const uint32_t cnt = (emitted - du_off) << (8 * (pend_n & 3));
+        const uint32_t cnt = ((emitted - du_off) | unit_esc) << (8 * (pend_n & 3));
         pend_lo |= done && pend_n < 4 ? cnt : 0u;
         pend_hi |= done && pend_n >= 4 ? cnt : 0u;
         pend_n += done ? 1 : 0;
@@ -746,9 +749,9 @@ struct StreamSink {
         uint32_t off = rec_off;
 #pragma unroll
         for (int k = 0; k < 4; ++k) {
-            const uint32_t cnt = (pend_lo >> (8 * k)) & 0xFFu;
+            const uint32_t cnt = (pend_lo >> (8 * k)) & 0xFFu; // entries | kUnitHasEscape
             rec[k]             = uint2_t{sym_at(base, off), cnt};
-            off += k < n ? cnt : 0u;
+            off += k < n ? cnt & 0x7Fu : 0u;
         }
         JG_GLOBAL uint2_t* dst = du_tab + rec_du;
         if (n == 4 && (rec_du & 3) == 0) { // a whole, aligned sector of the table
@@ -836,7 +839,7 @@ __device__ __forceinline__ uint32_t pk_sub(uint32_t a, uint32_t b) { return pk_a
 struct WriteLds {
     static constexpr uint32_t kScan = 0;                                   // T + 1 + 4 + 3 words
     static constexpr uint32_t kRing = ((T + 8) * 4 + 15) / 16 * 16;
-    static constexpr uint32_t kTabs = kRing + (kRingWords + 1) * T * 4; // + the spare row of StreamSink::put
+    static constexpr uint32_t kTabs = kRing + kRingWords * T * 4;
     static_assert(kTabs % 16 == 0, "the table pack is read with 16-byte loads");
     static_assert(kStaticLdsSlack + kTabs + kMaxTablePack <= 65536, "absolute table addresses are packed into 16 bits (load_tables)");
 };
@@ -937,6 +940,7 @@ __global__ __launch_bounds__(T) void huff_write(JS js)
     sink.pend_lo        = 0;
     sink.pend_hi        = 0;
     sink.pend_n         = 0;
+    sink.unit_esc       = 0;
 
     LaneState st{};
     st.dc01 = pred01;
@@ -1105,7 +1109,7 @@ __global__ __launch_bounds__(256) void idct_kernel(JS js)
         const int du = du0 + it * kIdctDuPerBlock + dl;
         uint2_t e{0u, 0u};
         if (du < num_du) e = ld_global(J.du_tab + du);
-        tcnt[it] = e.y < kMaxUnitEntries ? e.y : kMaxUnitEntries;
+        tcnt[it] = e.y & 0xFFu; // entries (at most 127) | kUnitHasEscape
         toff[it] = static_cast<uint32_t>(e.x < limit ? e.x : limit);
     }
 #ifndef JG_IDCT_PREFETCH
@@ -1121,18 +1125,26 @@ __global__ __launch_bounds__(256) void idct_kernel(JS js)
     const auto entry_at = [&](uint32_t index) -> uint32_t {
         return *reinterpret_cast<JG_GLOBAL const uint16_t*>(reinterpret_cast<JG_GLOBAL const uint8_t*>(J.sym) + index * 2u);
     };
+    // entries r, r + 8, r + 16, r + 24 of a unit: 8 further is the same sector or, from the upper half of one, the
+    // lower half of the next
+    const auto prefetch = [&](uint32_t first, uint32_t cnt, uint32_t (&out)[kAhead]) {
+        uint32_t w   = (first & (kSymSectorEntries - 1u)) + static_cast<uint32_t>(r);
+        uint32_t idx = (first & ~(kSymSectorEntries - 1u)) + (w >> 4) * kSymSectorStride + (w & 15u);
 #pragma unroll
-    for (int k = 0; k < kAhead; ++k) nx[k] = r + 8 * k < tcnt[0] ? entry_at(sym_advance(toff[0], r + 8 * k)) : 0u;
+        for (int k = 0; k < kAhead; ++k) {
+            out[k] = static_cast<uint32_t>(r + 8 * k) < cnt ? entry_at(idx) : 0u;
+            idx += 8u + (w & 8u) * ((kSymSectorStride - kSymSectorEntries) / 8u);
+            w += 8u;
+        }
+    };
+    prefetch(toff[0], tcnt[0] & 0x7Fu, nx);
 
 #pragma unroll
     for (int it = 0; it < kIdctIters; ++it) {
         uint32_t ex[kAhead];
 #pragma unroll
         for (int k = 0; k < kAhead; ++k) ex[k] = nx[k];
-        if (it + 1 < kIdctIters) { // next iteration's first entries are in flight while this one computes
-#pragma unroll
-            for (int k = 0; k < kAhead; ++k) nx[k] = r + 8 * k < tcnt[it + 1] ? entry_at(sym_advance(toff[it + 1], r + 8 * k)) : 0u;
-        }
+        if (it + 1 < kIdctIters) prefetch(toff[it + 1], tcnt[it + 1] & 0x7Fu, nx); // in flight while this one computes
         // The 8 lanes of a data unit sit in one wave and LDS executes a wave's instructions in order,
         // so the phases below need no workgroup barrier among themselves; only the pixel re-mapping
         // at the end crosses waves (one barrier per iteration, buffers alternate).
@@ -1144,20 +1156,17 @@ __global__ __launch_bounds__(256) void idct_kernel(JS js)
             const uint32_t e = zq[zz];
             *reinterpret_cast<int16_t*>(blk_bytes + (e & 0xFFu)) = static_cast<int16_t>(value * (e >> 16));
         };
-        const uint32_t cnt = tcnt[it];
-        // Entry j of the unit (jg_defs.h): j == 0 is the DC value; an AC entry holds index << 10 | low 10 bits of the
-        // value; an entry with index 0 behind one is the ESCAPE that carries the value's high bits. No photograph
-        // has one, so the wave first asks whether any of its lanes holds an escape at all.
-        bool have_escape = false;
-#pragma unroll
-        for (int k = 0; k < kAhead; ++k) have_escape |= r + 8 * k < cnt && r + 8 * k > 0 && (ex[k] >> 10) == 0;
-        if (__builtin_expect(__ballot(have_escape) == 0, 1)) {
+        const uint32_t cnt = tcnt[it] & 0x7Fu;
+        // Entry j of the unit (jg_defs.h): j == 0 is the DC value; an AC entry holds value << 6 | index; an entry
+        // with index 0 behind one is the ESCAPE that carries the value's high bits. The unit's record says whether it
+        // holds one (no photograph does): the wave asks once.
+        if (__builtin_expect(__ballot((tcnt[it] & kUnitHasEscape) != 0) == 0, 1)) {
 #pragma unroll
             for (int k = 0; k < kAhead; ++k) {
-                if (r + 8 * k < cnt) {
+                if (static_cast<uint32_t>(r + 8 * k) < cnt) {
                     const uint32_t e = ex[k];
                     if (k == 0 && r == 0) put(0, e);
-                    else put(e >> 10, static_cast<uint32_t>(static_cast<int32_t>(e << 22) >> 22));
+                    else put(sym_entry_index(e), static_cast<uint32_t>(sym_entry_value(e)));
                 }
             }
         } else {
@@ -1166,26 +1175,25 @@ __global__ __launch_bounds__(256) void idct_kernel(JS js)
 #pragma unroll
             for (int k = 0; k < kAhead; ++k) {
                 const uint32_t right = static_cast<uint32_t>(__builtin_amdgcn_update_dpp(0, static_cast<int>(ex[k]), 0x101, 0xF, 0xF, false));
-                uint32_t wrap        = 1u << 10; // behind the last prefetched entry: looked up below
+                uint32_t wrap        = 1u; // behind the last prefetched entry: looked up below
                 if (k + 1 < kAhead) wrap = static_cast<uint32_t>(__builtin_amdgcn_update_dpp(0, static_cast<int>(ex[k + 1]), 0x117, 0xF, 0xF, false));
                 uint32_t next = r == 7 ? wrap : right;
                 const uint32_t j = r + 8 * k;
                 if (k + 1 == kAhead && r == 7 && j + 1 < cnt) next = entry_at(sym_advance(toff[it], j + 1));
-                if (j + 1 >= cnt) next = 1u << 10; // nothing behind the unit's last entry
+                if (j + 1 >= cnt) next = 1u; // nothing behind the unit's last entry
                 if (j < cnt) {
                     const uint32_t e = ex[k];
                     if (j == 0) put(0, e);
-                    else if ((e >> 10) != 0) {
-                        const bool esc = (next >> 10) == 0;
-                        put(e >> 10, esc ? (next << 10) | (e & 0x3FFu) : static_cast<uint32_t>(static_cast<int32_t>(e << 22) >> 22));
-                    }
+                    else if (sym_entry_index(e) != 0)
+                        put(sym_entry_index(e), static_cast<uint32_t>(sym_entry_index(next) == 0 ? sym_entry_value(e, next) : sym_entry_value(e)));
                 }
             }
         }
         for (uint32_t i = r + 8 * kAhead; i < cnt; i += 8) { // dense units only
             const uint32_t e    = entry_at(sym_advance(toff[it], i));
-            const uint32_t next = i + 1 < cnt ? entry_at(sym_advance(toff[it], i + 1)) : 1u << 10;
-            if ((e >> 10) != 0) put(e >> 10, (next >> 10) == 0 ? (next << 10) | (e & 0x3FFu) : static_cast<uint32_t>(static_cast<int32_t>(e << 22) >> 22));
+            const uint32_t next = i + 1 < cnt ? entry_at(sym_advance(toff[it], i + 1)) : 1u;
+            if (sym_entry_index(e) != 0)
+                put(sym_entry_index(e), static_cast<uint32_t>(sym_entry_index(next) == 0 ? sym_entry_value(e, next) : sym_entry_value(e)));
         }
         __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
         int v[8];

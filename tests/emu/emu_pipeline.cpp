@@ -43,6 +43,7 @@ struct HostSink {
     int du_index;
     int du, quota; // next data unit to start, first data unit past the segment
     bool started;
+    uint32_t unit_esc = 0;
     bool full() const { return du >= quota; }
     void symbol(bool is_dc, bool nonzero, int zpos, int value, bool unit_end)
     {
@@ -50,12 +51,16 @@ struct HostSink {
             started  = true;
             du_off   = cur;
             du_index = du++;
+            unit_esc = 0;
         }
         if ((is_dc || (started && nonzero)) && cur < cur_end) {
             sym[cur++] = static_cast<uint16_t>(is_dc ? static_cast<uint32_t>(value) : sym_entry_ac(zpos, value));
-            if (!is_dc && sym_needs_escape(value) && cur < cur_end) sym[cur++] = static_cast<uint16_t>(sym_entry_escape(value));
+            if (!is_dc && sym_needs_escape(value)) {
+                if (cur < cur_end) sym[cur++] = static_cast<uint16_t>(sym_entry_escape(value));
+                unit_esc = kUnitHasEscape;
+            }
         }
-        if (unit_end && started) du_tab[du_index] = uint2_t{du_off, cur - du_off};
+        if (unit_end && started) du_tab[du_index] = uint2_t{du_off, (cur - du_off) | unit_esc};
     }
     void tick() {}
 };
@@ -369,16 +374,19 @@ int emu_decode_scan(
         std::memset(coef, 0, static_cast<size_t>(sc.num_du) * 128);
         for (int d = 0; d < sc.num_du; ++d) {
             const uint2_t e = du_tab[d];
-            if (e.y > kMaxUnitEntries || e.y < 1 || static_cast<size_t>(e.x) + e.y > sym.size()) return JPEGGPU_INTERNAL_ERROR; // table entry never written
+            const uint32_t n = e.y & 0x7Fu;
+            if (e.y > 0xFFu || n < 1 || static_cast<size_t>(e.x) + n > sym.size()) return JPEGGPU_INTERNAL_ERROR; // table entry never written
             coef[static_cast<size_t>(d) * 64] = static_cast<int16_t>(sym[e.x]); // the first entry is the DC value
-            for (uint32_t k = 1; k < e.y; ++k) {
+            bool escaped = false;
+            for (uint32_t k = 1; k < n; ++k) {
                 const uint32_t v = sym[e.x + k];
-                if ((v >> 10) == 0) continue; // an escape: taken with the entry in front of it
-                const uint32_t nx = k + 1 < e.y ? sym[e.x + k + 1] : 1u << 10;
-                const int16_t val = (nx >> 10) == 0 ? static_cast<int16_t>((nx << 10) | (v & 0x3FFu))
-                                                    : static_cast<int16_t>(static_cast<int32_t>(v << 22) >> 22);
-                coef[static_cast<size_t>(d) * 64 + nat[v >> 10]] = val;
+                if (sym_entry_index(v) == 0) continue; // an escape: taken with the entry in front of it
+                const uint32_t nx = k + 1 < n ? sym[e.x + k + 1] : 1u;
+                const bool esc    = sym_entry_index(nx) == 0;
+                escaped |= esc;
+                coef[static_cast<size_t>(d) * 64 + nat[sym_entry_index(v)]] = static_cast<int16_t>(esc ? sym_entry_value(v, nx) : sym_entry_value(v));
             }
+            if (escaped != ((e.y & kUnitHasEscape) != 0)) return JPEGGPU_INTERNAL_ERROR; // the record's flag says what the entries hold
         }
     }
 

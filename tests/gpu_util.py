@@ -15,17 +15,17 @@ def tmp_view(torch, tmp, base, off, count, dtype):
 def stream_coefficients(torch, tmp, base, sl, num_subseq=None):
     """Dense stream-order coefficients int16 [num_data_units, 64] (natural order, DC absolute) rebuilt from what
     the write pass leaves in d_tmp: the symbol stream (16-bit entries; regions of 64 subsequences interleaved in
-    sectors of 16 entries, jpeggpu_ext.h) and the data-unit table {physical index of the first entry, count}. A
-    unit's first entry is its DC value; an AC entry is zig-zag index << 10 | low 10 bits of the value; an entry with
-    index 0 behind one is an escape carrying value >> 10."""
+    sectors of 16 entries, jpeggpu_ext.h) and the data-unit table {physical index of the first entry, count | 128 if
+    the unit holds an escape}. A unit's first entry is its DC value; an AC entry is value << 6 | zig-zag index (10-bit
+    value); an entry with index 0 behind one is an escape carrying value >> 10 in its high bits."""
     S = sl.num_subsequences if num_subseq is None else num_subseq
     ND = sl.num_data_units
     nsym = ((S + 63) // 64) * (sl.symbol_region_entries // 16) * 1024
     sym = tmp_view(torch, tmp, base, sl.off_symbols, nsym, torch.int16).view(np.uint16).astype(np.uint32)
     tab = tmp_view(torch, tmp, base, sl.off_du_table, ND * 2, torch.int32).view(np.uint32).reshape(ND, 2)
-    assert tab[:, 1].max() <= 127 and tab[:, 1].min() >= 1
+    assert tab[:, 1].max() <= 255 and (tab[:, 1] & 127).min() >= 1
     coef = np.zeros((ND, 64), np.int16)
-    cnt = tab[:, 1].astype(np.int64)
+    cnt = (tab[:, 1] & 127).astype(np.int64)
     du = np.repeat(np.arange(ND), cnt)
     k = np.arange(len(du), dtype=np.int64) - np.repeat(np.cumsum(cnt) - cnt, cnt)  # index of the entry in its unit
     first = np.repeat(tab[:, 0].astype(np.int64), cnt)
@@ -33,7 +33,7 @@ def stream_coefficients(torch, tmp, base, sl, num_subseq=None):
     idx = (first & ~15) + (w >> 4) * 1024 + (w & 15)
     assert idx.max() < sym.size
     ent = sym[idx]
-    zz = ent >> 10
+    zz = ent & 63
     is_dc = k == 0
     is_esc = (~is_dc) & (zz == 0)
     nxt_esc = np.zeros(len(ent), bool)
@@ -43,10 +43,13 @@ def stream_coefficients(torch, tmp, base, sl, num_subseq=None):
     ent = ent.astype(np.int64)
     nxt = nxt.astype(np.int64)
     zz = zz.astype(np.int64)
-    val = np.where(nxt_esc, ((nxt << 10) | (ent & 0x3FF)) & 0xFFFF, ((ent & 0x3FF) ^ 0x200) - 0x200 + 0x10000) & 0xFFFF
+    val = np.where(nxt_esc, (((nxt >> 6) << 10) | (ent >> 6)) & 0xFFFF, ((ent >> 6) ^ 0x200) - 0x200 + 0x10000) & 0xFFFF
     val = np.where(is_dc, ent, val).astype(np.uint16).view(np.int16)
     keep = ~is_esc
     coef[du[keep], NATURAL[np.where(is_dc, 0, zz)[keep]]] = val[keep]
+    has_esc = np.zeros(ND, bool)
+    has_esc[du[is_esc]] = True
+    assert np.array_equal(has_esc, (tab[:, 1] & 128) != 0), "escape flag of the data-unit records"
     return coef
 
 
