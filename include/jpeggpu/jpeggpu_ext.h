@@ -139,8 +139,10 @@ enum jpeggpu_status jpeggpu_ext_get_stage_ms(jpeggpu_decoder_t decoder, float* m
  * parsed and transferred (jpeggpu_decoder_transfer) into its own d_tmp, and all decoders must use the
  * same subsequence size. `d_scratch` is caller-owned device memory of at least
  * jpeggpu_ext_batch_scratch_size(total number of scans) bytes (job descriptors and front-end parameters),
- * private to the stream. The batch
- * handle owns page-locked host staging only. */
+ * private to the stream. The batch handle owns page-locked host staging only: a ring of FOUR staging buffers for
+ * the job descriptors. Like jpeggpu_decoder_decode the call only enqueues -- with one exception: the fifth call in
+ * a row on one handle waits (hipEventSynchronize) until the copy of the first one has executed, i.e. the host can
+ * run at most four batch calls ahead of the device per handle. */
 struct jpeggpu_batch;
 typedef struct jpeggpu_batch* jpeggpu_batch_t;
 struct jpeggpu_ext_batch_item {

@@ -715,7 +715,7 @@ def test_segment_shard_bands_make_the_image(torch_cuda):
               "two_rows": jpegsynth.encode(333, 251, cases.S420, restart_interval=42, seed=78)}
     for name, data in inputs.items():
         ref = oracle.decode(data)
-        for world in (2, 3, 7):
+        for world in (2, 3, 7, 50) if name == "dri_row" else (2, 3, 7):  # 50: more decoders than segments, some get nothing
             planes = [torch.full(p.shape, 0xAB, dtype=torch.uint8, device="cuda:0") for p in ref.planes]
             for rank in range(world):
                 dec = jpeggpu_amd.Decoder(32 if rank % 2 else 64)
