@@ -44,7 +44,8 @@ struct jpeggpu_ext_scan_layout {
     size_t off_segments;       /* {int subseq_offset, subseq_count}[num_segments] */
     size_t off_chunks;
     size_t off_destuffed;      /* destuffed bytes, TILED in rows of W + 3 words (W = subsequence_bytes / 4): slot s of
-                                  subsequence t is 32-bit word ((t / 32) * (W + 3) + s) * 32 + t % 32; slots 1..W are
+                                  subsequence t is 32-bit word ((t / R) * (W + 3) + s) * R + t % R, R = 32 rows per
+                                  tile (16 for 256-byte subsequences); slots 1..W are
                                   the subsequence's own words, slot 0 mirrors the last word of subsequence t - 1,
                                   slots W + 1 and W + 2 the first two of t + 1; a word holds its four stream bytes
                                   most significant first (stream byte i is byte 3 - i % 4) */

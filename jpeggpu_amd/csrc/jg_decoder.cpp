@@ -165,7 +165,7 @@ void Decoder::make_plan()
         const size_t S = static_cast<size_t>(sc.num_subseq);
         sp.num_seq     = static_cast<int>((S + kSeqSubseq - 1) / kSeqSubseq);
         sp.destuffed   = o;
-        o += align_up(tiled_buffer_bytes(static_cast<uint32_t>(S), subseq_bytes, 2) + 256, 256); // whole tiles of padded rows, two spare
+        o += align_up(tiled_buffer_bytes(static_cast<uint32_t>(S), subseq_bytes, 96) + 256, 256); // whole tiles of padded rows, 96 rows spare
         sp.seg_idx = o;
         o += align_up(S * 4, 256);
         sp.st_p = o;

@@ -113,7 +113,7 @@ JG_HD inline uint32_t huff_entry(int codelen, uint32_t sym, bool is_dc)
     return (static_cast<uint32_t>(codelen) + s) | (s << 5) | ((eob ? 64u : r + 1u) << 9);
 }
 
-/// Layout of the destuffed buffer: TILES of kTileSubseq subsequences, word-major inside a tile. The lanes
+/// Layout of the destuffed buffer: TILES of 32 (or 16) subsequences, word-major inside a tile. The lanes
 /// of a wave walk 64 different subsequences at about the same pace, so their 4-byte refills fall into a few
 /// shared 128-byte lines; with the plain layout every refill touched its own line (lane stride = 128 B) and the
 /// write pass fetched 25x the bitstream (rocprofv3 FETCH_SIZE).
@@ -128,26 +128,32 @@ JG_HD inline uint32_t huff_entry(int codelen, uint32_t sym, bool is_dc)
 /// three times (+9 % bytes at W = 32); rows at the ends of the buffer keep slots nobody wrote, which no
 /// committed symbol depends on (jg_kernels.hip, GlobalFetch).
 ///
-///   slot s of row t:  32-bit word ((t / 32) * (W + 3) + s) * 32 + t % 32
-constexpr int kTileSubseq  = 32;
+///   slot s of row t:  32-bit word ((t / R) * (W + 3) + s) * R + t % R,   R = rows per tile
+///
+/// R = 32 rows, except 16 at W = 64 (256-byte subsequences): a destuff workgroup's 4 KiB window then still fills
+/// WHOLE tiles. With 32 rows of 64 words a window was half a tile, every 128-byte line got its two halves from two
+/// workgroups -- usually on two XCDs, i.e. through two L2s -- and destuff_kernel ran 35 % longer than at W = 32.
 constexpr int kRowLeadWords = 1; // copies in front of the row's own words
 constexpr int kRowTailWords = 2; // copies behind them
 constexpr int kRowExtraWords = kRowLeadWords + kRowTailWords;
+JG_HD constexpr int tile_rows_log2(int log2_w) { return log2_w >= 6 ? 4 : 5; }
+constexpr int kMaxTileRows = 32;
 /// 32-bit word index of slot `slot` of row `row`.
 JG_HD inline uint32_t tiled_slot(uint32_t row, uint32_t slot, int log2_w)
 {
-    return ((row >> 5) * ((1u << log2_w) + kRowExtraWords) + slot) * 32u + (row & 31u);
+    const int lr = tile_rows_log2(log2_w);
+    return (((row >> lr) * ((1u << log2_w) + kRowExtraWords) + slot) << lr) + (row & ((1u << lr) - 1u));
 }
 /// Word index of the MAIN copy of linear word `linear_word` of the scan.
 JG_HD inline uint32_t tiled_word(uint32_t linear_word, int log2_w)
 {
     return tiled_slot(linear_word >> log2_w, (linear_word & ((1u << log2_w) - 1u)) + kRowLeadWords, log2_w);
 }
-/// Bytes of the tiled buffer for `num_subseq` subsequences plus `spare_tiles` whole tiles behind them.
-JG_HD inline uint64_t tiled_buffer_bytes(uint32_t num_subseq, int subseq_bytes, int spare_tiles)
+/// Bytes of the tiled buffer for `num_subseq` subsequences plus `spare_rows` rows behind them (whole tiles).
+JG_HD inline uint64_t tiled_buffer_bytes(uint32_t num_subseq, int subseq_bytes, int spare_rows)
 {
-    const uint64_t tiles = (static_cast<uint64_t>(num_subseq) + kTileSubseq - 1) / kTileSubseq + static_cast<uint64_t>(spare_tiles);
-    return tiles * kTileSubseq * (static_cast<uint64_t>(subseq_bytes) + 4u * kRowExtraWords);
+    const uint64_t rows = (static_cast<uint64_t>(num_subseq) + static_cast<uint64_t>(spare_rows) + kMaxTileRows - 1) / kMaxTileRows * kMaxTileRows;
+    return rows * (static_cast<uint64_t>(subseq_bytes) + 4u * kRowExtraWords);
 }
 
 /// The SYMBOL STREAM the write pass emits and the IDCT gathers: 16-bit entries, contiguous per data unit.

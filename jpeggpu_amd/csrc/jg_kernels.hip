@@ -261,7 +261,7 @@ __global__ __launch_bounds__(256) void destuff_kernel(JS js)
 /// subsequences' words it can touch (jg_defs.h): the window starts at most 31 bits in front of the subsequence
 /// (slot 0) and a state-only pass looks at most one 32-bit peek plus one prefetched word past its end (slots
 /// W + 1, W + 2; one more, never used, is loaded from whatever follows the row). The position is therefore ONE
-/// byte offset and the step to the next word is `+= 128`. Only the write pass, whose lanes run on until the data
+/// byte offset and the step to the next word is one add (128 bytes; 64 in the 16-row tiles of W = 64). Only the write pass, whose lanes run on until the data
 /// unit they started is complete, can leave the row (kCrossRows): it then continues at the third word of the next
 /// row, a rare branch.
 ///
@@ -277,7 +277,9 @@ template <int W, bool kCrossRows = false>
 struct GlobalFetch {
     static constexpr int kLog2W = W == 8 ? 3 : W == 16 ? 4 : W == 32 ? 5 : 6;
     static_assert((1 << kLog2W) == W, "subsequence words must be 8, 16, 32 or 64");
-    static constexpr uint32_t kRowBytes = 128u * (W + kRowExtraWords); // slot 0 of a row to slot 0 of the same row of the next tile
+    static constexpr int kLog2Rows      = tile_rows_log2(kLog2W);          // rows per tile: 32, or 16 at W = 64 (jg_defs.h)
+    static constexpr uint32_t kSlotBytes = 4u << kLog2Rows;                 // one slot of every row of a tile
+    static constexpr uint32_t kRowBytes  = kSlotBytes * (W + kRowExtraWords); // slot 0 of a row to slot 0 of the same row of the next tile
     JG_GLOBAL const uint32_t* scan32; // the scan's destuffed buffer (tiled): the same for every lane (scalar base address)
     uint32_t row0;                    // byte offset of slot 0 of the row the decode works in
     int row_word0;                    // segment-relative index of that row's first own word (slot 1)
@@ -289,19 +291,19 @@ struct GlobalFetch {
     __device__ __forceinline__ void set_row(int sub, int rel)
     {
         const uint32_t u = static_cast<uint32_t>(sub);
-        row0             = (u >> 5) * kRowBytes + (u & 31u) * 4u;
+        row0             = (u >> kLog2Rows) * kRowBytes + (u & ((1u << kLog2Rows) - 1u)) * 4u;
         row_word0        = rel * W;
     }
     __device__ __forceinline__ Pos start(int w) const
     {
-        return Pos{row0 + static_cast<uint32_t>(w - row_word0 + kRowLeadWords) * 128u, row0 + kRowBytes};
+        return Pos{row0 + static_cast<uint32_t>(w - row_word0 + kRowLeadWords) * kSlotBytes, row0 + kRowBytes};
     }
     __device__ __forceinline__ void advance(Pos& q) const
     {
-        q.off += 128u;
+        q.off += kSlotBytes;
         if (kCrossRows && q.off == q.end) { // behind slot W + 2: the stream goes on at slot 3 of the next row
-            const uint32_t step = (q.off & 127u) == 124u ? kRowBytes - 124u : 4u; // last row of a tile: on to the next tile
-            q.off               = q.off - W * 128u + step;
+            const uint32_t step = (q.off & (kSlotBytes - 1u)) == kSlotBytes - 4u ? kRowBytes - (kSlotBytes - 4u) : 4u; // last row of a tile: on to the next tile
+            q.off               = q.off - W * kSlotBytes + step;
             q.end += step;
         }
     }

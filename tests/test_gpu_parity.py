@@ -47,7 +47,7 @@ _tmp_view = gpu_util.tmp_view
 
 
 @pytest.mark.parametrize("name", ["dri_row", "multi_seq_nodri", "ni_420_dri", "cfg5_small", "dri_fill"])
-@pytest.mark.parametrize("subseq_bytes", [128, 32])
+@pytest.mark.parametrize("subseq_bytes", [256, 128, 32])
 @pytest.mark.parametrize("device_scan", [False, True])
 def test_stage_parity(gpu_lib, torch_cuda, inputs, name, subseq_bytes, device_scan):
     """Every intermediate buffer against its CPU twin: destuffed bytes, subsequence->segment map,
@@ -76,9 +76,11 @@ def test_stage_parity(gpu_lib, torch_cuda, inputs, name, subseq_bytes, device_sc
         # the device keeps the destuffed bytes in tiles of 32 subsequences, word-major, every 32-bit word most
         # significant byte first; a subsequence's row holds, around its own W words, the last word of the
         # previous subsequence (slot 0) and the first two of the next one (slots W + 1, W + 2) (jg_defs.h)
-        W, tiles = subseq_bytes // 4, (S + 31) // 32
-        tiled = _tmp_view(torch, tmp, base, sl.off_destuffed, tiles * 32 * (subseq_bytes + 12), torch.uint8)
-        rows = tiled.reshape(tiles, W + 3, 32, 4)[..., ::-1].transpose(0, 2, 1, 3).reshape(tiles * 32, W + 3, 4)[:S]
+        W = subseq_bytes // 4
+        R = 16 if W >= 64 else 32  # rows per tile (jg_defs.h)
+        tiles = (S + R - 1) // R
+        tiled = _tmp_view(torch, tmp, base, sl.off_destuffed, tiles * R * (subseq_bytes + 12), torch.uint8)
+        rows = tiled.reshape(tiles, W + 3, R, 4)[..., ::-1].transpose(0, 2, 1, 3).reshape(tiles * R, W + 3, 4)[:S]
         dst = rows[:, 1:W + 1].reshape(-1)
         if S > 1:
             assert np.array_equal(rows[1:, 0], rows[:-1, W]), "slot 0 mirrors the previous row's last word"
