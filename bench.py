@@ -69,6 +69,8 @@ def parse_args():
                     help="1: the images of the timed batch use jpeggpu_ext_set_device_scan (marker scan inside the timed region)")
     ap.add_argument("--roofline-launches", type=int, default=6,
                     help="serialized launches (one stream, nothing else on the chip) the roofline figures are averaged over; 0 = skip")
+    ap.add_argument("--other-configs", type=int, default=10,
+                    help="iterations of the latency protocol on BASELINE.json configs[0] (the reference's photo), [3] and [4]; 0 = skip")
     ap.add_argument("--cpu-seconds", type=float, default=6.0, help="budget of each leg of the CPU baseline")
     ap.add_argument("--no-cpu", action="store_true")
     ap.add_argument("--no-verify", action="store_true")
@@ -616,6 +618,22 @@ def main():
         if args.latency_iters > 0:
             out["latency_ms"] = latency_probe(args, torch, jp, slots[0].data, device, streams[0], device_scan=False)
             out["latency_ms_device_scan"] = latency_probe(args, torch, jp, slots[0].data, device, streams[0], device_scan=True)
+        if args.other_configs > 0:
+            # the other BASELINE.json configurations under the same per-image protocol (parity at full size: tests/)
+            from tools import jpegsynth
+
+            saved, args.latency_iters = args.latency_iters, args.other_configs
+            others = {}
+            with open(os.path.join(ROOT, "tests", "golden", "IMG_6510.JPG"), "rb") as f:
+                photo = f.read()
+            for name, blob in (("config1_photo_12MP_420_dri252", photo),
+                               ("config4_39MP_444_three_scans", jpegsynth.config(4)),
+                               ("config5_12MP_4_components_8_tables_no_dri", jpegsynth.config(5))):
+                r = latency_probe(args, torch, jp, blob, device, streams[0], device_scan=False)
+                others[name] = {"file_bytes": len(blob), "p50_ms": r["p50"], "p50_host_parse_ms": r["p50_host_parse"],
+                                "images_per_s_single_stream": r["images_per_s_single_stream"], "stage_us_device": r["stage_us_device"]}
+            args.latency_iters = saved
+            out["other_configs"] = others
         if args.mode == "batch" and args.e2e_rounds > 0:
             out["pcie_inclusive"] = pcie_inclusive(args, torch, jp, slots, groups, nstreams)
             out["value_full_path"] = out["pcie_inclusive"]["value"]

@@ -665,7 +665,7 @@ def test_bench_multi_rank_control_flow_over_gloo(torch_cuda):
     env = dict(os.environ, JPEGGPU_BENCH_BACKEND="gloo", HSA_ENABLE_IPC_MODE_LEGACY="0")
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
            "--master-port", str(port), os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "2", "--warmup", "1",
-           "--batch", "8", "--rounds", "1", "--unique", "2", "--latency-iters", "0", "--no-cpu", "--e2e-rounds", "0",
+           "--batch", "8", "--rounds", "1", "--unique", "2", "--latency-iters", "0", "--other-configs", "0", "--no-cpu", "--e2e-rounds", "0",
            "--roofline-launches", "2", "--gather-rounds", "2", "--segment-shard-rounds", "2"]
     r = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=600)
     assert r.returncode == 0, r.stderr[-3000:]
