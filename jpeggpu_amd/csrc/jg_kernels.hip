@@ -314,6 +314,18 @@ struct GlobalFetch {
     __device__ __forceinline__ uint32_t cook(uint32_t v, const Pos&) const { return v; }
 };
 
+#if defined(JG_PROBE)
+// Probe builds only (python jpeggpu_amd/build.py out.so -DJG_PROBE): 100 MHz time stamps of the passes of
+// huff_sync_intra, 64 per workgroup; read back with jpeggpu_probe_read (tools/probe/sync_stamps.py).
+__device__ uint32_t g_probe[4096 * 64];
+#define JG_STAMP(i)                                                                                       \
+    do {                                                                                                  \
+        if (threadIdx.x == 0 && blockIdx.x < 4096 && (i) < 64) g_probe[blockIdx.x * 64 + (i)] = static_cast<uint32_t>(wall_clock64()); \
+    } while (0)
+#else
+#define JG_STAMP(i) do { } while (0)
+#endif
+
 /// LDS address of a pointer into the workgroup's shared memory.
 __device__ __forceinline__ uint32_t lds_address(const void* p)
 {
@@ -388,8 +400,10 @@ __global__ __launch_bounds__(T) void huff_sync_intra(JS js)
     const int img_first = first_sub - OV;                    // subsequence of lane 0
     const int img_end   = min(T, sp.num_subseq - img_first); // lanes below this have a subsequence
 
+    JG_STAMP(0);
     load_tables(s_tab, J.tables_sync, sp);
     __syncthreads();
+    JG_STAMP(1);
 
     constexpr int kBits = W * 32;
     const int sub       = img_first + t;
@@ -420,6 +434,7 @@ __global__ __launch_bounds__(T) void huff_sync_intra(JS js)
         s_cz[t] = st.c | (st.z << 8);
     }
     __syncthreads();
+    JG_STAMP(2);
 
     // Flow passes. Lane t first decodes subsequence j = t + 1 from the own exit state. With a state-only
     // speculative pass it also does so if j opens a restart segment -- from the segment's start state,
@@ -459,7 +474,9 @@ __global__ __launch_bounds__(T) void huff_sync_intra(JS js)
         } else {
             flowing = false;
         }
-        if (!__syncthreads_or(flowing && j + 1 < lim)) break;
+        const bool more = __syncthreads_or(flowing && j + 1 < lim);
+        JG_STAMP(3 + iter);
+        if (!more) break;
     }
     // Flows cut short by the iteration cap continue in huff_sync_tail from the entry they reached
     // last: mark that entry (flows still inside the overlap zone belong to the previous workgroup).
@@ -1389,6 +1406,18 @@ hipError_t launch_any(Stage stage, const JS& js, const JobExtent& e, int grid_y,
 }
 
 } // namespace
+
+#if defined(JG_PROBE)
+extern "C" __attribute__((visibility("default"))) int jpeggpu_probe_read(void* dst, size_t bytes, int clear)
+{
+    if (hipMemcpyFromSymbol(dst, HIP_SYMBOL(g_probe), bytes) != hipSuccess) return 1;
+    if (clear) {
+        void* p = nullptr;
+        if (hipGetSymbolAddress(&p, HIP_SYMBOL(g_probe)) != hipSuccess || hipMemset(p, 0, sizeof(g_probe)) != hipSuccess) return 2;
+    }
+    return 0;
+}
+#endif
 
 bool subseq_bytes_supported(int b) { return b == 32 || b == 64 || b == 128 || b == 256; }
 
