@@ -172,9 +172,11 @@ JG_HD inline uint32_t huff_second_level(TabPtr tab, uint32_t e, uint32_t peek, b
 
 JG_HD inline int extend_magnitude(uint32_t bits, int s)
 {
-    // T.81 F.2.2.1 EXTEND; reference get_value (decode_huffman.cu:196-200) without the signed shift.
-    const uint32_t half = (1u << s) >> 1;
-    return bits < half ? static_cast<int>(bits - (1u << s) + 1u) : static_cast<int>(bits);
+    // T.81 F.2.2.1 EXTEND; reference get_value (decode_huffman.cu:196-200) without the signed shift: a magnitude
+    // whose first bit is clear stands for bits - (2^s - 1). Written around the mask 2^s - 1 (one bit-field-mask
+    // instruction on the device).
+    const uint32_t mask = (1u << s) - 1u;
+    return bits > (mask >> 1) ? static_cast<int>(bits) : static_cast<int>(bits - mask);
 }
 
 JG_HD inline uint32_t bits_field(uint32_t peek, int total_len, int s)
@@ -193,7 +195,7 @@ struct NoSink {
     static constexpr bool kWholeUnits = false;
     static constexpr bool kSums       = true;
     JG_HD inline bool full() const { return false; }
-    JG_HD inline void symbol(bool, bool, int, int, bool) {}
+    JG_HD inline void symbol(bool, int, int, int, int, bool) {}
     JG_HD inline void tick() {}
 };
 
@@ -209,7 +211,9 @@ struct SpecSink : NoSink {
 /// ways back.
 JG_HD inline uint32_t sym_entry_ac(int zpos, int value) { return (static_cast<uint32_t>(value) << 6) | static_cast<uint32_t>(zpos); }
 JG_HD inline uint32_t sym_entry_escape(int value) { return (static_cast<uint32_t>(value) >> 10) << 6; }
-JG_HD inline bool sym_needs_escape(int value) { return static_cast<uint32_t>(value + 512) > 1023u; }
+/// A coefficient of category 10 or more (|value| >= 512) takes an escape entry; the write pass asks the category.
+JG_HD inline bool sym_needs_escape(int value) { return static_cast<uint32_t>(value + 511) > 1022u; }
+constexpr int kEscapeFromCategory = 10;
 JG_HD inline uint32_t sym_entry_index(uint32_t e) { return e & 63u; }
 JG_HD inline int sym_entry_value(uint32_t e) { return static_cast<int16_t>(e) >> 6; }
 JG_HD inline int sym_entry_value(uint32_t e, uint32_t escape) { return static_cast<int16_t>(((escape >> 6) << 10) | ((e & 0xFFFFu) >> 6)); }
@@ -256,10 +260,10 @@ JG_HD inline void decode_subsequence(
 #define JG_CUR_NEXT cur.next
 #endif
     int p       = st.p;
-    int z       = st.z;
+    int zm      = st.z - 1; // zig-zag index MINUS ONE: the index of the coefficient a symbol ends at is zm + its advance
     int units   = 0;
     uint32_t dc01 = st.dc01, dc23 = st.dc23;
-    bool is_dc = z == 0;
+    bool is_dc = st.z == 0;
     uint32_t peek, e;
     int total;
     // look the symbol under the bit window up: first-level LUT of the unit's DC or AC table, second level if needed
@@ -282,8 +286,8 @@ JG_HD inline void decode_subsequence(
         bw.skip(total);                                                                                   \
         p += total;                                                                                       \
         const int adv     = e >> 9;                                                                       \
-        const int z1      = z + adv;                                                                      \
-        const bool du_end = z1 >= 64;                                                                     \
+        const int zp      = zm + adv; /* index of the symbol's coefficient */                             \
+        const bool du_end = zp >= 63;                                                                     \
         if (Sink::kWrite) {                                                                               \
             /* branch-free: every lane computes the magnitude, only DC symbols move the sums */          \
             const int s      = (e >> 5) & 15;                                                             \
@@ -293,9 +297,9 @@ JG_HD inline void decode_subsequence(
             dc01             = pk_add_u16(dc01, static_cast<uint32_t>(d));                                \
             dc23             = pk_add_u16(dc23, static_cast<uint32_t>(d >> 32));                          \
             /* the component's running sum is the absolute DC value, 16-bit wrap like the reference's   \
-               int16 prefix sum (decode_dc.cu:129-155); an AC coefficient sits at zig-zag index z1 - 1 */ \
+               int16 prefix sum (decode_dc.cu:129-155); an AC coefficient sits at zig-zag index zp */          \
             const int absdc = static_cast<int>(((static_cast<uint64_t>(dc23) << 32) | dc01) >> sh);       \
-            sink.symbol(is_dc, s != 0, z1 - 1, is_dc ? absdc : v, du_end);                                \
+            sink.symbol(is_dc, s, zp, v, absdc, du_end);                                \
         } else if (Sink::kSums && is_dc) {                                                                \
             const int s      = (e >> 5) & 15;                                                             \
             const int v      = extend_magnitude(bits_field(peek, total, s), s);                           \
@@ -303,7 +307,7 @@ JG_HD inline void decode_subsequence(
             dc01             = pk_add_u16(dc01, static_cast<uint32_t>(d));                                \
             dc23             = pk_add_u16(dc23, static_cast<uint32_t>(d >> 32));                          \
         }                                                                                                 \
-        z = du_end ? 0 : z1;                                                                              \
+        zm = du_end ? -1 : zp;                                                                            \
         if (Sink::kWrite || Sink::kSums) units += du_end ? 1 : 0;                                         \
         cur = JG_LOAD_CURSOR(du_end ? JG_CUR_NEXT : JG_CUR_SELF);                                         \
         is_dc = du_end;                /* a unit just ended <=> the next symbol is a DC symbol */         \
@@ -337,7 +341,7 @@ JG_HD inline void decode_subsequence(
                 e = huff_second_level<kSyncEntryBytes>(tab, e, peek, is_dc);
             } else {
                 const uint32_t m = e32 >> 16;
-                if (z + static_cast<int>((m >> 5) & 15u) < 64) e = m;
+                if (zm + static_cast<int>((m >> 5) & 15u) < 63) e = m;
             }
             total = e & 31;
             JG_COMMIT();
@@ -360,9 +364,9 @@ JG_HD inline void decode_subsequence(
     }
 #undef JG_LOOKUP
 #undef JG_COMMIT
-    if (Sink::kWrite || Sink::kSums) st.n += 64 * units + z - st.z;
+    if (Sink::kWrite || Sink::kSums) st.n += 64 * units + (zm + 1) - st.z;
     st.p    = p;
-    st.z    = z;
+    st.z    = zm + 1;
     st.c    = (JG_CUR_META >> 8) & 0xFF;
     st.dc01 = dc01;
     st.dc23 = dc23;

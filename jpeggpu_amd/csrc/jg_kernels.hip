@@ -301,7 +301,10 @@ struct GlobalFetch {
     __device__ __forceinline__ void advance(Pos& q) const
     {
         q.off += kSlotBytes;
-        if (kCrossRows && q.off == q.end) { // behind slot W + 2: the stream goes on at slot 3 of the next row
+        if (kCrossRows && __builtin_expect(q.off == q.end, 0)) { // behind slot W + 2: the stream goes on at slot 3 of the next row
+            // a real branch: as selects these eight instructions run with every refill of every wave, while a lane
+            // leaves its row once or twice per subsequence (the empty statement keeps the compiler from if-converting)
+            asm volatile("");
             const uint32_t step = (q.off & (kSlotBytes - 1u)) == kSlotBytes - 4u ? kRowBytes - (kSlotBytes - 4u) : 4u; // last row of a tile: on to the next tile
             q.off               = q.off - W * kSlotBytes + step;
             q.end += step;
@@ -683,6 +686,7 @@ __global__ __launch_bounds__(T) void huff_seq_tails(JS js)
 // ------------------------------------------------------------------------------------------------
 
 constexpr int kRingWords    = 16;                         // 32-bit words of a lane's write-combining ring: two entries each
+constexpr int kRingStride   = (kRingWords + 1) * 4;       // bytes from one lane's ring to the next: 17 words, an odd number of banks
 constexpr int kStageEntries = 2 * kRingWords;             // entries the ring holds (a power of two)
 constexpr int kFlushEntries = kSymSectorEntries;          // entries per flush: 16 = one 32-byte sector
 constexpr int kFlushPeriod  = 8;                          // iterations between two flush points
@@ -695,21 +699,26 @@ constexpr int kFlushPeriod  = 8;                          // iterations between 
 ///
 /// A lane's appends must not go to memory one by one: with many images in flight the ~200 k open lines do not fit
 /// in L2 and every append becomes its own 32-byte sector write. Entries are therefore collected in a ring per lane
-/// in LDS ([word][lane], conflict-free; 16 words = 32 entries) and every 8 iterations ALL lanes that have 16 or
-/// more waiting flush one whole 32-byte sector: an iteration adds at most two entries (a coefficient and its
-/// escape), so at most 15 stay behind and at most 16 arrive in between.
+/// in LDS (32 entries = 64 bytes, rings 17 words apart: the lanes of a wave hit different banks) and every 8
+/// iterations ALL lanes that have 16 or more waiting flush one whole 32-byte sector: an iteration adds at most two
+/// entries (a coefficient and its escape), so at most 15 stay behind and at most 16 arrive in between.
+///
+/// The kernel is bound by vector-instruction issue, so the per-symbol part is counted in instructions: the ring
+/// address is an AND and a shift-add; the escape flag of the open unit lives in `du_off` (minus 128, so that
+/// entries - du_off comes out with bit 7 set); the counts of finished units are shifted into a 64-bit register from
+/// the top (two funnel shifts and two selects).
 struct StreamSink {
     static constexpr bool kWrite      = true;
     static constexpr bool kWholeUnits = true;
     static constexpr bool kSums       = true;
     JG_GLOBAL uint16_t* sym;
     JG_GLOBAL uint2_t* du_tab;
-    uint32_t ring;      // LDS byte address of word 0 of the lane's ring; word k at ring + k * T * 4
+    uint32_t ring;      // LDS byte address of the lane's ring: entry n at ring + (n % 32) * 2
     uint32_t base;      // physical index of the region's first entry (jg_defs.h, sym_region_base)
     uint32_t flushed;   // entries of this lane already in memory (a multiple of 16), region-relative like the next three
     uint32_t emitted;   // entries produced so far
     uint32_t cur_end;   // entries a region holds
-    uint32_t du_off;
+    uint32_t du_off;    // first entry of the unit being decoded, minus kUnitHasEscape once it has taken an escape entry
     int du;       // next data unit this lane starts
     int quota;    // first data unit past the segment
     int ticks;
@@ -721,58 +730,63 @@ struct StreamSink {
     // table (rocprofv3 WRITE_SIZE).
     uint32_t rec_off;   // region-relative offset of the first unit whose record has not been stored
     int rec_du;         // its index in the data-unit table
-    uint32_t pend_lo, pend_hi; // counts of waiting units 0..3 and 4..7
+    uint32_t pend_lo, pend_hi; // counts (| kUnitHasEscape) of the waiting units: the TOP pend_n bytes of hi:lo, oldest lowest
     int pend_n;
-    uint32_t unit_esc; // kUnitHasEscape once the unit being decoded has taken an escape entry
     bool started; // false while the first symbols finish the predecessor's data unit
     __device__ __forceinline__ bool full() const { return du >= quota; }
-    /// 16-bit store into the lane's ring: entry n sits in half n & 1 of word (n / 2) % 16. A lane that has nothing
-    /// to keep stores all the same, into the slot its next kept entry will overwrite (at most 31 entries wait, so
-    /// slot n is free): no select, no spare row.
+    /// 16-bit store into the lane's ring. A lane that has nothing to keep stores all the same, into the slot its
+    /// next kept entry will overwrite (at most 31 entries wait, so slot n is free): no select, no spare row.
     __device__ __forceinline__ void put(uint32_t n, uint32_t entry)
     {
         typedef __attribute__((address_space(3))) uint16_t LdsHalf;
-        const uint32_t word = (n >> 1) & (kRingWords - 1);
-        *reinterpret_cast<LdsHalf*>(static_cast<uintptr_t>(ring + word * (T * 4) + (n & 1u) * 2u)) = static_cast<uint16_t>(entry);
+        uint32_t a; // ring + (n % 32) * 2 as AND + shift-add (the compiler turns it into shift, AND, add)
+        asm("v_and_b32 %0, %1, %2\n\tv_lshl_add_u32 %0, %0, 1, %3" : "=&v"(a) : "n"(kStageEntries - 1), "v"(n), "v"(ring));
+        *reinterpret_cast<LdsHalf*>(static_cast<uintptr_t>(a)) = static_cast<uint16_t>(entry);
     }
-    /// One call per decoded symbol. `value` is the absolute DC value of a DC symbol (zig-zag index 0) or the
-    /// coefficient of an AC symbol at index `zpos`; zero AC coefficients, symbols that finish the predecessor's
-    /// unit, and anything past the region on a corrupt stream go to the spare ring row.
-    __device__ __forceinline__ void symbol(bool is_dc, bool nonzero, int zpos, int value, bool unit_end)
+    /// One call per decoded symbol: a DC symbol brings the absolute DC value `dc`, an AC symbol the coefficient
+    /// `value` at zig-zag index `zpos`. Zero AC coefficients, symbols that finish the predecessor's unit, and
+    /// anything past the region on a corrupt stream are stored where the next kept entry will go.
+    __device__ __forceinline__ void symbol(bool is_dc, int category, int zpos, int value, int dc, bool unit_end)
     {
-        du_off   = is_dc ? emitted : du_off;
-        unit_esc = is_dc ? 0u : unit_esc;
+        du_off = is_dc ? emitted : du_off;
         du += is_dc ? 1 : 0;
         started         = started || is_dc;
-        const bool emit = started && (is_dc || nonzero) && emitted < cur_end;
-        put(emitted, is_dc ? static_cast<uint32_t>(value) : sym_entry_ac(zpos, value));
+        const bool emit = started && (is_dc || category != 0) && emitted < cur_end;
+        put(emitted, is_dc ? static_cast<uint32_t>(dc) : sym_entry_ac(zpos, value));
         emitted += emit ? 1u : 0u;
-        // a coefficient that does not fit 10 bits (no photograph has one) takes a second entry
-        if (__builtin_expect(emit && !is_dc && sym_needs_escape(value), 0)) {
+        // a coefficient of category 10 or more (no photograph has one) takes a second entry
+        if (__builtin_expect(emit && !is_dc && category >= kEscapeFromCategory, 0)) {
             put(emitted, sym_entry_escape(value));
             emitted += emitted < cur_end ? 1u : 0u;
-            unit_esc = kUnitHasEscape;
+            du_off -= ((emitted - du_off) & kUnitHasEscape) ? 0u : kUnitHasEscape; // once per unit (a unit has at most 127 entries)
         }
         // A unit takes at least two symbols, so at most four finish between two flush points (8 iterations); a
-        // flush leaves at most three waiting: eight slots are enough.
+        // flush leaves at most three waiting: eight slots are enough. The count enters at the top.
         const bool done    = unit_end && started;
-        const uint32_t cnt = ((emitted - du_off) | unit_esc) << (8 * (pend_n & 3));
-        pend_lo |= done && pend_n < 4 ? cnt : 0u;
-        pend_hi |= done && pend_n >= 4 ? cnt : 0u;
+        const uint32_t cnt = emitted - du_off; // entries | kUnitHasEscape
+        const uint32_t lo = __builtin_amdgcn_alignbit(pend_hi, pend_lo, 8);
+        const uint32_t hi = __builtin_amdgcn_alignbit(cnt, pend_hi, 8);
+        pend_lo = done ? lo : pend_lo;
+        pend_hi = done ? hi : pend_hi;
         pend_n += done ? 1 : 0;
     }
-    /// Store the first `n` waiting records (1..4) and move the others down.
+    /// Store the first `n` waiting records (1..4).
     __device__ __forceinline__ void store_units(int n)
     {
+        // the waiting counts, oldest in byte 0
+        const uint32_t counts = static_cast<uint32_t>(((static_cast<uint64_t>(pend_hi) << 32) | pend_lo) >> (8 * (8 - pend_n)));
         uint2_t rec[4];
         uint32_t off = rec_off;
 #pragma unroll
         for (int k = 0; k < 4; ++k) {
-            const uint32_t cnt = (pend_lo >> (8 * k)) & 0xFFu; // entries | kUnitHasEscape
+            const uint32_t cnt = (counts >> (8 * k)) & 0xFFu; // entries | kUnitHasEscape
             rec[k]             = uint2_t{sym_at(base, off), cnt};
             off += k < n ? cnt & 0x7Fu : 0u;
         }
         JG_GLOBAL uint2_t* dst = du_tab + rec_du;
+#if defined(JG_EXP_NO_UNIT_STORES) // traffic experiments only (tools/probe/pmc_lib.sh): results are wrong
+        if (rec[0].x == 0xFFFFFFFEu)
+#endif
         if (n == 4 && (rec_du & 3) == 0) { // a whole, aligned sector of the table
             st_global(reinterpret_cast<JG_GLOBAL uint4*>(dst), make_uint4(rec[0].x, rec[0].y, rec[1].x, rec[1].y));
             st_global(reinterpret_cast<JG_GLOBAL uint4*>(dst) + 1, make_uint4(rec[2].x, rec[2].y, rec[3].x, rec[3].y));
@@ -783,11 +797,7 @@ struct StreamSink {
         }
         rec_off = off;
         rec_du += n;
-        pend_n -= n;
-        // the counts move down by n bytes (n == 4: the high word becomes the low one)
-        const uint64_t both = ((static_cast<uint64_t>(pend_hi) << 32) | pend_lo) >> (8 * n);
-        pend_lo = static_cast<uint32_t>(both);
-        pend_hi = static_cast<uint32_t>(both >> 32);
+        pend_n -= n; // the others are still the top pend_n bytes
     }
     __device__ __forceinline__ void flush_units()
     {
@@ -800,13 +810,18 @@ struct StreamSink {
     {
         typedef __attribute__((address_space(3))) uint32_t LdsWord;
         uint32_t e[kFlushEntries / 2];
-        const uint32_t r = ring + ((flushed >> 1) & (kRingWords - 1)) * (T * 4); // no wrap inside a sector
+        const uint32_t r = ring + ((flushed & (kStageEntries - 1u)) << 1); // lower or upper half of the ring
 #pragma unroll
-        for (int k = 0; k < kFlushEntries / 2; ++k) e[k] = *reinterpret_cast<const LdsWord*>(static_cast<uintptr_t>(r + k * (T * 4)));
+        for (int k = 0; k < kFlushEntries / 2; ++k) e[k] = *reinterpret_cast<const LdsWord*>(static_cast<uintptr_t>(r + k * 4));
         static_assert(kFlushEntries == 16, "a flush is one sector of the interleaved stream");
         JG_GLOBAL uint4* dst = reinterpret_cast<JG_GLOBAL uint4*>(sym + sym_at(base, flushed));
-        st_global(dst, make_uint4(e[0], e[1], e[2], e[3]));
-        st_global(dst + 1, make_uint4(e[4], e[5], e[6], e[7]));
+#if defined(JG_EXP_NO_SECTOR_STORES)
+        if (e[0] == 0xFFFFFFFEu && e[1] == 0x12345678u)
+#endif
+        {
+            st_global(dst, make_uint4(e[0], e[1], e[2], e[3]));
+            st_global(dst + 1, make_uint4(e[4], e[5], e[6], e[7]));
+        }
         flushed += kFlushEntries;
     }
     __device__ __forceinline__ void tick()
@@ -858,7 +873,7 @@ __device__ __forceinline__ uint32_t pk_sub(uint32_t a, uint32_t b) { return pk_a
 struct WriteLds {
     static constexpr uint32_t kScan = 0;                                   // T + 1 + 4 + 3 words
     static constexpr uint32_t kRing = ((T + 8) * 4 + 15) / 16 * 16;
-    static constexpr uint32_t kTabs = kRing + kRingWords * T * 4;
+    static constexpr uint32_t kTabs = (kRing + kRingStride * SEQ + 15) / 16 * 16; // lanes SEQ..T-1 emit nothing
     static_assert(kTabs % 16 == 0, "the table pack is read with 16-byte loads");
     static_assert(kStaticLdsSlack + kTabs + kMaxTablePack <= 65536, "absolute table addresses are packed into 16 bits (load_tables)");
 };
@@ -929,7 +944,7 @@ __global__ __launch_bounds__(T) void huff_write(JS js)
     StreamSink sink;
     sink.sym     = J.sym;
     sink.du_tab  = J.du_tab;
-    sink.ring    = lds_address(s_ring + t);
+    sink.ring    = lds_address(s_ring) + static_cast<uint32_t>(t) * kRingStride;
     int nprefix  = 0;
     uint32_t pred01 = 0, pred23 = 0; // DC predictors at the lane's first symbol: sums over the segment so far
     {
@@ -959,7 +974,6 @@ __global__ __launch_bounds__(T) void huff_write(JS js)
     sink.pend_lo        = 0;
     sink.pend_hi        = 0;
     sink.pend_n         = 0;
-    sink.unit_esc       = 0;
 
     LaneState st{};
     st.dc01 = pred01;

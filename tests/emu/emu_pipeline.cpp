@@ -45,8 +45,10 @@ struct HostSink {
     bool started;
     uint32_t unit_esc = 0;
     bool full() const { return du >= quota; }
-    void symbol(bool is_dc, bool nonzero, int zpos, int value, bool unit_end)
+    void symbol(bool is_dc, int category, int zpos, int ac_value, int dc, bool unit_end)
     {
+        const bool nonzero = category != 0;
+        const int value = is_dc ? dc : ac_value;
         if (is_dc) {
             started  = true;
             du_off   = cur;
