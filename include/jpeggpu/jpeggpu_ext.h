@@ -58,7 +58,7 @@ struct jpeggpu_ext_scan_layout {
     size_t off_state_dc23;     /* same for scan components 2 and 3 */
     size_t off_symbols;        /* uint16 entries, contiguous per data unit: the unit's DC value (absolute) first, then
                                   one entry per non-zero AC coefficient, value << 6 | zig-zag index (value in
-                                  -512..511); a coefficient outside that range is followed by an escape entry with
+                                  -512..511); a coefficient of magnitude 512 or more (category >= 10) is followed by an escape entry with
                                   index 0 holding value >> 10 in its high bits. Logically one region of symbol_region_entries per
                                   subsequence; physically the regions of 64 consecutive subsequences are interleaved
                                   in sectors of 16 entries: sector j of subsequence s starts at entry

@@ -160,7 +160,7 @@ JG_HD inline uint64_t tiled_buffer_bytes(uint32_t num_subseq, int subseq_bytes, 
 ///   * a unit's FIRST entry is its DC coefficient, absolute (the predictor is already added), 16 bits;
 ///   * every other entry is a non-zero AC coefficient: value << 6 | zig-zag index (1..63), value in -512..511 as a
 ///     10-bit two's complement number in the high bits;
-///   * an AC coefficient outside that range (magnitude category 10 and above: quantisers of 1 at best) is followed by an
+///   * an AC coefficient of magnitude category 10 and above (|value| >= 512, -512 included: quantisers of 1 at best) is followed by an
 ///     ESCAPE entry, index field 0, whose high bits are value >> 10: value = int16((escape >> 6) << 10 | entry >> 6).
 ///     The count of a unit that holds an escape has bit 7 set in the data-unit table (a count is at most 127).
 /// Half the bytes of a 32-bit entry (index << 16 | value) -- the stream is most of what the write pass stores and the
