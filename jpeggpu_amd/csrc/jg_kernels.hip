@@ -119,32 +119,24 @@ struct JobArray {
 // destuff
 // ------------------------------------------------------------------------------------------------
 
-/// One workgroup = one aligned 4 KiB window of the transferred bytes clipped to one segment.
+/// One aligned 4 KiB window of the transferred bytes clipped to one segment = one chunk; a workgroup takes TWO
+/// neighbouring chunks, with the loads of both issued before the first is worked on: a chunk is little work behind
+/// two dependent loads (its record, then its bytes), so a workgroup's life was mostly those two latencies.
 /// Lane t owns 16 consecutive source bytes. Byte rule (reference src/decode_destuff.cu:37-44): a byte is
 /// data iff (prev == FF and b == 00) or (prev != FF and b != FF); the first case stores FF.
 /// The compacted bytes are staged in LDS at the destination's 16-byte phase and leave as whole
 /// 16-byte stores except at the two ragged ends (neighbouring chunks own the other bytes there).
-template <class JS>
-__global__ __launch_bounds__(256) void destuff_kernel(JS js)
+constexpr int kDestuffChunksPerWg = 2;
+
+template <class J_t>
+__device__ __forceinline__ void destuff_chunk(const J_t& J, const DestuffChunk& ck, const uint4& v, uint32_t prev_of_lane0, uint8_t* s_out, uint32_t* s_wave)
 {
-    __shared__ __attribute__((aligned(16))) uint8_t s_out[kDestuffWin + 32];
-    __shared__ uint32_t s_wave[4];
-
-    const JobView J(js.get());
-    if (static_cast<int>(blockIdx.x) >= J.num_chunks) return;
-    JG_GLOBAL const uint8_t* __restrict__ src = J.bytes;
-    JG_GLOBAL uint8_t* __restrict__ dst       = J.destuffed;
-    const DestuffChunk ck           = ld_global(J.chunks + blockIdx.x);
-    const int t                     = threadIdx.x;
-    const uint32_t gpos             = ck.win_off + t * 16;
-
-    uint32_t w[4];
-    {
-        const uint4 v = ld_global(reinterpret_cast<JG_GLOBAL const uint4*>(src + gpos));
-        w[0] = v.x; w[1] = v.y; w[2] = v.z; w[3] = v.w;
-    }
-    uint32_t prev = __shfl_up(w[3] >> 24, 1);
-    if (lane_id() == 0) prev = gpos > 0 ? src[gpos - 1] : 0u;
+    JG_GLOBAL uint8_t* __restrict__ dst = J.destuffed;
+    const int t         = threadIdx.x;
+    const uint32_t gpos = ck.win_off + t * 16;
+    uint32_t w[4]       = {v.x, v.y, v.z, v.w};
+    uint32_t prev       = __shfl_up(w[3] >> 24, 1);
+    if (lane_id() == 0) prev = prev_of_lane0;
 
     // Byte rule on four bytes at a time (jg_bytes.h): F / Z = bytes equal to FF / 00, PF = the byte in front is
     // FF. A stuffed zero is data and stands for the FF in front of it: the word is patched so that the
@@ -220,14 +212,51 @@ __global__ __launch_bounds__(256) void destuff_kernel(JS js)
     };
     const uint32_t word0     = (ck.dst_off - phase) >> 2; // linear word of s_out[0]
     const uint32_t lo = phase, hi = phase + total;        // valid LDS byte range
-    for (uint32_t g = t; g * 4 < hi; g += 256) {
-        const uint32_t b0 = g * 4;
-        uint32_t at[3];
-        const int n = slots_of(word0 + g, at);
-        if (b0 >= lo && b0 + 4 <= hi) {
-            const uint32_t v = __builtin_bswap32(*reinterpret_cast<const uint32_t*>(s_out + b0)); // most significant byte first
-            for (int i = 0; i < n; ++i) dst32[at[i]] = v;
-        } else {
+    const auto word_at = [&](uint32_t lw) -> uint32_t { // linear word lw of the scan, most significant byte first
+        return __builtin_bswap32(*reinterpret_cast<const uint32_t*>(s_out + (lw - word0) * 4u));
+    };
+    // The words that lie wholly inside the chunk, [wa, wb): row R of the tiled buffer holds the linear words
+    // R * W - 1 .. R * W + W + 1 in its slots 0 .. W + 2 (jg_defs.h: own words and the mirrored neighbours), and the
+    // same slot of four consecutive rows is 16 consecutive bytes of a tile. So the write-out walks PIECES (tile, slot,
+    // group of four rows): four LDS words W apart, one 16-byte store, and the 64 lanes of a wave fill 1 KiB of
+    // consecutive memory. Stored word by word in stream order a wave's store touched 64 lines with 4 bytes each:
+    // half the kernel's time. Pieces at the chunk's first and last rows, which a neighbouring chunk shares, fall
+    // back to single words.
+    const uint32_t wa = word0 + ((lo + 3u) >> 2), wb = word0 + (hi >> 2);
+    if (wa < wb) {
+        const int lr          = tile_rows_log2(log2w);
+        const uint32_t W      = wmask + 1u;
+        const uint32_t gmask  = (1u << (lr - 2)) - 1u;                  // groups of four rows in a tile, minus one
+        const uint32_t pieces = (W + kRowExtraWords) << (lr - 2);       // of one tile
+        const uint32_t r_min  = wa >= 2u ? (wa - 2u) >> log2w : 0u;     // first and last row that hold one of the words
+        const uint32_t r_max  = wb >> log2w;
+        for (uint32_t tile = r_min >> lr; tile <= r_max >> lr; ++tile) {
+            for (uint32_t p = t; p < pieces; p += 256) {
+                const uint32_t slot = p >> (lr - 2), j = p & gmask;
+                const uint32_t row0 = (tile << lr) + 4u * j;
+                const uint32_t lw0  = (row0 << log2w) + slot - 1u;      // row 0, slot 0 wraps around: outside [wa, wb)
+                bool in[4];
+#pragma unroll
+                for (int i = 0; i < 4; ++i) in[i] = lw0 + static_cast<uint32_t>(i) * W - wa < wb - wa;
+                JG_GLOBAL uint32_t* at = dst32 + (((tile * (W + kRowExtraWords) + slot) << lr) + 4u * j);
+                if (in[0] && in[1] && in[2] && in[3]) {
+                    st_global(reinterpret_cast<JG_GLOBAL uint4*>(at), make_uint4(word_at(lw0), word_at(lw0 + W), word_at(lw0 + 2u * W), word_at(lw0 + 3u * W)));
+                } else {
+#pragma unroll
+                    for (int i = 0; i < 4; ++i)
+                        if (in[i]) at[i] = word_at(lw0 + static_cast<uint32_t>(i) * W);
+                }
+            }
+        }
+    }
+    // the chunk's first and last word when a neighbouring chunk owns the other bytes: byte stores into every copy
+    if (t < 2 && lo < hi) {
+        const uint32_t f = lo >> 2, l = hi >> 2; // LDS words that hold the first byte and the one behind the last
+        const bool mine  = t == 0 ? (lo & 3u) != 0 : (hi & 3u) != 0 && (l != f || (lo & 3u) == 0);
+        const uint32_t b0 = (t == 0 ? f : l) * 4u;
+        if (mine) {
+            uint32_t at[3];
+            const int n = slots_of(word0 + (b0 >> 2), at);
             for (uint32_t b = b0 > lo ? b0 : lo; b < b0 + 4 && b < hi; ++b)
                 for (int i = 0; i < n; ++i) dst[at[i] * 4 + (3u - (b & 3))] = s_out[b];
         }
@@ -245,6 +274,39 @@ __global__ __launch_bounds__(256) void destuff_kernel(JS js)
         const uint32_t sb    = static_cast<uint32_t>(J.sp.subseq_words) * 4u;
         const uint32_t first = (ck.dst_off + sb - 1) / sb;
         for (uint32_t s = first + t; s * sb < ck.dst_off + total; s += 256) J.seg_idx[s] = ck.seg;
+    }
+}
+
+template <class JS>
+__global__ __launch_bounds__(256) void destuff_kernel(JS js)
+{
+    __shared__ __attribute__((aligned(16))) uint8_t s_out[kDestuffWin + 32];
+    __shared__ uint32_t s_wave[4];
+
+    const JobView J(js.get());
+    const int c0 = static_cast<int>(blockIdx.x) * kDestuffChunksPerWg;
+    if (c0 >= J.num_chunks) return;
+    const int n = min(kDestuffChunksPerWg, J.num_chunks - c0);
+    JG_GLOBAL const uint8_t* __restrict__ src = J.bytes;
+    const int t = threadIdx.x;
+    DestuffChunk ck[kDestuffChunksPerWg];
+    uint4 v[kDestuffChunksPerWg];
+    uint32_t prev0[kDestuffChunksPerWg];
+#pragma unroll
+    for (int k = 0; k < kDestuffChunksPerWg; ++k) ck[k] = ld_global(J.chunks + c0 + (k < n ? k : 0));
+#pragma unroll
+    for (int k = 0; k < kDestuffChunksPerWg; ++k) {
+        const uint32_t gpos = ck[k].win_off + t * 16;
+        v[k]                = ld_global(reinterpret_cast<JG_GLOBAL const uint4*>(src + gpos));
+        prev0[k]            = 0u;
+        if (lane_id() == 0 && gpos > 0) prev0[k] = src[gpos - 1]; // the byte in front of a wave's first one
+    }
+#pragma unroll
+    for (int k = 0; k < kDestuffChunksPerWg; ++k) {
+        if (k < n) { // uniform
+            if (k) __syncthreads(); // the staging buffer is free again
+            destuff_chunk(J, ck[k], v[k], prev0[k], s_out, s_wave);
+        }
     }
 }
 
@@ -1394,7 +1456,7 @@ hipError_t launch_any(Stage stage, const JS& js, const JobExtent& e, int grid_y,
         return hipSuccess; // nothing to clear any more: the write pass emits a symbol stream
     case kStageDestuff:
         if (e.max_chunks == 0) return hipSuccess;
-        destuff_kernel<JS><<<dim3(e.max_chunks, grid_y), 256, 0, stream>>>(js);
+        destuff_kernel<JS><<<dim3((e.max_chunks + kDestuffChunksPerWg - 1) / kDestuffChunksPerWg, grid_y), 256, 0, stream>>>(js);
         return hipGetLastError();
     case kStageTails:
         if (e.max_seq == 0) return hipSuccess;
