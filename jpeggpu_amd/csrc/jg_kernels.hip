@@ -1063,6 +1063,9 @@ __device__ __forceinline__ int unfixo(int x) { return (x + 0x1000) >> 13; }
 
 /// 8-point fixed-point inverse DCT, the arithmetic of the reference's `idct_vector`
 /// (src/idct.cu:49-95): Q15 even part, Q13 odd part, results rounded to int16.
+/// kRound = 0x8000 is the reference's rounding; the row pass adds the level shift as well (128 in the high half:
+/// the int16 the reference stores and then offsets, `(int16)(t + 128)`, src/idct.cu:218, wraps the same way).
+template <int kRound = 0x8000>
 __device__ __forceinline__ void idct8(int (&v)[8])
 {
     constexpr int cos_1_4 = 0x5a82, sin_1_8 = 0x30fc, cos_1_8 = 0x7642;
@@ -1085,14 +1088,14 @@ __device__ __forceinline__ void idct8(int (&v)[8])
     const int b3 = o2 * osin_5_16 - o3 * ocos_5_16;
 
     // results rounded but NOT shifted: the int16 the reference stores (`unfixh`) is the high half
-    v[0] = a0 + b0 + 0x8000;
-    v[1] = a1 + b3 + 0x8000;
-    v[2] = a2 + b2 + 0x8000;
-    v[3] = a3 + b1 + 0x8000;
-    v[4] = a3 - b1 + 0x8000;
-    v[5] = a2 - b2 + 0x8000;
-    v[6] = a1 - b3 + 0x8000;
-    v[7] = a0 - b0 + 0x8000;
+    v[0] = a0 + b0 + kRound;
+    v[1] = a1 + b3 + kRound;
+    v[2] = a2 + b2 + kRound;
+    v[3] = a3 + b1 + kRound;
+    v[4] = a3 - b1 + kRound;
+    v[5] = a2 - b2 + kRound;
+    v[6] = a1 - b3 + kRound;
+    v[7] = a0 - b0 + kRound;
 }
 
 __device__ __forceinline__ uint32_t magic_quot(uint32_t n, uint32_t mul, uint32_t shift)
@@ -1100,15 +1103,13 @@ __device__ __forceinline__ uint32_t magic_quot(uint32_t n, uint32_t mul, uint32_
     return mul ? __umulhi(n, mul) >> shift : n;
 }
 
-/// Two finished samples from two row-pass results: (int16)(hi16 + 128) each, clamped to 0..255
-/// (reference src/idct.cu:218-220), as two bytes in the low half of the result.
+/// Two finished samples from two row-pass results whose high halves already hold (int16)(t + 128): clamped to
+/// 0..255 (reference src/idct.cu:218-220), as two bytes in the low half of the result.
 __device__ __forceinline__ uint32_t finish_pixels(int w0, int w1)
 {
-    typedef short s2 __attribute__((ext_vector_type(2)));
     const uint32_t pair = __builtin_amdgcn_perm(static_cast<uint32_t>(w1), static_cast<uint32_t>(w0), 0x07060302u);
-    const s2 sum        = __builtin_bit_cast(s2, pair) + s2{128, 128}; // wraps like the reference's int16 store
     uint32_t r;
-    asm("v_sat_pk_u8_i16 %0, %1" : "=v"(r) : "v"(__builtin_bit_cast(uint32_t, sum)));
+    asm("v_sat_pk_u8_i16 %0, %1" : "=v"(r) : "v"(pair));
     return r & 0xFFFFu;
 }
 
@@ -1222,14 +1223,19 @@ __global__ __launch_bounds__(256) void idct_kernel(JS js)
     };
     // entries r, r + 8, r + 16, r + 24 of a unit: 8 further is the same sector or, from the upper half of one, the
     // lower half of the next
+    // Entry w of the sector row that holds `first` (w = first % 16 + j for the unit's entry j) lies at entry index
+    // (first & ~15) + (w / 16) * 1024 + w % 16 = (first & ~15) + w + (w & ~15) * 63: in BYTES one AND and one
+    // multiply-add per entry, the step of 8 entries between a lane's fetches inside the AND's operand.
     const auto prefetch = [&](uint32_t first, uint32_t cnt, uint32_t (&out)[kAhead]) {
-        uint32_t w   = (first & (kSymSectorEntries - 1u)) + static_cast<uint32_t>(r);
-        uint32_t idx = (first & ~(kSymSectorEntries - 1u)) + (w >> 4) * kSymSectorStride + (w & 15u);
+        const uint32_t w2   = ((first & (kSymSectorEntries - 1u)) + static_cast<uint32_t>(r)) * 2u; // byte offset of entry r in the row
+        const uint32_t row2 = (first & ~(kSymSectorEntries - 1u)) * 2u + w2;
+        JG_GLOBAL const uint8_t* stream = reinterpret_cast<JG_GLOBAL const uint8_t*>(J.sym);
 #pragma unroll
         for (int k = 0; k < kAhead; ++k) {
-            out[k] = static_cast<uint32_t>(r + 8 * k) < cnt ? entry_at(idx) : 0u;
-            idx += 8u + (w & 8u) * ((kSymSectorStride - kSymSectorEntries) / 8u);
-            w += 8u;
+            const uint32_t sector2 = (w2 + 16u * k) & ~(2u * kSymSectorEntries - 1u);
+            out[k] = static_cast<uint32_t>(r + 8 * k) < cnt
+                         ? *reinterpret_cast<JG_GLOBAL const uint16_t*>(stream + (row2 + sector2 * (kSymSectorStride / kSymSectorEntries - 1u)) + 16u * k)
+                         : 0u;
         }
     };
     prefetch(toff[0], tcnt[0] & 0x7Fu, nx);
@@ -1300,7 +1306,7 @@ __global__ __launch_bounds__(256) void idct_kernel(JS js)
         __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
         unpack8(*reinterpret_cast<const uint4*>(blk + r * 8), v); // row r
         __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront"); // row reads precede the next iteration's zeroing
-        idct8(v);
+        idct8<0x8000 + (128 << 16)>(v);
 
         uint2 o;
         o.x = finish_pixels(v[0], v[1]) | finish_pixels(v[2], v[3]) << 16;
@@ -1318,7 +1324,7 @@ __global__ __launch_bounds__(256) void idct_kernel(JS js)
             if (r2 < vy && vx > 0) {
                 const uint2 w = s_px[it & 1][j][r2];
                 JG_GLOBAL uint8_t* row = reinterpret_cast<JG_GLOBAL uint8_t*>(
-                    ((static_cast<uint64_t>(g.addr_hi) << 32) | g.addr_lo) + static_cast<uint64_t>(static_cast<uint32_t>(r2) * static_cast<uint32_t>(g.pitch)));
+                    ((static_cast<uint64_t>(g.addr_hi) << 32) | g.addr_lo) + static_cast<uint64_t>(static_cast<uint32_t>(r2)) * static_cast<uint64_t>(static_cast<uint32_t>(g.pitch))); // one v_mad_u64_u32
                 if (vx == 8 && (reinterpret_cast<uintptr_t>(row) & 7) == 0) {
                     st_global(reinterpret_cast<JG_GLOBAL uint2*>(row), w);
                 } else {
