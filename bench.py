@@ -631,7 +631,7 @@ def main():
                                ("config5_12MP_4_components_8_tables_no_dri", jpegsynth.config(5))):
                 r = latency_probe(args, torch, jp, blob, device, streams[0], device_scan=False)
                 others[name] = {"file_bytes": len(blob), "p50_ms": r["p50"], "p50_host_parse_ms": r["p50_host_parse"],
-                                "images_per_s_single_stream": r["images_per_s_single_stream"], "stage_us_device": r["stage_us_device"]}
+                                "max_ms": r["max"], "iters": r["iters"], "stage_us_device": r["stage_us_device"]}
             args.latency_iters = saved
             out["other_configs"] = others
         if args.mode == "batch" and args.e2e_rounds > 0:
