@@ -7,7 +7,7 @@ One "step" = `--rounds` passes of the hot path (destuff -> Huffman sync / write 
 jpeggpu_ext_decode_batch by default or the drop-in jpeggpu_decoder_decode with --mode streams) over the rank's
 batch of 12 MP 4:2:0 restart-interval JPEGs (BASELINE.json configs[1]; with N > 1 the images are sharded by
 rank as in configs[2], no data-path collective in the timed region, weak scaling). The defaults make a step
-1024 images (~50 ms), so the timed region is about a second.
+2048 images (~75 ms), so the timed region is about 1.5 s.
 
 `value` is the rate with inputs (entropy-coded bytes + table blobs) resident in HBM when the timed region
 starts; `value_full_path` is the rate of the whole boundary protocol from pinned host memory (parse_header +
@@ -44,7 +44,7 @@ def parse_args():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=3)
-    ap.add_argument("--batch", type=int, default=128, help="images per GPU per round")
+    ap.add_argument("--batch", type=int, default=256, help="images per GPU per round (4 groups of 64: one launch per stage and group; BASELINE configs[2] is a batch of 64)")
     ap.add_argument("--rounds", type=int, default=8, help="passes over the batch per step (a step = batch * rounds images)")
     ap.add_argument("--mode", default="batch", choices=["batch", "streams"],
                     help="batch: jpeggpu_ext_decode_batch, one launch per stage per group of images; "

@@ -3,7 +3,7 @@
 #   bash tools/collect_profiles.sh r02
 # 1. the bench line of the default command                              -> gpurun_out/<round>_bench_default.json
 # 2. rocprofv3 --kernel-trace --stats of the default command             -> gpurun_out/<round>_stats_default/
-# 3. the same of a run whose batched launches are all SERIALIZED (one stream, 32 images per launch: the shape
+# 3. the same of a run whose batched launches are all SERIALIZED (one stream, 64 images per launch: the shape
 #    of bench.py's roofline leg)                                         -> gpurun_out/<round>_stats_serialized/
 # 4. counter passes over the serialized run, one --pmc group per pass     -> gpurun_out/<round>_pmc_<i>/
 # tools/summarize_profiles.py then writes the summaries into profiles/ (run it here, commit the result).
@@ -11,7 +11,7 @@ set -e
 rnd=$1
 root=${GRAFT_REPO_ROOT:-$(pwd)}
 out=$root/gpurun_out
-ser="--steps 1 --warmup 1 --batch 32 --rounds 4 --streams 1 --unique 4 --no-cpu --no-verify --latency-iters 0 --other-configs 0 --e2e-rounds 0 --roofline-launches 8"
+ser="--steps 1 --warmup 1 --batch 64 --rounds 2 --streams 1 --unique 4 --no-cpu --no-verify --latency-iters 0 --other-configs 0 --e2e-rounds 0 --roofline-launches 8"
 cd /tmp && export TMPDIR=/tmp
 timeout -k 10 500 python3 "$root/bench.py" > "$out/${rnd}_bench_default.json" 2> "$out/${rnd}_bench_default.err"
 echo "bench done"

@@ -11,7 +11,7 @@ for group in "$@"; do
     out=$root/gpurun_out/${tag}_$i
     rm -rf "$out"
     timeout -k 10 150 rocprofv3 --kernel-trace --pmc $group -d "$out" -o bench --output-format csv -- \
-        python3 "$root/bench.py" --steps 1 --warmup 1 --batch 32 --rounds 2 --streams 1 --unique 2 --no-cpu --no-verify --latency-iters 0 --other-configs 0 --e2e-rounds 0 --roofline-launches 3 \
+        python3 "$root/bench.py" --steps 1 --warmup 1 --batch 64 --rounds 1 --streams 1 --unique 2 --no-cpu --no-verify --latency-iters 0 --other-configs 0 --e2e-rounds 0 --roofline-launches 3 \
         > "$out.json" 2> "$out.err"
     python3 "$root/tools/pmc_summary.py" "$out" | tee "$out.txt"
     i=$((i + 1))

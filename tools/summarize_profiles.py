@@ -21,7 +21,7 @@ import sys
 
 KERNELS = r"(destuff_kernel|huff_sync_intra|huff_sync_tail|huff_seq_tails|huff_write|idct_kernel)"
 WIDE_READERS = {"destuff_kernel"}
-IMAGES_PER_LAUNCH = 32
+IMAGES_PER_LAUNCH = 64
 
 
 def counters(d):
@@ -66,13 +66,13 @@ def main():
                          "fetch_kib_per_launch_raw": fetch, "write_kib_per_launch": write, "fetch_multiplier": mult,
                          "images_per_launch": IMAGES_PER_LAUNCH,
                          "valu_insts_per_image": v.get("SQ_INSTS_VALU", 0.0) / IMAGES_PER_LAUNCH,
-                         "command": "tools/collect_profiles.sh %s (serialized run: one stream, 32 images per launch)" % rnd}
+                         "command": "tools/collect_profiles.sh %s (serialized run: one stream, 64 images per launch)" % rnd}
         print("%-18s fetch %10.0f KiB  write %10.0f KiB  -> %7.2f MB/image   VALU %.2f M/image" % (
             name, fetch, write, per / 1e6, v.get("SQ_INSTS_VALU", 0.0) / IMAGES_PER_LAUNCH / 1e6))
     print("total %.1f MB/image" % (total / 1e6))
     json.dump(traffic, open(os.path.join(prof, "pmc_traffic.json"), "w"), indent=1)
-    json.dump(traffic, open(os.path.join(prof, "%s_pmc_traffic_batch32.json" % rnd), "w"), indent=1)
-    json.dump({k: v for k, v in sorted(merged.items())}, open(os.path.join(prof, "%s_pmc_counters_batch32.json" % rnd), "w"), indent=1)
+    json.dump(traffic, open(os.path.join(prof, "%s_pmc_traffic_batch64.json" % rnd), "w"), indent=1)
+    json.dump({k: v for k, v in sorted(merged.items())}, open(os.path.join(prof, "%s_pmc_counters_batch64.json" % rnd), "w"), indent=1)
 
 
 if __name__ == "__main__":
