@@ -74,7 +74,7 @@ def parse_args():
     ap.add_argument("--cpu-seconds", type=float, default=6.0, help="budget of each leg of the CPU baseline")
     ap.add_argument("--no-cpu", action="store_true")
     ap.add_argument("--no-verify", action="store_true")
-    ap.add_argument("--e2e-rounds", type=int, default=8,
+    ap.add_argument("--e2e-rounds", type=int, default=16,
                     help="rounds of the full-path measurement (parse + transfer + decode from pinned host memory); 0 = skip")
     ap.add_argument("--host-threads", type=int, default=6, help="threads of jpeggpu_ext_parse_headers in that measurement")
     return ap.parse_args()
