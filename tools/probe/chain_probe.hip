@@ -21,6 +21,97 @@ __global__ __launch_bounds__(256) void probe(uint64_t* out, int n_iter, int mode
             x = x * 3u + 1u; x ^= x >> 3; x = x * 5u + 7u; x ^= x >> 5;
             asm volatile("" : "+v"(x));
         }
+    } else if (mode == 3) {
+        // four VALU-compare -> scalar-branch round trips per iteration (never taken), 4 VALU besides
+        for (int i = 0; i < n_iter; ++i) {
+            asm volatile(
+                "v_add_u32 %0, 1, %0\n\t"
+                "v_cmp_eq_u32 vcc, 0xdead, %0\n\t"
+                "s_cbranch_vccnz 7f\n\t"
+                "v_add_u32 %0, 1, %0\n\t"
+                "v_cmp_eq_u32 vcc, 0xdead, %0\n\t"
+                "s_cbranch_vccnz 7f\n\t"
+                "v_add_u32 %0, 1, %0\n\t"
+                "v_cmp_eq_u32 vcc, 0xdead, %0\n\t"
+                "s_cbranch_vccnz 7f\n\t"
+                "v_add_u32 %0, 1, %0\n\t"
+                "v_cmp_eq_u32 vcc, 0xdead, %0\n\t"
+                "s_cbranch_vccnz 7f\n"
+                "7:\n\t"
+                : "+v"(x) : : "vcc");
+        }
+    } else if (mode == 4) {
+        // the same four compares feeding exec-mask updates (s_and_b64 exec) and execz branches
+        for (int i = 0; i < n_iter; ++i) {
+            asm volatile(
+                "s_mov_b64 s[20:21], exec\n\t"
+                "v_add_u32 %0, 1, %0\n\t"
+                "v_cmp_ne_u32 vcc, 0xdead, %0\n\t"
+                "s_and_b64 exec, exec, vcc\n\t"
+                "s_cbranch_execz 8f\n\t"
+                "v_add_u32 %0, 1, %0\n\t"
+                "v_cmp_ne_u32 vcc, 0xdead, %0\n\t"
+                "s_and_b64 exec, exec, vcc\n\t"
+                "s_cbranch_execz 8f\n\t"
+                "v_add_u32 %0, 1, %0\n\t"
+                "v_cmp_ne_u32 vcc, 0xdead, %0\n\t"
+                "s_and_b64 exec, exec, vcc\n\t"
+                "s_cbranch_execz 8f\n\t"
+                "v_add_u32 %0, 1, %0\n\t"
+                "v_cmp_ne_u32 vcc, 0xdead, %0\n\t"
+                "s_and_b64 exec, exec, vcc\n\t"
+                "s_cbranch_execz 8f\n"
+                "8:\n\t"
+                "s_mov_b64 exec, s[20:21]\n\t"
+                : "+v"(x) : : "vcc", "s20", "s21");
+        }
+    } else if (mode == 6) {
+        // the step of the hand-scheduled symbol loop (jg_huff_core.h, sync_steps_asm), every look-up a plain hit
+        uint32_t hi = x * 2654435761u, lo = x * 40503u + 7u, sh = 5, zm = 3, p = 0, isdc = 0, shift = 21, tab = 0, plast = 0x7fffffff;
+        uint32_t peek, e, t, zp, total, u, zold;
+        for (int i = threadIdx.x; i < 4096; i += 256) lds[i] = 0x0a050a05u; // length 5, advance 5 (hi = lo half)
+        __syncthreads();
+        for (int i = 0; i < n_iter; ++i) {
+            asm volatile(
+                "v_alignbit_b32 %[peek], %[hi], %[lo], %[sh]\n\t"
+                "v_lshrrev_b32 %[u], %[shift], %[peek]\n\t"
+                "v_lshl_add_u32 %[u], %[u], 2, %[tab]\n\t"
+                "ds_read_b32 %[e], %[u]\n\t"
+                "v_mov_b32 %[zold], %[zm]\n\t"
+                "s_waitcnt lgkmcnt(0)\n\t"
+                "v_bfe_u32 %[t], %[e], 21, 4\n\t"
+                "v_add_u32 %[t], %[zm], %[t]\n\t"
+                "v_cmp_gt_i32 vcc, 63, %[t]\n\t"
+                "v_and_b32 %[t], 31, %[e]\n\t"
+                "v_add_u32 %[t], -1, %[t]\n\t"
+                "v_cndmask_b32_sdwa %[e], %[e], %[e], vcc dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:WORD_0 src1_sel:WORD_1\n\t"
+                "v_lshrrev_b32 %[zp], 9, %[e]\n\t"
+                "v_add_u32 %[zm], %[zm], %[zp]\n\t"
+                "v_and_b32 %[zm], 31, %[zm]\n\t"
+                "v_and_b32 %[total], 31, %[e]\n\t"
+                "v_sub_u32 %[sh], %[sh], %[total]\n\t"
+                "v_and_b32 %[sh], 31, %[sh]\n\t"
+                "v_add_u32 %[p], %[p], %[total]\n\t"
+                "v_sub_u32 %[zp], 62, %[zm]\n\t"
+                "v_or3_b32 %[t], %[t], %[zp], %[isdc]\n\t"
+                "v_sub_u32 %[zp], %[plast], %[p]\n\t"
+                "v_or_b32 %[t], %[t], %[zp]\n\t"
+                "v_or_b32 %[zp], %[t], %[sh]\n\t"
+                "v_cmp_gt_i32 vcc, 0, %[zp]\n\t"
+                "s_cbranch_vccnz 7f\n"
+                "7:\n\t"
+                : [hi] "+v"(hi), [lo] "+v"(lo), [sh] "+v"(sh), [zm] "+v"(zm), [p] "+v"(p), [peek] "=&v"(peek), [e] "=&v"(e), [t] "=&v"(t),
+                  [zp] "=&v"(zp), [total] "=&v"(total), [u] "=&v"(u), [zold] "=&v"(zold)
+                : [isdc] "v"(isdc), [shift] "v"(shift), [tab] "v"(tab), [plast] "v"(plast)
+                : "vcc");
+        }
+        x = p + zm + sh + zold;
+    } else if (mode == 5) {
+        // eight independent-looking VALU adds per iteration, for the plain issue rate
+        for (int i = 0; i < n_iter; ++i) {
+            asm volatile("v_add_u32 %0, 1, %0\n\tv_add_u32 %0, 1, %0\n\tv_add_u32 %0, 1, %0\n\tv_add_u32 %0, 1, %0\n\t"
+                         "v_add_u32 %0, 1, %0\n\tv_add_u32 %0, 1, %0\n\tv_add_u32 %0, 1, %0\n\tv_add_u32 %0, 1, %0\n\t" : "+v"(x));
+        }
     } else {
         for (int i = 0; i < n_iter; ++i) { // LDS read + 8 VALU + a divergent-looking branch
             x = lds[x & 4095u];
@@ -45,10 +136,10 @@ int main()
     const int max_blocks = 4096;
     hipMalloc(&d, max_blocks * 3 * sizeof(uint64_t));
     std::vector<uint64_t> h(max_blocks * 3);
-    for (int blocks : {1, 206, 2048}) {
-        for (int mode = 0; mode < 3; ++mode) {
+    for (int blocks : {206}) {
+        for (int mode : {0, 3, 5, 6}) {
             const int n = 20000;
-            for (int rep = 0; rep < 3; ++rep) {
+            for (int rep = 0; rep < 2; ++rep) {
                 hipEvent_t e0, e1;
                 hipEventCreate(&e0); hipEventCreate(&e1);
                 hipEventRecord(e0, 0);
