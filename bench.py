@@ -7,7 +7,7 @@ One "step" = `--rounds` passes of the hot path (destuff -> Huffman sync / write 
 jpeggpu_ext_decode_batch by default or the drop-in jpeggpu_decoder_decode with --mode streams) over the rank's
 batch of 12 MP 4:2:0 restart-interval JPEGs (BASELINE.json configs[1]; with N > 1 the images are sharded by
 rank as in configs[2], no data-path collective in the timed region, weak scaling). The defaults make a step
-2048 images (~75 ms), so the timed region is about 1.5 s.
+2048 images, so the timed region is about 1.5 s.
 
 `value` is the rate with inputs (entropy-coded bytes + table blobs) resident in HBM when the timed region
 starts; `value_full_path` is the rate of the whole boundary protocol from pinned host memory (parse_header +
@@ -15,9 +15,15 @@ transfer + decode), which the boundary hands over -- never `value`. After the ti
 distinct image are compared with the CPU oracle (`verified`). Rank 0 prints ONE JSON line; DESIGN.md section 4
 defines every field.
 
+`roofline` is the destuff+Huffman PASS the north star names: SURVEY.md 8(d)'s algorithmic bytes of that pass
+(B_dh = stuffed scan bytes + 128 B per data unit) x the images of one launch / the SUM of the average durations of
+the pass's kernels, measured in this run from serialized launches with HIP events on the launch stream, over the
+HBM peak. `kernels` lists every kernel with the bytes it really has to move. `cpu_baseline` is libjpeg-turbo on this
+box's host cores, timed BEFORE this process touches the GPU (its worker processes are spawned, not forked).
+
 For N > 1 the driver launches this file with torch.distributed.run, one rank per GPU (RCCL); the line then also
 carries `gather`: BASELINE.json configs[2] itself -- 64 images sharded over the ranks, decoded, and collected
-on rank 0 with one RCCL gather per round.
+on rank 0, the gather of round k on a side stream while round k + 1 decodes.
 """
 import argparse
 import hashlib
@@ -35,8 +41,12 @@ sys.path.insert(0, ROOT)
 os.environ.setdefault("GPU_MAX_HW_QUEUES", "16")
 
 HBM_PEAK_GBS = 8000.0  # /opt/skills/guides/MI355X_MICROARCH.md: HBM3E 8.0 TB/s (spec)
-KERNEL_NAMES = {"front": "front_windows", "destuff": "destuff_kernel", "sync_intra": "huff_sync_intra",
-                "sync_inter": "huff_sync_tail", "tails": "huff_seq_tails", "write": "huff_write", "idct": "idct_kernel"}
+SIMDS, VALU_CYCLES, SHADER_HZ = 1024, 4, 2.4e9  # 256 CUs x 4 SIMDs; a wave64 VALU instruction issues over 4 cycles
+KERNEL_NAMES = {"front": "front_count+front_prefix+front_marks+front_plan", "destuff": "destuff_kernel",
+                "sync_intra": "huff_sync_intra", "sync_inter": "huff_sync_tail", "tails": "huff_seq_tails",
+                "write": "huff_write", "idct": "idct_kernel"}
+PASS_STAGES = ("front", "destuff", "sync_intra", "sync_inter", "tails", "write")  # "front" only with the device scan
+PHOTO = os.path.join(ROOT, "tests", "golden", "IMG_6510.JPG")
 
 
 def parse_args():
@@ -53,7 +63,7 @@ def parse_args():
                     help="HIP streams (batch mode: groups of images, default 4; streams mode: default 16)")
     ap.add_argument("--unique", type=int, default=16, help="distinct synthetic images per rank (seeded)")
     ap.add_argument("--workload", default="cfg2", choices=["cfg2", "photo"])
-    ap.add_argument("--subseq-bytes", type=int, default=0, help="0 = the library's choice for batches")
+    ap.add_argument("--subseq-bytes", type=int, default=0, help="0 = the library's choice for the call type (jpeggpu_ext.h)")
     ap.add_argument("--overlap", type=int, default=1,
                     help="jpeggpu_ext_batch_set_overlap: concurrent parts per batch call (for --streams 1)")
     ap.add_argument("--sync-iters", type=int, default=0,
@@ -71,6 +81,8 @@ def parse_args():
                     help="serialized launches (one stream, nothing else on the chip) the roofline figures are averaged over; 0 = skip")
     ap.add_argument("--other-configs", type=int, default=10,
                     help="iterations of the latency protocol on BASELINE.json configs[0] (the reference's photo), [3] and [4]; 0 = skip")
+    ap.add_argument("--photo-steps", type=int, default=3,
+                    help="N = 1: steps of the batched protocol of `value` on the reference's photo (other_configs...batch_images_per_s); 0 = skip")
     ap.add_argument("--cpu-seconds", type=float, default=6.0, help="budget of each leg of the CPU baseline")
     ap.add_argument("--no-cpu", action="store_true")
     ap.add_argument("--no-verify", action="store_true")
@@ -85,7 +97,7 @@ def make_images(args, rank, world):
     (unique * world) and is decoded by rank i mod world (jpeggpu_amd.shard), so a rank needs only the
     `unique` seeds of its own shard."""
     if args.workload == "photo":
-        with open(os.path.join(ROOT, "tests", "golden", "IMG_6510.JPG"), "rb") as f:
+        with open(PHOTO, "rb") as f:
             return [f.read()]
     from jpeggpu_amd import shard
     from tools import jpegsynth
@@ -97,8 +109,10 @@ def make_images(args, rank, world):
 class Slot:
     """One image in flight: its decoder, its temporary device memory and its output planes."""
 
-    def __init__(self, torch, jp, data, device, subseq_bytes, planes_flat=None, planes_off=0, device_scan=False):
+    def __init__(self, torch, jp, data, device, subseq_bytes, planes_flat=None, planes_off=0, device_scan=False, batched=False):
         self.dec = jp.Decoder(subseq_bytes or None)
+        if batched and not subseq_bytes:
+            self.dec.set_batched(True)  # the library picks the subsequence size for images that share launches
         if device_scan:
             self.dec.set_device_scan(True)
         self.data = data
@@ -126,33 +140,99 @@ class Slot:
     def decode(self, stream):
         self.dec.decode(self.ptrs, self.pitches, self.base, self.tmp_size, stream)
 
+    def stream_entries(self, torch):
+        """16-bit entries of the symbol stream the write pass emitted for this image (sum of the data-unit table's
+        counts, read back after a decode): what huff_write really stores and idct_kernel really gathers."""
+        total = 0
+        off0 = self.base - self.tmp.data_ptr()
+        for s in range(self.layout.num_scans):
+            sc = self.layout.scans[s]
+            raw = self.tmp[off0 + sc.off_du_table: off0 + sc.off_du_table + 8 * sc.num_data_units]
+            total += int((raw.view(torch.int32).view(-1, 2)[:, 1] & 0x7F).sum().item())
+        return total
 
-def algorithmic_bytes(slot):
-    """SURVEY.md 8(d): destuff+Huffman pass B_dh = stuffed scan bytes + 128 B per data unit;
-    end-to-end B_e2e = stuffed scan bytes + plane bytes. Plus each kernel's own bytes."""
+
+class BatchSet:
+    """`batch` images of a rank, resident in HBM, in `nstreams` groups: each group is one jpeggpu_ext_decode_batch call
+    per round on its own stream (--mode streams: the drop-in call, one image per call)."""
+
+    def __init__(self, args, torch, jp, images, device, streams, batch):
+        self.args, self.streams = args, streams
+        nstreams = len(streams)
+        batched = args.mode == "batch"
+        probe = Slot(torch, jp, images[0], device, args.subseq_bytes, device_scan=bool(args.device_scan), batched=batched)
+        self.per_image = probe.plane_bytes
+        probe.dec.cleanup()
+        # all planes of the rank's batch live in one flat tensor so that a gather is one collective
+        self.planes_flat = torch.empty(self.per_image * batch, dtype=torch.uint8, device=device)
+        self.slots = [Slot(torch, jp, images[i % len(images)], device, args.subseq_bytes, self.planes_flat, i * self.per_image,
+                           device_scan=bool(args.device_scan), batched=batched) for i in range(batch)]
+        for i, s in enumerate(self.slots):
+            s.transfer(streams[i % nstreams].cuda_stream)
+        torch.cuda.synchronize()
+        self.groups = []
+        if batched:
+            for g in range(nstreams):
+                mine = self.slots[g::nstreams]
+                bt = jp.Batch(sum(s.layout.num_scans for s in mine))
+                scratch = torch.empty(bt.scratch_size, dtype=torch.uint8, device=device)
+                bt.set_items([(s.dec, s.ptrs, s.pitches, s.base, s.tmp_size) for s in mine])
+                if args.sync_iters > 0:
+                    bt.set_sync_iterations(args.sync_iters)
+                bt.set_overlap(args.overlap)
+                self.groups.append((bt, scratch, streams[g], len(mine)))
+
+    def one_round(self):
+        if self.groups:
+            for bt, scratch, st, _ in self.groups:
+                bt.decode(scratch.data_ptr(), st.cuda_stream)
+        else:
+            for i, s in enumerate(self.slots):
+                s.decode(self.streams[i % len(self.streams)].cuda_stream)
+
+    def step(self):
+        for _ in range(self.args.rounds):
+            self.one_round()
+
+    def destroy(self):
+        for bt, _, _, _ in self.groups:
+            bt.destroy()
+        for s in self.slots:
+            s.dec.cleanup()
+
+
+def algorithmic_bytes(slot, entries):
+    """destuff+Huffman pass B_dh = stuffed scan bytes + 128 B per data unit; end-to-end B_e2e =
+    stuffed scan bytes + plane bytes. And per kernel the bytes it has to move in THIS design:
+    `entries` 16-bit symbol-stream entries per image (measured), an 8-byte record per data unit."""
     lay = slot.layout
     stuffed = lay.transferred_bytes
     ndu = sum(lay.scans[s].num_data_units for s in range(lay.num_scans))
     nsub = sum(lay.scans[s].num_subsequences for s in range(lay.num_scans))
+    sb = lay.subsequence_bytes
     return {
         "stuffed": stuffed,
         "b_dh": stuffed + 128 * ndu,
         "b_e2e": stuffed + slot.plane_bytes,
         "front": stuffed,
-        "destuff": 2 * stuffed,
+        # stuffed bytes in, padded rows (own words + 3 mirrored ones) and the subsequence -> segment map out
+        "destuff": stuffed + nsub * (sb + 12) + nsub * 4,
         # sync_intra: destuffed bytes read once + subsequence->segment map read + 21 B of state written
-        "sync_intra": nsub * lay.subsequence_bytes + nsub * 4 + nsub * 21,
+        "sync_intra": nsub * sb + nsub * 4 + nsub * 21,
         # sync_tail: about one subsequence of bitstream per subsequence (the live flows decay
         # geometrically, summing to ~0.9 lane-passes) + state read and written
-        "sync_inter": nsub * lay.subsequence_bytes + nsub * 40,
+        "sync_inter": nsub * sb + nsub * 40,
         "tails": nsub * 16,
-        # write pass: destuffed bytes + state read, coefficient buffer written (128 B per data unit)
-        "write": nsub * lay.subsequence_bytes + nsub * 24 + 128 * ndu,
-        "idct": 128 * ndu + slot.plane_bytes,
+        # write pass: destuffed bytes + state in, symbol stream + data-unit table out
+        "write": nsub * sb + nsub * 24 + 2 * entries + 8 * ndu,
+        # IDCT: symbol stream + data-unit table in, planes out
+        "idct": 2 * entries + 8 * ndu + slot.plane_bytes,
     }
 
 
-def _turbo_decode(data):
+# ---- CPU baseline: runs before this process touches the GPU ---------------------------------------------------------
+
+def _pillow_decode(data):
     import io
 
     from PIL import Image
@@ -162,11 +242,79 @@ def _turbo_decode(data):
     im.load()
 
 
-def _turbo_worker(args):
-    data, seconds = args
+_TJ = None
+
+
+def _turbojpeg():
+    """libturbojpeg's planes-only decode (tjDecompressToYUVPlanes: entropy decode + IDCT, no upsampling, no colour
+    conversion -- the closest CPU counterpart of this path), bound with ctypes; None when the library is not installed."""
+    global _TJ
+    if _TJ is not None:
+        return _TJ or None
+    import ctypes as C
+
+    _TJ = False
+    for name in ("libturbojpeg.so.0", "libturbojpeg.so"):
+        try:
+            L = C.CDLL(name)
+        except OSError:
+            continue
+        try:
+            L.tjInitDecompress.restype = C.c_void_p
+            L.tjDecompressHeader3.argtypes = [C.c_void_p, C.c_char_p, C.c_ulong] + [C.POINTER(C.c_int)] * 4
+            L.tjDecompressToYUVPlanes.argtypes = [C.c_void_p, C.c_char_p, C.c_ulong, C.POINTER(C.c_void_p), C.c_int,
+                                                  C.POINTER(C.c_int), C.c_int, C.c_int]
+            L.tjPlaneWidth.argtypes = L.tjPlaneHeight.argtypes = [C.c_int, C.c_int, C.c_int]
+            handle = L.tjInitDecompress()
+            if handle:
+                _TJ = (L, handle)
+                break
+        except AttributeError:
+            continue
+    return _TJ or None
+
+
+def _tj_decode(data, state={}):
+    import ctypes as C
+
+    L, h = _turbojpeg()
+    w, hgt, ss, cs = C.c_int(), C.c_int(), C.c_int(), C.c_int()
+    if L.tjDecompressHeader3(h, data, len(data), C.byref(w), C.byref(hgt), C.byref(ss), C.byref(cs)) != 0:
+        raise RuntimeError("tjDecompressHeader3 failed")
+    key = (w.value, hgt.value, ss.value)
+    if key not in state:
+        bufs = [C.create_string_buffer(L.tjPlaneWidth(c, w.value, ss.value) * L.tjPlaneHeight(c, hgt.value, ss.value)) for c in range(3)]
+        state.clear()
+        state[key] = (bufs, (C.c_void_p * 3)(*[C.cast(b, C.c_void_p) for b in bufs]))
+    _, planes = state[key]
+    if L.tjDecompressToYUVPlanes(h, data, len(data), planes, w.value, None, hgt.value, 0) != 0:
+        raise RuntimeError("tjDecompressToYUVPlanes failed")
+
+
+def _turbo_backend():
+    """(name, decode function, version) of the libjpeg-turbo decode available on this box, or None. Probe order of
+    SURVEY.md 8(d): the TurboJPEG API's planes-only decode, then Pillow (libjpeg-turbo inside, YCbCr draft mode:
+    planes at full resolution, i.e. including its chroma upsampling)."""
+    if _turbojpeg():
+        return "libturbojpeg tjDecompressToYUVPlanes (planes only)", _tj_decode, "turbojpeg"
+    try:
+        from PIL import features
+
+        ver = features.version_feature("libjpeg_turbo")
+        if ver:
+            return "Pillow draft('YCbCr') on libjpeg-turbo %s (planes incl. chroma upsampling)" % ver, _pillow_decode, ver
+    except Exception:
+        pass
+    return None
+
+
+def _turbo_worker(job):
+    data, seconds = job
+    _, fn, _ = _turbo_backend()
+    fn(data)
     n, t0 = 0, time.perf_counter()
     while time.perf_counter() - t0 < seconds and n < 256:
-        _turbo_decode(data)
+        fn(data)
         n += 1
     return n, time.perf_counter() - t0
 
@@ -189,9 +337,10 @@ def usable_cores():
 
 
 def cpu_baseline(args, data):
-    """CPU decodes of the same 12 MP image on this box's host cores, bounded samples: the oracle (scalar C port
-    of the reference's arithmetic, `kind: port`) on one core, and libjpeg-turbo (through Pillow: planes in
-    YCbCr, which includes its chroma upsampling) on one core and on every core the process may use."""
+    """CPU decodes of the same 12 MP image on this box's host cores, bounded samples. `value` is libjpeg-turbo on ONE
+    core (`kind` names the entry point that was found); `all_cores_value` the same on every core this process may use,
+    one image stream per spawned worker process; `port_value` the oracle (scalar C restatement of the reference's
+    arithmetic, oracle/jpeg_oracle.c) on one core -- also the fallback for `value` when no libjpeg-turbo is installed."""
     from oracle import oracle
 
     oracle.decode(data)  # warm (page in the library)
@@ -202,30 +351,32 @@ def cpu_baseline(args, data):
         dt = time.perf_counter() - t0
         if dt >= args.cpu_seconds or n >= 64:
             break
-    out = {"value": n / dt, "unit": "images/s", "cores": 1, "kind": "port",
-           "sample": "%d sequential decodes of one 12 MP image by oracle/jpeg_oracle.c, %.1f s" % (n, dt)}
+    port = {"value": n / dt, "sample": "%d sequential decodes of one 12 MP image by oracle/jpeg_oracle.c, %.1f s" % (n, dt)}
+    out = {"value": port["value"], "unit": "images/s", "cores": 1, "kind": "port", "sample": port["sample"],
+           "port_value": port["value"]}
     try:
-        from PIL import features
-
-        ver = features.version_feature("libjpeg_turbo")
-        if ver:
-            _turbo_decode(data)
-            m, dt1 = _turbo_worker((data, min(4.0, args.cpu_seconds)))
-            out["libjpeg_turbo_1_thread"] = {
-                "value": m / dt1, "unit": "images/s", "cores": 1, "version": ver,
-                "sample": "%d Pillow decodes of the same image (YCbCr planes, incl. chroma upsampling), %.1f s" % (m, dt1)}
+        backend = _turbo_backend()
+        if backend:
+            name, _, ver = backend
+            budget = min(4.0, args.cpu_seconds)
+            m, dt1 = _turbo_worker((data, budget))
+            out.update({"value": m / dt1, "kind": "libjpeg-turbo: " + name, "version": ver,
+                        "sample": "%d decodes of the same 12 MP image on one core, %.1f s" % (m, dt1)})
             cores = usable_cores()
             import multiprocessing as mp
 
-            with mp.get_context("fork").Pool(cores) as pool:
+            # spawned, not forked: the children never inherit anything of a GPU runtime (and this runs before the
+            # parent has one)
+            with mp.get_context("spawn").Pool(cores) as pool:
                 t1 = time.perf_counter()
-                res = pool.map(_turbo_worker, [(data, min(4.0, args.cpu_seconds))] * cores)
+                res = pool.map(_turbo_worker, [(data, budget)] * cores)
                 wall = time.perf_counter() - t1
             total = sum(r[0] for r in res)
-            out["libjpeg_turbo_all_cores"] = {
-                "value": total / wall, "unit": "images/s", "cores": cores, "version": ver,
-                "sample": "%d processes, one image stream each, %d decodes in %.1f s" % (cores, total, wall)}
-    except Exception as e:  # Pillow is optional on the box
+            rate = sum(r[0] / r[1] for r in res)  # per-worker rates: the pool's start-up is not decode time
+            out["all_cores_value"] = rate
+            out["all_cores"] = cores
+            out["all_cores_sample"] = "%d spawned processes, one image stream each, %d decodes, %.1f s wall incl. start-up" % (cores, total, wall)
+    except Exception as e:  # libjpeg-turbo is optional on the box
         out["libjpeg_turbo_error"] = repr(e)
     return out
 
@@ -305,7 +456,7 @@ def latency_probe(args, torch, jp, data, device, stream, device_scan):
     return out
 
 
-def verify(args, slots, images, torch):
+def verify(slots, torch):
     """Planes of one slot per distinct image against the CPU oracle, after the timed loop: the timed launches
     did the work the number claims."""
     from oracle import oracle
@@ -324,14 +475,236 @@ def verify(args, slots, images, torch):
     return len(seen), bad
 
 
+def timed_steps(torch, bset, steps, warmup, barrier):
+    """W untimed steps, then K steps bracketed by barrier + synchronize on both sides; seconds of the K steps."""
+    for p in bset.planes_flat.split(1 << 30):
+        p.zero_()  # the planes hold nothing a previous run could have left behind
+    for _ in range(warmup):
+        bset.step()
+    torch.cuda.synchronize()
+    barrier()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        bset.step()
+    torch.cuda.synchronize()
+    barrier()
+    torch.cuda.synchronize()
+    return time.perf_counter() - t0
+
+
+def serialized_stage_us(args, bset):
+    """Average duration of every stage over `--roofline-launches` launches of ONE group (64 images by default) on one
+    stream with nothing else on the chip: HIP events the library records on the launch stream between its launches."""
+    bt, scratch, st, images_per_launch = bset.groups[0]
+    bt.set_profiling(True)
+    for _ in range(args.roofline_launches):
+        bt.decode(scratch.data_ptr(), st.cuda_stream)
+        st.synchronize()
+    us = {k: v * 1e3 for k, v in bt.stage_ms().items()}
+    bt.set_profiling(False)
+    return us, images_per_launch
+
+
+def committed_profile(name):
+    """A summary under profiles/ written by tools/summarize_profiles.py from rocprofv3 --pmc passes over the serialized
+    run (counters cannot be read from inside this process); {} when it is not there."""
+    try:
+        with open(os.path.join(ROOT, "profiles", name)) as f:
+            return json.load(f)
+    except Exception:
+        return {}
+
+
+def roofline_report(args, slot, stage_us, images_per_launch, entries, value, world):
+    """The `roofline` and `kernels` objects (module docstring)."""
+    ab = algorithmic_bytes(slot, entries)
+    device_scan = bool(slot.layout.scans[0].device_scan)
+    stages = [k for k in stage_us if k != "front" or device_scan]  # without the device scan "front" is a 24-us descriptor copy, not a kernel
+    traffic = committed_profile("pmc_traffic.json")
+    counters = committed_profile("pmc_counters.json")
+    kernels = {}
+    for k in stages:
+        us = stage_us[k]
+        name = KERNEL_NAMES[k]
+        t = traffic.get(name.split("+")[0], {}).get("per_image_bytes")
+        valu = counters.get(name.split("+")[0], {}).get("SQ_INSTS_VALU")
+        kernels[name] = {
+            "avg_launch_us": us, "own_bytes_per_launch": ab[k] * images_per_launch,
+            "own_GBs": ab[k] * images_per_launch / (us * 1e-6) / 1e9 if us > 0 else None,
+            "own_frac_of_hbm_peak": ab[k] * images_per_launch / (us * 1e-6) / 1e9 / HBM_PEAK_GBS if us > 0 else None,
+            "traffic_bytes_per_launch": t * images_per_launch if t else None,
+            "valu_issue_util": valu * VALU_CYCLES / (SIMDS * SHADER_HZ * us * 1e-6) if valu and us > 0 else None}
+    in_pass = [k for k in stages if k in PASS_STAGES]
+    t_pass_us = sum(stage_us[k] for k in in_pass)
+    pass_traffic = [kernels[KERNEL_NAMES[k]]["traffic_bytes_per_launch"] for k in in_pass]
+    pass_valu = [counters.get(KERNEL_NAMES[k].split("+")[0], {}).get("SQ_INSTS_VALU") for k in in_pass]
+    bytes_per_launch = ab["b_dh"] * images_per_launch
+    roofline = None
+    if t_pass_us > 0:
+        achieved = bytes_per_launch / (t_pass_us * 1e-6) / 1e9
+        roofline = {
+            "bound": "hbm", "limiter": "valu-issue",
+            "kernel": "destuff+Huffman pass: " + " + ".join(KERNEL_NAMES[k] for k in in_pass),
+            "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
+            "traffic": sum(pass_traffic) if all(pass_traffic) else None,
+            "traffic_source": "profiles/pmc_traffic.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes over the same serialized "
+                              "launches, per-shape calibration of profiles/*_fetch_calibration.json)",
+            "algorithmic_bytes_per_launch": bytes_per_launch, "algorithmic_bytes_per_image": ab["b_dh"],
+            "avg_launch_us": t_pass_us, "images_per_launch": images_per_launch,
+            "valu_issue_util": (sum(pass_valu) * VALU_CYCLES / (SIMDS * SHADER_HZ * t_pass_us * 1e-6)) if all(pass_valu) else None,
+            "frac_at_throughput": ab["b_dh"] * value / world / 1e9 / HBM_PEAK_GBS,
+            "what": "B_dh = stuffed scan bytes + 128 B per data unit (SURVEY.md 8d) x images per launch / SUM of the serialized "
+                    "average durations of the pass's kernels / HBM peak; the kernels are bound by vector-instruction issue "
+                    "(valu_issue_util: SQ_INSTS_VALU of profiles/pmc_counters.json x 4 cycles / (1024 SIMDs x 2.4 GHz x this time))",
+            "measured": "HIP events on the launch stream, %d serialized launches of %d images, one stream"
+                        % (args.roofline_launches, images_per_launch)}
+    e2e = {"bytes_per_image": ab["b_e2e"], "throughput_GBs": ab["b_e2e"] * value / world / 1e9,
+           "frac_of_hbm_peak": ab["b_e2e"] * value / world / 1e9 / HBM_PEAK_GBS}
+    return roofline, kernels, e2e, ab
+
+
+def gather_leg(args, torch, dist, jp, shard, bset, streams, device, rank, world, backend, barrier, max_over_ranks):
+    """BASELINE.json configs[2]: 64 images over the ranks (image i -> rank i mod N), decoded, planes collected on rank 0.
+    Double-buffered: round k decodes into plane buffer k % 2 on the decode stream, its gather runs on a side stream
+    (RCCL's own stream behind it) while round k + 1 decodes into the other buffer. Three timings, same rounds each:
+    decode alone, gather alone, the pipeline."""
+    per_rank = max(1, min(64 // world, args.batch))
+    per_image = bset.per_image
+    mine = bset.slots[:per_rank]
+    on_gpu = backend == "nccl"
+    nbytes = per_rank * per_image
+    bufs = [bset.planes_flat[:nbytes], torch.empty(nbytes, dtype=torch.uint8, device=device)]
+    bts, scratches = [], []
+    for b in range(2):
+        items = []
+        for i, s in enumerate(mine):
+            ptrs, o = [], bufs[b].data_ptr() + i * per_image
+            for p in s.planes:
+                ptrs.append(o)
+                o += p.numel()
+            items.append((s.dec, ptrs, s.pitches, s.base, s.tmp_size))
+        bt = jp.Batch(sum(s.layout.num_scans for s in mine))
+        bt.set_items(items)
+        bt.set_overlap(2 if per_rank >= 8 else 1)  # a rank's 8 images fill a sixth of the chip: two parts hide each other's sync tail
+        bts.append(bt)
+        scratches.append(torch.empty(bt.scratch_size, dtype=torch.uint8, device=device))
+    gl = [None, None]
+    if rank == 0:
+        gl = [[torch.empty(nbytes, dtype=torch.uint8, device=device if on_gpu else "cpu") for _ in range(world)] for _ in range(2)]
+    dec_st, comm_st = streams[0], streams[1 % len(streams)] if len(streams) > 1 else torch.cuda.Stream(device=device)
+    decoded = [torch.cuda.Event() for _ in range(2)]
+    gathered = [torch.cuda.Event() for _ in range(2)]
+
+    def decode(b):
+        bts[b].decode(scratches[b].data_ptr(), dec_st.cuda_stream)
+
+    def gather(b):
+        if on_gpu:
+            with torch.cuda.stream(comm_st):
+                shard.gather_planes(bufs[b], rank, world, dst=0, gather_list=gl[b])
+        else:  # gloo rehearsal: the collective runs on CPU tensors
+            comm_st.synchronize()
+            shard.gather_planes(bufs[b].cpu(), rank, world, dst=0, gather_list=gl[b])
+
+    def timed(fn):
+        fn(0)
+        torch.cuda.synchronize()
+        barrier()
+        t1 = time.perf_counter()
+        for k in range(args.gather_rounds):
+            fn(k)
+        torch.cuda.synchronize()
+        barrier()
+        return max_over_ranks(time.perf_counter() - t1) / args.gather_rounds * 1e3
+
+    def pipelined(k):
+        b = k % 2
+        dec_st.wait_event(gathered[b])  # the gather that read this buffer two rounds ago is done
+        decode(b)
+        decoded[b].record(dec_st)
+        comm_st.wait_event(decoded[b])
+        gather(b)
+        gathered[b].record(comm_st)
+
+    decode_ms = timed(lambda k: decode(k % 2))
+    gather_ms = timed(lambda k: gather(k % 2))
+    overlapped_ms = timed(pipelined)
+
+    # what arrived on rank 0 is what every rank sent: 64-bit wrapping sums of the buffers, exchanged separately
+    def checksum(t):
+        return int(t[: t.numel() // 8 * 8].view(torch.int64).sum().item())
+
+    ok = True
+    for b in range(2):
+        mine_sum = torch.tensor([checksum(bufs[b])], dtype=torch.int64, device=device if on_gpu else "cpu")
+        sums = [torch.zeros_like(mine_sum) for _ in range(world)]
+        dist.all_gather(sums, mine_sum)
+        if rank == 0:
+            ok = ok and all(checksum(gl[b][r]) == int(sums[r].item()) for r in range(world))
+    for bt in bts:
+        bt.destroy()
+    return {"what": "BASELINE.json configs[2]: 64 x 12 MP 4:2:0 sharded over the ranks (image i -> rank i mod N), decoded, planes "
+                    "gathered on rank 0; the gather of round k overlaps the decode of round k + 1 (two plane buffers, side stream)",
+            "images_per_round": per_rank * world, "rounds": args.gather_rounds,
+            "value": per_rank * world / (overlapped_ms * 1e-3), "unit": "images/s",
+            "decode_ms": decode_ms, "gather_ms": gather_ms, "overlapped_ms": overlapped_ms, "ms_per_round": overlapped_ms,
+            "bytes_per_rank": nbytes, "backend": backend, "gathered_buffers_match_senders": ok}
+
+
+def segment_shard_leg(args, torch, dist, jp, shard, streams, device, rank, world, backend, barrier, max_over_ranks):
+    """Restart-interval sharding of ONE large image (second bullet): 39 MP 4:2:0 (the size of
+    BASELINE.json configs[3]) with one restart interval per MCU row; rank r decodes segments [r n / N, (r + 1) n / N)
+    into its band of the planes (jpeggpu_ext_set_segment_shard), bands gathered on rank 0."""
+    from tools import jpegsynth
+
+    big = jpegsynth.encode(7216, 5408, ((2, 2), (1, 1), (1, 1)), True, (7216 + 15) // 16, quality=88, noise=9, seed=4242)
+    dec = jp.Decoder()
+    dec.set_batched(True)
+    dec.set_segment_shard(rank, world)
+    info = dec.parse_header(big)
+    n = dec.get_buffer_size()
+    tmp = torch.empty(n + 256, dtype=torch.uint8, device=device)
+    base = (tmp.data_ptr() + 255) // 256 * 256
+    shapes = [(info.sizes_y[c], info.sizes_x[c]) for c in range(info.num_components)]
+    full = [torch.zeros(h, w, dtype=torch.uint8, device=device) for h, w in shapes]
+    rows = [dec.shard_rows(c) for c in range(info.num_components)]
+    st = streams[0]
+    on_gpu = backend == "nccl"
+    dec.transfer(base, n, st.cuda_stream)
+    all_rows = [None] * world
+    dist.all_gather_object(all_rows, rows)
+
+    def shard_round():
+        with torch.cuda.stream(st):
+            dec.decode([p.data_ptr() for p in full], [p.stride(0) for p in full], base, n, st.cuda_stream)
+            band = torch.cat([full[c][a:a + k].reshape(-1) for c, (a, k) in enumerate(rows)])
+            return shard.gather_bands(band if on_gpu else band.cpu(), rank, world, dst=0)
+
+    bands = shard_round()
+    torch.cuda.synchronize()
+    barrier()
+    t1 = time.perf_counter()
+    for _ in range(args.segment_shard_rounds):
+        bands = shard_round()
+    torch.cuda.synchronize()
+    barrier()
+    dt = max_over_ranks(time.perf_counter() - t1)
+    ok = None
+    if rank == 0:  # the assembled image against this GPU's own decode of the whole file
+        got = shard.assemble_bands(bands, all_rows, shapes)
+        whole, _ = jp.decode_to_planes(big, device=str(device))
+        ok = all(bool(torch.equal(got[c].to(device), whole[c])) for c in range(len(shapes)))
+    dec.cleanup()
+    return {"what": "ONE 7216x5408 4:2:0 image (39 MP, DRI = one MCU row) over the ranks by restart segments, "
+                    "bands gathered on rank 0", "file_bytes": len(big), "rounds": args.segment_shard_rounds,
+            "value": args.segment_shard_rounds / dt, "unit": "images/s", "ms_per_image": dt / args.segment_shard_rounds * 1e3,
+            "rows_of_plane_0_per_rank": [r[0] for r in all_rows], "backend": backend,
+            "assembled_equals_whole_decode": ok}
+
+
 def main():
     args = parse_args()
-    import torch
-    import torch.distributed as dist
-
-    import jpeggpu_amd as jp
-    from jpeggpu_amd import shard
-
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -339,6 +712,20 @@ def main():
         if world == 1 and args.gpus > 1:
             raise SystemExit("bench.py --gpus %d must be launched with torch.distributed.run" % args.gpus)
         args.gpus = world
+
+    images = make_images(args, rank, world)
+    # CPU baseline: rank 0 at N = 1 only, and FIRST -- before this process has initialised HIP or RCCL, so that its
+    # worker processes start from a parent without a GPU runtime
+    cpu = None
+    if rank == 0 and world == 1 and not args.no_cpu:
+        cpu = cpu_baseline(args, images[0])
+
+    import torch
+    import torch.distributed as dist
+
+    import jpeggpu_amd as jp
+    from jpeggpu_amd import shard
+
     assert torch.cuda.is_available(), "bench.py needs a HIP device (there is no CPU fallback)"
     # JPEGGPU_BENCH_BACKEND=gloo rehearses the N > 1 control flow on a box with fewer GPUs than ranks
     # (ranks share devices, collectives on CPU tensors); the driver's runs use nccl (= RCCL).
@@ -353,53 +740,10 @@ def main():
         else:
             dist.init_process_group(backend)
 
-    images = make_images(args, rank, world)
     if args.streams <= 0:
         args.streams = 4 if args.mode == "batch" else 16
     nstreams = max(1, min(args.streams, args.batch))
     streams = [torch.cuda.Stream(device=device) for _ in range(nstreams)]
-    if args.subseq_bytes == 0 and args.mode == "batch":
-        args.subseq_bytes = jp.BATCH_SUBSEQ_BYTES
-
-    # all planes of the rank's batch live in one flat tensor so that a gather is one collective
-    probe = Slot(torch, jp, images[0], device, args.subseq_bytes, device_scan=bool(args.device_scan))
-    per_image = probe.plane_bytes
-    planes_flat = torch.empty(per_image * args.batch, dtype=torch.uint8, device=device)
-    slots = [Slot(torch, jp, images[i % len(images)], device, args.subseq_bytes, planes_flat, i * per_image,
-                  device_scan=bool(args.device_scan))
-             for i in range(args.batch)]
-    probe.dec.cleanup()
-    del probe
-    for i, s in enumerate(slots):
-        s.transfer(streams[i % nstreams].cuda_stream)
-    torch.cuda.synchronize()
-
-    # batch mode: the rank's images are split into `nstreams` groups, each group is one
-    # jpeggpu_ext_decode_batch call (7 launches) on its own stream
-    groups = []
-    if args.mode == "batch":
-        for g in range(nstreams):
-            mine = slots[g::nstreams]
-            nscans = sum(s.layout.num_scans for s in mine)
-            bt = jp.Batch(nscans)
-            scratch = torch.empty(bt.scratch_size, dtype=torch.uint8, device=device)
-            bt.set_items([(s.dec, s.ptrs, s.pitches, s.base, s.tmp_size) for s in mine])
-            if args.sync_iters > 0:
-                bt.set_sync_iterations(args.sync_iters)
-            bt.set_overlap(args.overlap)
-            groups.append((bt, scratch, streams[g], len(mine)))
-
-    def one_round():
-        if args.mode == "batch":
-            for bt, scratch, st, _ in groups:
-                bt.decode(scratch.data_ptr(), st.cuda_stream)
-        else:
-            for i, s in enumerate(slots):
-                s.decode(streams[i % nstreams].cuda_stream)
-
-    def step():
-        for _ in range(args.rounds):
-            one_round()
 
     def barrier():
         if world > 1:
@@ -412,21 +756,9 @@ def main():
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         return float(t.item())
 
-    for p in planes_flat.split(1 << 30):
-        p.zero_()  # the planes hold nothing a previous run could have left behind
-    for _ in range(args.warmup):
-        step()
-    torch.cuda.synchronize()
-    barrier()
-    torch.cuda.synchronize()
-    t0 = time.perf_counter()
-    for _ in range(args.steps):
-        step()
-    torch.cuda.synchronize()
-    barrier()
-    torch.cuda.synchronize()
-    elapsed = max_over_ranks(time.perf_counter() - t0)
-
+    bset = BatchSet(args, torch, jp, images, device, streams, args.batch)
+    slots = bset.slots
+    elapsed = max_over_ranks(timed_steps(torch, bset, args.steps, args.warmup, barrier))
     ms_per_step = elapsed / args.steps * 1e3
     images_per_step = world * args.batch * args.rounds
     value = images_per_step * args.steps / elapsed
@@ -434,7 +766,7 @@ def main():
     # every distinct image of the timed batch against the oracle
     verified, nverified = None, 0
     if not args.no_verify:
-        nverified, bad = verify(args, slots, images, torch)
+        nverified, bad = verify(slots, torch)
         ok = 0.0 if bad else 1.0
         if world > 1:
             ok = -max_over_ranks(-ok)  # min over ranks
@@ -442,155 +774,37 @@ def main():
         if bad:
             sys.stderr.write("bench: planes differ from the oracle: %r\n" % (bad[:8],))
 
-    # BASELINE.json configs[2]: 64 images over the ranks, decoded and gathered on rank 0
     gather = None
     if world > 1 and args.gather_rounds > 0 and args.mode == "batch":
-        per_rank = max(1, min(64 // world, args.batch))
-        mine = slots[:per_rank]
-        bt = jp.Batch(sum(s.layout.num_scans for s in mine))
-        scratch = torch.empty(bt.scratch_size, dtype=torch.uint8, device=device)
-        bt.set_items([(s.dec, s.ptrs, s.pitches, s.base, s.tmp_size) for s in mine])
-        bt.set_overlap(min(4, max(1, per_rank // 8)))
-        send = planes_flat[: per_rank * per_image]
-        on_gpu = backend == "nccl"
-        gl = None
-        if rank == 0:
-            gl = [torch.empty(per_rank * per_image, dtype=torch.uint8, device=device if on_gpu else "cpu") for _ in range(world)]
-        st = streams[0]
-
-        def gather_round():
-            with torch.cuda.stream(st):
-                bt.decode(scratch.data_ptr(), st.cuda_stream)
-                shard.gather_planes(send if on_gpu else send.cpu(), rank, world, dst=0, gather_list=gl)
-
-        gather_round()
-        torch.cuda.synchronize()
-        barrier()
-        t1 = time.perf_counter()
-        for _ in range(args.gather_rounds):
-            gather_round()
-        torch.cuda.synchronize()
-        barrier()
-        dt = max_over_ranks(time.perf_counter() - t1)
-        # what arrived on rank 0 is what every rank sent: 64-bit wrapping sums of the buffers, exchanged separately
-        def checksum(t):
-            return int(t[: t.numel() // 8 * 8].view(torch.int64).sum().item())
-
-        mine_sum = torch.tensor([checksum(send)], dtype=torch.int64, device=device if on_gpu else "cpu")
-        sums = [torch.zeros_like(mine_sum) for _ in range(world)]
-        dist.all_gather(sums, mine_sum)
-        ok = True
-        if rank == 0:
-            ok = all(checksum(gl[r]) == int(sums[r].item()) for r in range(world))
-        gather = {"what": "BASELINE.json configs[2]: 64 x 12 MP 4:2:0 sharded over the ranks (image i -> rank i mod N), "
-                          "decoded, planes gathered on rank 0 (one RCCL gather per round)",
-                  "images_per_round": per_rank * world, "rounds": args.gather_rounds,
-                  "value": per_rank * world * args.gather_rounds / dt, "unit": "images/s",
-                  "ms_per_round": dt / args.gather_rounds * 1e3, "bytes_per_rank": per_rank * per_image,
-                  "backend": backend, "gathered_buffers_match_senders": ok}
-        bt.destroy()
-
-    # Restart-interval sharding of ONE large image (second bullet): 39 MP 4:2:0 (the size of
-    # BASELINE.json configs[3]) with one restart interval per MCU row; rank r decodes segments [r n / N, (r + 1) n / N)
-    # into its band of the planes (jpeggpu_ext_set_segment_shard), bands gathered on rank 0.
+        gather = gather_leg(args, torch, dist, jp, shard, bset, streams, device, rank, world, backend, barrier, max_over_ranks)
     segment_shard = None
     if world > 1 and args.segment_shard_rounds > 0:
-        from tools import jpegsynth
-
-        big = jpegsynth.encode(7216, 5408, ((2, 2), (1, 1), (1, 1)), True, (7216 + 15) // 16, quality=88, noise=9, seed=4242)
-        dec = jp.Decoder(jp.BATCH_SUBSEQ_BYTES)
-        dec.set_segment_shard(rank, world)
-        info = dec.parse_header(big)
-        n = dec.get_buffer_size()
-        tmp = torch.empty(n + 256, dtype=torch.uint8, device=device)
-        base = (tmp.data_ptr() + 255) // 256 * 256
-        shapes = [(info.sizes_y[c], info.sizes_x[c]) for c in range(info.num_components)]
-        full = [torch.zeros(h, w, dtype=torch.uint8, device=device) for h, w in shapes]
-        rows = [dec.shard_rows(c) for c in range(info.num_components)]
-        st = streams[0]
-        on_gpu = backend == "nccl"
-        dec.transfer(base, n, st.cuda_stream)
-        all_rows = [None] * world
-        dist.all_gather_object(all_rows, rows)
-
-        def shard_round():
-            with torch.cuda.stream(st):
-                dec.decode([p.data_ptr() for p in full], [p.stride(0) for p in full], base, n, st.cuda_stream)
-                band = torch.cat([full[c][a:a + k].reshape(-1) for c, (a, k) in enumerate(rows)])
-                return shard.gather_bands(band if on_gpu else band.cpu(), rank, world, dst=0)
-
-        bands = shard_round()
-        torch.cuda.synchronize()
-        barrier()
-        t1 = time.perf_counter()
-        for _ in range(args.segment_shard_rounds):
-            bands = shard_round()
-        torch.cuda.synchronize()
-        barrier()
-        dt = max_over_ranks(time.perf_counter() - t1)
-        ok = None
-        if rank == 0:  # the assembled image against this GPU's own decode of the whole file
-            got = shard.assemble_bands(bands, all_rows, shapes)
-            whole, _ = jp.decode_to_planes(big, device=str(device), subseq_bytes=jp.BATCH_SUBSEQ_BYTES)
-            ok = all(bool(torch.equal(got[c].to(device), whole[c])) for c in range(len(shapes)))
-        segment_shard = {"what": "ONE 7216x5408 4:2:0 image (39 MP, DRI = one MCU row) over the ranks by restart segments, "
-                                 "bands gathered on rank 0", "file_bytes": len(big), "rounds": args.segment_shard_rounds,
-                         "value": args.segment_shard_rounds / dt, "unit": "images/s", "ms_per_image": dt / args.segment_shard_rounds * 1e3,
-                         "rows_of_plane_0_per_rank": [r[0] for r in all_rows], "backend": backend,
-                         "assembled_equals_whole_decode": ok}
-        dec.cleanup()
+        segment_shard = segment_shard_leg(args, torch, dist, jp, shard, streams, device, rank, world, backend, barrier, max_over_ranks)
 
     out = None
     if rank == 0:
-        ab = algorithmic_bytes(slots[0])
         # Roofline figures from SERIALIZED launches: one stream, one batched launch per stage, nothing else on the
-        # chip -- what `rocprofv3 --kernel-trace --stats -- python3 bench.py --roofline-only`-style runs reproduce
+        # chip -- what `rocprofv3 --kernel-trace --stats` of tools/collect_profiles.sh's serialized run reproduces
         # (profiles/). In the timed region the launches of the groups overlap and their durations say nothing
         # about a kernel alone.
-        roofline, all_kernels, stage_us, images_per_launch = None, {}, {}, 0
+        roofline, kernels, e2e, ab = None, {}, None, algorithmic_bytes(slots[0], 0)
         if args.roofline_launches > 0 and args.mode == "batch":
-            bt, scratch, st, images_per_launch = groups[0]
-            bt.set_profiling(True)
-            for _ in range(args.roofline_launches):
-                bt.decode(scratch.data_ptr(), st.cuda_stream)
-                st.synchronize()
-            stage_us = {k: v * 1e3 for k, v in bt.stage_ms().items()}
-            bt.set_profiling(False)
-            pmc_traffic = {}
-            pmc = os.path.join(ROOT, "profiles", "pmc_traffic.json")
-            if os.path.exists(pmc):  # HBM bytes per image from separate rocprofv3 --pmc passes (profiles/README.md)
-                try:
-                    with open(pmc) as f:
-                        pmc_traffic = json.load(f)
-                except Exception:
-                    pmc_traffic = {}
-            for k, us in stage_us.items():
-                t = pmc_traffic.get(KERNEL_NAMES[k], {}).get("per_image_bytes")
-                all_kernels[KERNEL_NAMES[k]] = {
-                    "avg_launch_us": us, "algorithmic_bytes_per_launch": ab[k] * images_per_launch,
-                    "achieved_GBs": ab[k] * images_per_launch / (us * 1e-6) / 1e9 if us > 0 else None,
-                    "frac_of_hbm_peak": ab[k] * images_per_launch / (us * 1e-6) / 1e9 / HBM_PEAK_GBS if us > 0 else None,
-                    "traffic_bytes_per_launch": t * images_per_launch if t else None}
-            dom = max(stage_us, key=stage_us.get)
-            d = all_kernels[KERNEL_NAMES[dom]]
-            roofline = {"bound": "hbm", "kernel": KERNEL_NAMES[dom], "achieved": d["achieved_GBs"], "peak": HBM_PEAK_GBS,
-                        "unit": "GB/s", "frac": d["frac_of_hbm_peak"], "traffic": d["traffic_bytes_per_launch"],
-                        "algorithmic_bytes_per_launch": d["algorithmic_bytes_per_launch"], "avg_launch_us": d["avg_launch_us"],
-                        "images_per_launch": images_per_launch,
-                        "measured": "HIP events on the launch stream, %d serialized launches of %d images, one stream"
-                                    % (args.roofline_launches, images_per_launch)}
-        t_pass_us = sum(stage_us.get(k, 0.0) for k in ("front", "destuff", "sync_intra", "sync_inter", "tails", "write"))
+            stage_us, images_per_launch = serialized_stage_us(args, bset)
+            entries = slots[0].stream_entries(torch)
+            roofline, kernels, e2e, ab = roofline_report(args, slots[0], stage_us, images_per_launch, entries, value, world)
+        photo = args.workload == "photo"
         out = {
             "metric": "images/s, 12 MP 4:2:0 baseline JPEG decode, inputs resident in HBM "
                       "(value_full_path: from pinned host memory, parse + transfer + decode; latency_ms: p50 of the reference's protocol)",
             "value": value, "unit": "images/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": ms_per_step, "higher_is_better": True, "scaling": "weak",
             "vs_baseline": None,  # BASELINE.md holds no published number for this metric on this hardware
-            "dtype": "int16/int32 fixed point, u8 out", "data": "synthetic",
+            "dtype": "int16/int32 fixed point, u8 out",
+            "data": "the reference's photo (tests/golden/IMG_6510.JPG), one file repeated" if photo else "synthetic",
             "verified": verified, "verified_images": nverified,
-            "config": {"workload": "cfg2: 4032x3024 4:2:0 interleaved baseline JPEG, DRI=252 (one MCU row), "
-                                   "%d seeded images per rank" % len(images) if args.workload == "cfg2"
-                       else "cfg1 bytes: tests/golden/IMG_6510.JPG (the reference's 12 MP photo)",
+            "config": {"workload": "cfg1 bytes: tests/golden/IMG_6510.JPG (the reference's 12 MP photo)" if photo else
+                                   "cfg2: 4032x3024 4:2:0 interleaved baseline JPEG, DRI=252 (one MCU row), "
+                                   "%d seeded images per rank" % len(images),
                        "images_per_gpu_per_step": args.batch * args.rounds, "images_per_step": images_per_step,
                        "batch_per_gpu": args.batch, "rounds_per_step": args.rounds,
                        "mode": args.mode, "streams": nstreams,
@@ -598,18 +812,8 @@ def main():
                        "device_scan": bool(slots[0].layout.scans[0].device_scan),
                        "stuffed_scan_bytes": ab["stuffed"], "parallelism": "image-sharded x%d" % world},
             "roofline": roofline,
-            "roofline_pass": {
-                "what": "destuff+Huffman pass (front end, destuff, sync_intra, sync_inter, tails, write), "
-                        "B_dh = stuffed scan bytes + 128 B per data unit (SURVEY.md 8d)",
-                "bytes_per_image": ab["b_dh"], "sum_serialized_launch_us": t_pass_us,
-                "images_per_launch": images_per_launch,
-                "frac_of_hbm_peak_serialized": (ab["b_dh"] * images_per_launch / (t_pass_us * 1e-6) / 1e9 / HBM_PEAK_GBS)
-                if t_pass_us > 0 else None,
-                "throughput_GBs": ab["b_dh"] * value / world / 1e9,
-                "frac_of_hbm_peak": ab["b_dh"] * value / world / 1e9 / HBM_PEAK_GBS},
-            "roofline_e2e": {"bytes_per_image": ab["b_e2e"], "throughput_GBs": ab["b_e2e"] * value / world / 1e9,
-                             "frac_of_hbm_peak": ab["b_e2e"] * value / world / 1e9 / HBM_PEAK_GBS},
-            "kernels": all_kernels,
+            "roofline_e2e": e2e,
+            "kernels": kernels,
         }
         if gather is not None:
             out["gather"] = gather
@@ -618,31 +822,50 @@ def main():
         if args.latency_iters > 0:
             out["latency_ms"] = latency_probe(args, torch, jp, slots[0].data, device, streams[0], device_scan=False)
             out["latency_ms_device_scan"] = latency_probe(args, torch, jp, slots[0].data, device, streams[0], device_scan=True)
-        if args.other_configs > 0:
-            # the other BASELINE.json configurations under the same per-image protocol (parity at full size: tests/)
-            from tools import jpegsynth
-
-            saved, args.latency_iters = args.latency_iters, args.other_configs
-            others = {}
-            with open(os.path.join(ROOT, "tests", "golden", "IMG_6510.JPG"), "rb") as f:
-                photo = f.read()
-            for name, blob in (("config1_photo_12MP_420_dri252", photo),
-                               ("config4_39MP_444_three_scans", jpegsynth.config(4)),
-                               ("config5_12MP_4_components_8_tables_no_dri", jpegsynth.config(5))):
-                r = latency_probe(args, torch, jp, blob, device, streams[0], device_scan=False)
-                others[name] = {"file_bytes": len(blob), "p50_ms": r["p50"], "p50_host_parse_ms": r["p50_host_parse"],
-                                "max_ms": r["max"], "iters": r["iters"], "stage_us_device": r["stage_us_device"]}
-            args.latency_iters = saved
-            out["other_configs"] = others
         if args.mode == "batch" and args.e2e_rounds > 0:
-            out["pcie_inclusive"] = pcie_inclusive(args, torch, jp, slots, groups, nstreams)
+            out["pcie_inclusive"] = pcie_inclusive(args, torch, jp, slots, bset.groups, nstreams)
             out["value_full_path"] = out["pcie_inclusive"]["value"]
-        if not args.no_cpu:
-            out["cpu_baseline"] = cpu_baseline(args, slots[0].data)
-    for bt, _, _, _ in groups:
-        bt.destroy()
-    for s in slots:
-        s.dec.cleanup()
+    bset.destroy()
+    del bset, slots
+    torch.cuda.empty_cache()
+    if rank == 0 and args.other_configs > 0:
+        # the other BASELINE.json configurations under the per-image protocol (parity at full size: tests/), and the
+        # reference's photo under the batched protocol of `value`
+        from tools import jpegsynth
+
+        saved, args.latency_iters = args.latency_iters, args.other_configs
+        others = {}
+        with open(PHOTO, "rb") as f:
+            photo_bytes = f.read()
+        for name, blob in (("config1_photo_12MP_420_dri252", photo_bytes),
+                           ("config4_39MP_444_three_scans", jpegsynth.config(4)),
+                           ("config5_12MP_4_components_8_tables_no_dri", jpegsynth.config(5))):
+            r = latency_probe(args, torch, jp, blob, device, streams[0], device_scan=False)
+            others[name] = {"file_bytes": len(blob), "p50_ms": r["p50"], "p50_host_parse_ms": r["p50_host_parse"],
+                            "max_ms": r["max"], "iters": r["iters"], "subsequence_bytes": r["subsequence_bytes"],
+                            "stage_us_device": r["stage_us_device"]}
+        args.latency_iters = saved
+        if world == 1 and args.photo_steps > 0 and args.mode == "batch" and args.workload != "photo":
+            pset = BatchSet(args, torch, jp, [photo_bytes], device, streams, args.batch)
+            dt = timed_steps(torch, pset, args.photo_steps, 1, lambda: None)
+            p = others["config1_photo_12MP_420_dri252"]
+            p["batch_images_per_s"] = args.batch * args.rounds * args.photo_steps / dt
+            p["batch_protocol"] = "as `value`: %d images per round in %d groups, %d rounds per step, %d steps, inputs resident" % (
+                args.batch, nstreams, args.rounds, args.photo_steps)
+            p["batch_subsequence_bytes"] = pset.slots[0].layout.subsequence_bytes
+            if args.roofline_launches > 0:
+                us, ipl = serialized_stage_us(args, pset)
+                p["batch_stage_us_serialized"] = us
+                t_pass = sum(v for k, v in us.items() if k in PASS_STAGES and (k != "front" or args.device_scan))
+                pab = algorithmic_bytes(pset.slots[0], 0)
+                p["batch_roofline_frac"] = pab["b_dh"] * ipl / (t_pass * 1e-6) / 1e9 / HBM_PEAK_GBS if t_pass > 0 else None
+            if not args.no_verify:
+                _, bad = verify(pset.slots[:1], torch)
+                p["batch_verified"] = not bad
+            pset.destroy()
+        out["other_configs"] = others
+    if rank == 0 and cpu is not None:
+        out["cpu_baseline"] = cpu
     if world > 1:
         dist.barrier()
         dist.destroy_process_group()

@@ -3,7 +3,7 @@
  * the reference; callers that only use jpeggpu.h never need this header.
  *
  *   jpeggpu_ext_set_subsequence_bytes  tuning knob the reference leaves as a compile-time constant
- *                                      (src/decoder_defs.hpp:28-34 `chunk_size`)
+ *   jpeggpu_ext_set_batched            (src/decoder_defs.hpp:28-34 `chunk_size`); chosen per image by default
  *   jpeggpu_ext_get_layout             where the intermediate buffers of the last parsed image sit
  *   jpeggpu_ext_set_segment_shard      decode a share of one image's restart segments (one image over several GPUs)
  *                                      inside d_tmp, for stage-level parity tests and profiling
@@ -27,9 +27,17 @@
 extern "C" {
 #endif
 
-/* 32, 64, 128 or 256. Takes effect at the next jpeggpu_decoder_parse_header. Default 128 (the reference's
- * value) unless the environment variable JPEGGPU_SUBSEQ_BYTES overrides it at startup. */
+/* Subsequence size (the reference's compile-time `chunk_size`, 128, with the TODO "pick per image",
+ * src/decoder_defs.hpp:28-34). By default the library picks it PER IMAGE at jpeggpu_decoder_parse_header from the size
+ * of the scan, its restart density and the call type: 64 bytes for an image decoded on its own (the sequence kernel's
+ * serial chain is what such a decode waits for), 256 for one that shares its launches with others, less where restart
+ * segments are so short that padding them to whole subsequences would show (jpeggpu_ext_layout.subsequence_bytes says
+ * what an image got). jpeggpu_ext_set_batched tells the decoder which call type its images are for;
+ * jpeggpu_ext_set_subsequence_bytes fixes the size instead (32, 64, 128 or 256; 0 = back to the per-image choice), as
+ * does the environment variable JPEGGPU_SUBSEQ_BYTES at startup. Both take effect at the next parse_header.
+ * jpeggpu_ext_decode_batch accepts any mix of sizes (one group of launches per size). */
 enum jpeggpu_status jpeggpu_ext_set_subsequence_bytes(jpeggpu_decoder_t decoder, int subseq_bytes);
+enum jpeggpu_status jpeggpu_ext_set_batched(jpeggpu_decoder_t decoder, int batched);
 
 struct jpeggpu_ext_scan_layout {
     int num_components;        /* components in this scan */
@@ -82,6 +90,7 @@ struct jpeggpu_ext_layout {
     size_t off_bytes;          /* stuffed bytes inside d_tmp */
     size_t off_qtables;        /* uint16[4][64], natural order */
     struct jpeggpu_ext_scan_layout scans[JPEGGPU_MAX_COMP];
+    int shard_rank, shard_world; /* jpeggpu_ext_set_segment_shard as it applies to this image (0, 1: the whole image) */
 };
 
 enum jpeggpu_status jpeggpu_ext_get_layout(jpeggpu_decoder_t decoder, struct jpeggpu_ext_layout* layout);
@@ -111,9 +120,12 @@ enum jpeggpu_status jpeggpu_ext_get_shard_rows(jpeggpu_decoder_t decoder, int co
  * device-scanned images runs as four launches for the whole batch (grid.y = image). */
 /* enable: 0 off (default); 1 on, the caller asks for the status as above; 2 on and CHECKED: jpeggpu_decoder_decode
  * itself waits for the stream and returns the device's status (it then blocks the host, unlike every other mode).
- * The environment variable JPEGGPU_DEVICE_SCAN=1 selects mode 2 at jpeggpu_decoder_startup: it is meant for callers
- * of the drop-in API alone, who cannot ask the device and would otherwise learn of a truncated scan from unwritten
- * planes. Items of jpeggpu_ext_decode_batch are never waited for: their status is read with the call below. */
+ * The environment variable JPEGGPU_DEVICE_SCAN selects the same modes at jpeggpu_decoder_startup (1: asynchronous,
+ * 2: checked), for callers of the drop-in API alone: in mode 1 such a caller learns of a truncated scan from unwritten
+ * planes only, mode 2 tells it at the price of a blocking decode. Items of jpeggpu_ext_decode_batch are never waited
+ * for: their status is read with the call below. A decoder in segment-shard mode (jpeggpu_ext_set_segment_shard with
+ * world > 1) always takes the host walk -- its share is cut out of the host walk's tables -- and parse_header logs
+ * that the device scan was not used (jpeggpu_ext_layout.scans[0].device_scan says which walk an image got). */
 enum jpeggpu_status jpeggpu_ext_set_device_scan(jpeggpu_decoder_t decoder, int enable);
 enum jpeggpu_status jpeggpu_ext_get_device_status(
     jpeggpu_decoder_t decoder, const void* d_tmp, jpeggpu_stream_t stream, enum jpeggpu_status* status);
@@ -137,8 +149,8 @@ enum jpeggpu_status jpeggpu_ext_get_stage_ms(jpeggpu_decoder_t decoder, float* m
 
 /* Batched decode: ONE launch per stage for all scans of all items (grid.y = scan), which is what fills
  * a 256-CU device; the drop-in jpeggpu_decoder_decode launches per image. Every item must have been
- * parsed and transferred (jpeggpu_decoder_transfer) into its own d_tmp, and all decoders must use the
- * same subsequence size. `d_scratch` is caller-owned device memory of at least
+ * parsed and transferred (jpeggpu_decoder_transfer) into its own d_tmp; items whose images got different
+ * subsequence sizes are launched as one group per size. `d_scratch` is caller-owned device memory of at least
  * jpeggpu_ext_batch_scratch_size(total number of scans) bytes (job descriptors and front-end parameters),
  * private to the stream. The batch handle owns page-locked host staging only: a ring of FOUR staging buffers for
  * the job descriptors. Like jpeggpu_decoder_decode the call only enqueues -- with one exception: the fifth call in

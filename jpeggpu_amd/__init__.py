@@ -5,7 +5,6 @@ hipcc for gfx950). This package is the thin host-side mirror used by the tests a
 ctypes bindings with the reference's function names, argument meaning and status codes.
 """
 from .api import (  # noqa: F401
-    BATCH_SUBSEQ_BYTES,
     Batch,
     Decoder,
     ImgInfo,

@@ -13,9 +13,6 @@ import os
 from . import build as _build
 
 MAX_COMP = 4
-# Subsequence size the benchmark and the batch examples ask for (jpeggpu_ext_set_subsequence_bytes) when many images
-# share a launch; a decoder left alone uses the library's default, chosen for a lone decode.
-BATCH_SUBSEQ_BYTES = 256
 STAGES = ("front", "destuff", "sync_intra", "sync_inter", "tails", "write", "idct")
 
 
@@ -61,6 +58,7 @@ class ExtLayout(C.Structure):
         ("transferred_bytes", C.c_size_t), ("blob_bytes", C.c_size_t),
         ("off_bytes", C.c_size_t), ("off_qtables", C.c_size_t),
         ("scans", ExtScanLayout * MAX_COMP),
+        ("shard_rank", C.c_int), ("shard_world", C.c_int),
     ]
 
 
@@ -110,6 +108,7 @@ def lib():
     L.jpeggpu_decoder_decode.argtypes = [dec, C.POINTER(Img), C.c_void_p, C.c_size_t, C.c_void_p]
     L.jpeggpu_decoder_cleanup.argtypes = [dec]
     L.jpeggpu_ext_set_subsequence_bytes.argtypes = [dec, C.c_int]
+    L.jpeggpu_ext_set_batched.argtypes = [dec, C.c_int]
     L.jpeggpu_ext_get_layout.argtypes = [dec, C.POINTER(ExtLayout)]
     L.jpeggpu_ext_set_profiling.argtypes = [dec, C.c_int]
     L.jpeggpu_ext_get_stage_ms.argtypes = [dec, C.POINTER(C.c_float)]
@@ -170,6 +169,11 @@ class Decoder:
     def set_subsequence_bytes(self, n: int):
         _check(lib().jpeggpu_ext_set_subsequence_bytes(self._h, n), "jpeggpu_ext_set_subsequence_bytes")
 
+    def set_batched(self, on: bool = True):
+        """This decoder's images share their launches with others (jpeggpu_ext_decode_batch): the per-image choice
+        of the subsequence size is made for throughput instead of for the latency of one image."""
+        _check(lib().jpeggpu_ext_set_batched(self._h, int(on)), "jpeggpu_ext_set_batched")
+
     def parse_header(self, data, size=None) -> ImgInfo:
         """`data`: bytes, a numpy uint8 array, or an integer host address (then `size` is required).
         The buffer is borrowed until the copy enqueued by transfer() has executed."""
@@ -187,7 +191,7 @@ class Decoder:
 
     def set_device_scan(self, on=True):
         """False / 0: host walk; True / 1: marker scan on the device, status via device_status(); 2: checked --
-        decode() waits for the stream and raises the device's status (what JPEGGPU_DEVICE_SCAN=1 selects)."""
+        decode() waits for the stream and raises the device's status (what JPEGGPU_DEVICE_SCAN=2 selects)."""
         _check(lib().jpeggpu_ext_set_device_scan(self._h, int(on)), "jpeggpu_ext_set_device_scan")
 
     def set_segment_shard(self, rank: int, world: int):

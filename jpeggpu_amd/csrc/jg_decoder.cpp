@@ -99,9 +99,12 @@ struct Decoder {
     Plan plan;
     const uint8_t* data = nullptr;
     size_t data_size    = 0;
-    // Default of a decoder nobody configured: the best size for ONE image at a time, from 0.08 to 12 MP
-    // (tools/probe/latency_by_size.py; a shorter subsequence is a shorter serial chain per lane). Callers that put many
-    // images into one launch ask for 256 (jpeggpu_ext_set_subsequence_bytes; bench.py).
+    // Subsequence size: chosen PER IMAGE at parse_header (jg_reader.hpp, choose_subseq_bytes) from the scan's size, its
+    // restart density and the call type -- `batched`: the decoder's images share their launches with others
+    // (jpeggpu_ext_set_batched; jpeggpu_ext_decode_batch accepts any mix of sizes) -- unless the caller fixed one
+    // (jpeggpu_ext_set_subsequence_bytes, JPEGGPU_SUBSEQ_BYTES). `subseq_bytes` is the size of the last parsed image.
+    int subseq_request  = 0;     // 0: choose per image; else 32 / 64 / 128 / 256
+    bool batched        = false;
     int subseq_bytes    = 64;
     bool parsed         = false;
     int shard_rank = 0, shard_world = 1; // jpeggpu_ext_set_segment_shard
@@ -526,11 +529,16 @@ enum jpeggpu_status jpeggpu_decoder_startup(jpeggpu_decoder_t* decoder)
     if (*decoder == nullptr) return JPEGGPU_OUT_OF_HOST_MEMORY;
     if (const char* e = std::getenv("JPEGGPU_SUBSEQ_BYTES")) {
         const int v = std::atoi(e);
-        if (jg::subseq_bytes_supported(v)) (*decoder)->d.subseq_bytes = v;
+        if (jg::subseq_bytes_supported(v)) (*decoder)->d.subseq_request = v;
     }
-    // a caller of the drop-in API alone can opt into the device-side marker scan; such a caller cannot ask the
-    // device for its verdict on the stream, so decode waits for it and returns it (mode 2, jpeggpu_ext.h)
-    if (const char* e = std::getenv("JPEGGPU_DEVICE_SCAN")) (*decoder)->d.device_scan = std::atoi(e) != 0 ? 2 : 0;
+    // A caller of the drop-in API alone can opt into the device-side marker scan: JPEGGPU_DEVICE_SCAN=1 keeps decode
+    // asynchronous like every other mode (a truncated scan then shows as untouched planes, the reference's own
+    // behaviour for corrupt entropy data); =2 is the CHECKED mode, in which decode waits for the stream and returns
+    // the device's verdict -- the only way such a caller can learn it, at the price of a blocking call (jpeggpu_ext.h).
+    if (const char* e = std::getenv("JPEGGPU_DEVICE_SCAN")) {
+        const int v = std::atoi(e);
+        (*decoder)->d.device_scan = v == 1 || v == 2 ? v : 0;
+    }
     return JPEGGPU_SUCCESS;
 }
 
@@ -558,7 +566,9 @@ enum jpeggpu_status jpeggpu_decoder_parse_header(
     d.parsed   = false;
     jpeggpu_status st;
     try {
-        st = d.reader.parse(data, size, d.subseq_bytes, d.logger, d.device_scan != 0, d.shard_rank, d.shard_world);
+        const int ask = d.subseq_request > 0 ? d.subseq_request : d.batched ? jg::kSubseqAutoBatched : jg::kSubseqAutoLone;
+        st = d.reader.parse(data, size, ask, d.logger, d.device_scan != 0, d.shard_rank, d.shard_world);
+        d.subseq_bytes = d.reader.subseq_bytes();
     } catch (const std::bad_alloc&) {
         return JPEGGPU_OUT_OF_HOST_MEMORY;
     }
@@ -574,6 +584,17 @@ enum jpeggpu_status jpeggpu_decoder_parse_header(
     }
     d.data      = data;
     d.data_size = size;
+    // The IDCT addresses the 16-bit symbol stream with 32-bit BYTE offsets and the data-unit table holds 32-bit
+    // entry indices (jg_kernels.hip, entry_at / prefetch): a scan whose stream would not fit them (from about
+    // 400 MB of entropy-coded data at 64-byte subsequences) is refused here instead of gathering from wrapped offsets.
+    for (int i = 0; i < s.num_scans; ++i) {
+        const uint64_t entries = jg::sym_buffer_entries(static_cast<uint32_t>(s.scans[i].num_subseq), jg::sym_region_entries(d.subseq_bytes));
+        if (entries * 2u >= (1ull << 32)) {
+            d.logger.log("scan %d: %d subsequences of %d bytes need a symbol stream of %llu bytes (32-bit offsets)\n", i,
+                         s.scans[i].num_subseq, d.subseq_bytes, static_cast<unsigned long long>(entries * 2u));
+            return JPEGGPU_NOT_SUPPORTED;
+        }
+    }
     d.make_plan();
     if (!d.fill_blob()) return JPEGGPU_OUT_OF_HOST_MEMORY;
     d.parsed = true;
@@ -614,9 +635,17 @@ enum jpeggpu_status jpeggpu_decoder_cleanup(jpeggpu_decoder_t decoder)
 
 enum jpeggpu_status jpeggpu_ext_set_subsequence_bytes(jpeggpu_decoder_t decoder, int subseq_bytes)
 {
-    if (!decoder || !jg::subseq_bytes_supported(subseq_bytes)) return JPEGGPU_INVALID_ARGUMENT;
-    decoder->d.subseq_bytes = subseq_bytes;
-    decoder->d.parsed       = false;
+    if (!decoder || (subseq_bytes != 0 && !jg::subseq_bytes_supported(subseq_bytes))) return JPEGGPU_INVALID_ARGUMENT;
+    decoder->d.subseq_request = subseq_bytes; // 0: back to the per-image choice
+    decoder->d.parsed         = false;
+    return JPEGGPU_SUCCESS;
+}
+
+enum jpeggpu_status jpeggpu_ext_set_batched(jpeggpu_decoder_t decoder, int batched)
+{
+    if (!decoder) return JPEGGPU_INVALID_ARGUMENT;
+    decoder->d.batched = batched != 0;
+    decoder->d.parsed  = false;
     return JPEGGPU_SUCCESS;
 }
 
@@ -695,6 +724,8 @@ enum jpeggpu_status jpeggpu_ext_get_layout(jpeggpu_decoder_t decoder, struct jpe
     out->blob_bytes        = d.plan.blob_size;
     out->off_bytes         = d.plan.off_bytes;
     out->off_qtables       = d.plan.off_blob + d.plan.blob_qtables;
+    out->shard_rank        = d.shard_rank;
+    out->shard_world       = d.shard_world;
     for (int i = 0; i < s.num_scans; ++i) {
         const jg::Scan& sc         = s.scans[i];
         const jg::ScanPlan& pl     = d.plan.scan[i];
@@ -764,6 +795,7 @@ struct jpeggpu_batch {
     hipEvent_t joined[kMaxOverlap - 1] = {};
     std::vector<jg::ScanJob> jobs;
     std::vector<jg::FrontParams> fronts;
+    std::vector<int> order, group_begin; // scratch of decode_batch: items by subsequence size, job ranges of the sizes
     // optional stage timing, same contract as the decoder's
     bool profiling = false;
     std::vector<std::vector<hipEvent_t>> sets; // ring of kNumStages + 1 events
@@ -827,14 +859,25 @@ enum jpeggpu_status jpeggpu_ext_decode_batch(
     if (num_items == 0) return JPEGGPU_SUCCESS;
     batch->jobs.clear();
     batch->fronts.clear();
-    int subseq_bytes = 0;
     jg::ScanJob* d_jobs_rw = static_cast<jg::ScanJob*>(d_scratch);
     uint32_t front_windows = 0;
-    for (int i = 0; i < num_items; ++i) {
-        const jpeggpu_ext_batch_item& it = items[i];
-        if (!it.decoder || !it.img) return JPEGGPU_INVALID_ARGUMENT;
-        if (i == 0) subseq_bytes = it.decoder->d.subseq_bytes;
-        if (it.decoder->d.subseq_bytes != subseq_bytes) return JPEGGPU_INVALID_ARGUMENT; // one kernel variant per launch
+    // One kernel variant per launch: the items are taken in the order of their subsequence size (chosen per image at
+    // parse_header unless the caller fixed it), and every size is a group of launches of its own.
+    for (int i = 0; i < num_items; ++i)
+        if (!items[i].decoder || !items[i].img) return JPEGGPU_INVALID_ARGUMENT;
+    std::vector<int>& order = batch->order;
+    order.resize(static_cast<size_t>(num_items));
+    for (int i = 0; i < num_items; ++i) order[static_cast<size_t>(i)] = i;
+    std::stable_sort(order.begin(), order.end(), [&](int a, int b) { return items[a].decoder->d.subseq_bytes > items[b].decoder->d.subseq_bytes; });
+    std::vector<int>& group_begin = batch->group_begin; // job index at which each size group starts, plus the end
+    group_begin.clear();
+    int subseq_bytes = 0;
+    for (int k = 0; k < num_items; ++k) {
+        const jpeggpu_ext_batch_item& it = items[order[static_cast<size_t>(k)]];
+        if (it.decoder->d.subseq_bytes != subseq_bytes) {
+            subseq_bytes = it.decoder->d.subseq_bytes;
+            group_begin.push_back(static_cast<int>(batch->jobs.size()));
+        }
         const size_t first_job = batch->jobs.size();
         const jpeggpu_status st = build_jobs(it.decoder->d, it.img, it.d_tmp, it.tmp_size, batch->sync_iters, batch->jobs);
         if (st != JPEGGPU_SUCCESS) return st;
@@ -844,6 +887,7 @@ enum jpeggpu_status jpeggpu_ext_decode_batch(
             front_windows = std::max(front_windows, batch->fronts.back().num_windows);
         }
     }
+    group_begin.push_back(static_cast<int>(batch->jobs.size()));
     const int n         = static_cast<int>(batch->jobs.size());
     const int nf        = static_cast<int>(batch->fronts.size());
     const size_t jbytes = sizeof(jg::ScanJob) * static_cast<size_t>(n), fbytes = sizeof(jg::FrontParams) * static_cast<size_t>(nf);
@@ -854,8 +898,6 @@ enum jpeggpu_status jpeggpu_ext_decode_batch(
     if (batch->in_use[r] && hipEventSynchronize(batch->copied[r]) != hipSuccess) return JPEGGPU_INTERNAL_ERROR;
     std::memcpy(batch->staging[r], batch->jobs.data(), jbytes);
     if (nf) std::memcpy(batch->staging[r] + jbytes, batch->fronts.data(), fbytes);
-    jg::JobExtent extent;
-    for (const jg::ScanJob& j : batch->jobs) jg::extend(extent, j);
     const jg::ScanJob* d_jobs = static_cast<const jg::ScanJob*>(d_scratch);
     std::vector<hipEvent_t>* ev = nullptr;
     if (batch->profiling) {
@@ -879,13 +921,10 @@ enum jpeggpu_status jpeggpu_ext_decode_batch(
     // the staging buffer is free again, and the parts below may start: the job array is complete
     if (hipEventRecord(batch->copied[r], stream) != hipSuccess) return JPEGGPU_INTERNAL_ERROR;
     batch->in_use[r] = true;
-    // parts of the job array: contiguous, at least 8 jobs each
-    int ways = batch->overlap;
-    while (ways > 1 && n / ways < 8) --ways;
-    int begin[jpeggpu_batch::kMaxOverlap + 1];
-    jg::JobExtent part_extent[jpeggpu_batch::kMaxOverlap];
+    // parts of the job array: every size group is cut into up to `overlap` contiguous parts of at least 4 jobs each,
+    // part w of every group on stream w
+    const int ways = batch->overlap;
     hipStream_t part_stream[jpeggpu_batch::kMaxOverlap];
-    for (int w = 0; w <= ways; ++w) begin[w] = static_cast<int>(static_cast<long long>(n) * w / ways);
     part_stream[0] = stream;
     for (int w = 1; w < ways; ++w) {
         if (!batch->aux[w - 1]) {
@@ -896,19 +935,29 @@ enum jpeggpu_status jpeggpu_ext_decode_batch(
         part_stream[w] = batch->aux[w - 1];
         if (hipStreamWaitEvent(part_stream[w], batch->copied[r], 0) != hipSuccess) return JPEGGPU_INTERNAL_ERROR; // fork
     }
-    for (int w = 0; w < ways; ++w) {
-        part_extent[w] = jg::JobExtent{};
-        for (int j = begin[w]; j < begin[w + 1]; ++j) jg::extend(part_extent[w], batch->jobs[j]);
+    struct Part {
+        int begin, end, way;
+        jg::JobExtent extent;
+    };
+    std::vector<Part> parts;
+    for (size_t g = 0; g + 1 < group_begin.size(); ++g) {
+        const int a = group_begin[g], b = group_begin[g + 1];
+        int gw = ways;
+        while (gw > 1 && (b - a) / gw < 4) --gw;
+        for (int w = 0; w < gw; ++w) {
+            Part p{a + static_cast<int>(static_cast<long long>(b - a) * w / gw), a + static_cast<int>(static_cast<long long>(b - a) * (w + 1) / gw), w, jg::JobExtent{}};
+            for (int j = p.begin; j < p.end; ++j) jg::extend(p.extent, batch->jobs[static_cast<size_t>(j)]);
+            if (p.end > p.begin) parts.push_back(p);
+        }
     }
     for (int stage = 0; stage < jg::kNumStages; ++stage) {
-        for (int w = 0; w < ways; ++w) {
-            if (jg::launch_stage_batch(static_cast<jg::Stage>(stage), d_jobs + begin[w], begin[w + 1] - begin[w], part_extent[w],
-                                       part_stream[w]) != hipSuccess) {
+        for (const Part& p : parts) {
+            if (jg::launch_stage_batch(static_cast<jg::Stage>(stage), d_jobs + p.begin, p.end - p.begin, p.extent, part_stream[p.way]) != hipSuccess) {
                 (void)hipGetLastError();
                 return JPEGGPU_INTERNAL_ERROR;
             }
         }
-        if (ev) (void)hipEventRecord((*ev)[stage + 1], stream); // stage times are those of part 0
+        if (ev) (void)hipEventRecord((*ev)[stage + 1], stream); // stage times are those of the caller's stream
     }
     for (int w = 1; w < ways; ++w) { // join: the caller's stream completes when every part has
         if (hipEventRecord(batch->joined[w - 1], part_stream[w]) != hipSuccess ||

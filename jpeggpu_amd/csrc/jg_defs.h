@@ -166,11 +166,23 @@ JG_HD inline uint64_t tiled_buffer_bytes(uint32_t num_subseq, int subseq_bytes, 
 /// Half the bytes of a 32-bit entry (index << 16 | value) -- the stream is most of what the write pass stores and the
 /// IDCT fetches: with every other sector left out (timing only) the write pass ran 15 % and a batch 11 % faster.
 ///
-/// Entries reserved per subsequence: an emitted entry takes at least 2 bits of the stream on average over a data
-/// unit (an escaped coefficient two entries for 12 bits or more), plus up to one data unit of overrun (a lane
-/// finishes the unit it started).
+/// Most entries a data unit can have: 64 coefficients, every AC one escaped.
+constexpr uint32_t kMaxUnitEntries = 64 + 63;
+
+/// Entries reserved per subsequence. A lane of the write pass emits the data units whose DC symbol its subsequence
+/// commits. The densest unit a code table allows is 64 entries in 127 bits (a one-bit DC code of category 0, then 63
+/// coefficients of one code bit and one magnitude bit each; an escaped coefficient is two entries for twelve bits or
+/// more), so the units that start AND end inside the 8 * B bits of the subsequence hold at most ceil(8 * B * 64 / 127)
+/// entries, and the unit the lane runs on to finish at most kMaxUnitEntries more. (The round-2 figure, 4 * B + 64 +
+/// 16, forgot that the last unit may be all escapes: a crafted table pack overran it by 47 entries at B = 64, and the
+/// sink's clamp then dropped entries silently; tests/test_emulation.py holds that file.)
 constexpr uint32_t kSymSectorEntries = 16; // entries a lane flushes at a time: one 32-byte sector
-JG_HD inline uint32_t sym_region_entries(int subseq_bytes) { return static_cast<uint32_t>(subseq_bytes) * 4u + 64u + 16u; } // + a sector of flush slack; a multiple of 16
+JG_HD constexpr uint32_t sym_region_entries(int subseq_bytes)
+{
+    return ((static_cast<uint32_t>(subseq_bytes) * 8u * 64u + 126u) / 127u + kMaxUnitEntries + kSymSectorEntries - 1u) / kSymSectorEntries * kSymSectorEntries;
+}
+static_assert(sym_region_entries(32) == 272 && sym_region_entries(64) == 400 && sym_region_entries(128) == 656 && sym_region_entries(256) == 1168,
+              "whole sectors, at least ceil(8 B 64 / 127) + kMaxUnitEntries entries");
 
 struct uint2_t {
     uint32_t x, y;
@@ -205,9 +217,6 @@ JG_HD inline uint64_t sym_buffer_entries(uint32_t num_subseq, uint32_t region_en
     const uint64_t tiles = (static_cast<uint64_t>(num_subseq) + kSymTileSubseq - 1) / kSymTileSubseq;
     return tiles * (region_entries / kSymSectorEntries) * kSymSectorStride + 16u * kSymSectorStride;
 }
-/// Most entries a data unit can have: 64 coefficients, every AC one escaped.
-constexpr uint32_t kMaxUnitEntries = 64 + 63;
-
 /// One restart segment of a scan inside the destuffed buffer (reference src/reader.hpp:38-43).
 struct Segment {
     int subseq_offset; // subsequences before this segment

@@ -502,6 +502,12 @@ jpeggpu_status Reader::read_sos(const Logger& log)
     scan.mcus_per_segment = s.restart_interval ? s.restart_interval : total_mcus;
     scan.num_du           = total_mcus * scan.du_per_mcu;
     scan.begin            = static_cast<size_t>(cur_ - base_);
+    if (s.num_scans == 0 && subseq_request_ <= 0) {
+        // per-image choice (jg_reader.hpp): what is left of the file bounds the scan, DRI and the geometry give the segments
+        subseq_bytes_ = choose_subseq_bytes(subseq_request_ == kSubseqAutoBatched, static_cast<size_t>(end_ - cur_),
+                                            static_cast<size_t>(ceil_div(total_mcus, scan.mcus_per_segment)));
+        log.log("\tsubsequence size chosen for this image: %d bytes\n", subseq_bytes_);
+    }
     if (s.num_scans == 0) s.xfer_begin = (scan.begin - 1) & ~static_cast<size_t>(15);
     ++s.num_scans;
     if (device_scan_ && s.num_scans == 1 && ns == s.num_comp) {
@@ -754,7 +760,11 @@ jpeggpu_status Reader::apply_segment_shard(int rank, int world, const Logger& lo
 jpeggpu_status Reader::parse(const uint8_t* data, size_t size, int subseq_bytes, const Logger& log, bool device_scan,
                              int shard_rank, int shard_world)
 {
-    if (shard_world > 1) device_scan = false; // the share is cut out of the host walk's tables
+    if (shard_world > 1 && device_scan) {
+        // the share is cut out of the host walk's tables (jpeggpu_ext.h says so; the layout shows which walk was used)
+        log.log("segment shard %d of %d: host walk, the device scan that was asked for is not used\n", shard_rank, shard_world);
+        device_scan = false;
+    }
     device_scan_ = device_scan;
     stop_        = false;
     {
@@ -785,7 +795,8 @@ jpeggpu_status Reader::parse(const uint8_t* data, size_t size, int subseq_bytes,
     base_         = data;
     cur_          = data;
     end_          = data + size;
-    subseq_bytes_ = subseq_bytes;
+    subseq_request_ = subseq_bytes;
+    subseq_bytes_   = subseq_bytes > 0 ? subseq_bytes : 64; // an automatic choice is made at the first scan header
     found_sof_    = false;
     std::memset(qt_defined_, 0, sizeof(qt_defined_));
     std::memset(dc_defined_, 0, sizeof(dc_defined_));

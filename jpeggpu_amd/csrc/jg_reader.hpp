@@ -93,11 +93,38 @@ struct Stream {
     size_t xfer_end   = 0;
 };
 
+constexpr int kSubseqAutoLone = 0, kSubseqAutoBatched = -1;
+
+/// Subsequence size for an image whose first scan has `scan_bytes_bound` bytes at most, in `segments` restart segments.
+///   * One image at a time: the sequence kernel's flows are a chain whose length in BITS is what the content makes it,
+///     so a shorter subsequence only shortens the lanes' serial decode around it: 64 bytes measured best from 0.08 to
+///     12 MP and on the reference's photo (tools/probe/latency_by_size.py; 32 bytes doubles the state traffic for no
+///     shorter chain).
+///   * Images that share launches: the chip is full anyway and every subsequence costs a fixed amount of state,
+///     table loads and scan work, so the longest size wins -- 256 bytes -- unless the restart segments are so short
+///     that padding each of them to whole subsequences would be a visible share of the decode (kept below 1/16: a
+///     segment is padded by half a subsequence on average), or the scan so small that it would not fill two sequences.
+inline int choose_subseq_bytes(bool batched, size_t scan_bytes_bound, size_t segments)
+{
+    if (segments == 0) segments = 1;
+    const size_t per_segment = scan_bytes_bound / segments;
+    int b = batched ? 256 : 64;
+    while (b > 32 && per_segment < static_cast<size_t>(8 * b)) b >>= 1;
+    while (b > 64 && scan_bytes_bound < static_cast<size_t>(2 * kSeqSubseq) * static_cast<size_t>(b)) b >>= 1;
+    return b;
+}
+
 struct Reader {
     /// `device_scan`: a file whose first scan holds every component is not walked on the host (jg_front.hip
     /// does it on the device); parsing stops at that scan's first entropy-coded byte.
+    /// `subseq_bytes`: 32, 64, 128 or 256, or a request to choose per image (the reference leaves this as a TODO,
+    /// src/decoder_defs.hpp:28-34): kSubseqAutoLone for an image decoded on its own (jpeggpu_decoder_decode),
+    /// kSubseqAutoBatched for one that shares its launches with others (jpeggpu_ext_decode_batch). The choice is made
+    /// at the first scan header from the bytes left in the file and the restart density (choose_subseq_bytes) and
+    /// holds for every scan of the image; subseq_bytes() says what it was.
     jpeggpu_status parse(const uint8_t* data, size_t size, int subseq_bytes, const Logger& log, bool device_scan = false,
                          int shard_rank = 0, int shard_world = 1);
+    int subseq_bytes() const { return subseq_bytes_; }
 
     Stream s;
 
@@ -106,6 +133,7 @@ struct Reader {
     const uint8_t* cur_  = nullptr;
     const uint8_t* end_  = nullptr;
     int subseq_bytes_    = 128;
+    int subseq_request_  = 128; // what parse was asked for (a size or one of the kSubseqAuto values)
     bool found_sof_      = false;
     bool qt_defined_[4]{};
     bool dc_defined_[4]{}, ac_defined_[4]{};

@@ -6,6 +6,23 @@ S420 = ((2, 2), (1, 1), (1, 1))
 S444 = ((1, 1), (1, 1), (1, 1))
 
 
+def dense_escape_case(groups=96, seed=5):
+    """The most entries per bit a code table allows (jg_defs.h, sym_region_entries): a grayscale file whose fitted
+    tables give the DC symbol and the AC symbol (0, 1) one-bit codes, in groups of four data units of 63 coefficients
+    +-1 (64 entries in 127 bits each) followed by one unit of 63 coefficients of magnitude >= 512 (127 entries: every
+    one takes an escape). A subsequence that commits four dense units and the DC symbol of the escaped one emits
+    4.03 B + 127 entries."""
+    import numpy as np
+
+    rng = np.random.default_rng(seed)
+    n = 5 * groups
+    coef = np.zeros((n, 64), np.int16)
+    sign = lambda shape: rng.integers(0, 2, shape).astype(np.int16) * 2 - 1
+    coef[:, 1:] = sign((n, 63))
+    coef[4::5, 1:] = sign((groups, 63)) * rng.integers(512, 1024, (groups, 63)).astype(np.int16)
+    return jpegsynth.encode_blocks(coef, 24, np.ones(64, np.uint8), optimize=True)
+
+
 def matrix():
     """name -> bytes. Small enough for the oracle to finish in well under a second each."""
     e = jpegsynth.encode
@@ -40,6 +57,7 @@ def matrix():
         # entropy extremes
         "q100_noisy": e(160, 128, S420, quality=100, noise=40, seed=23),   # long codes, long blocks
         "q5_flat": e(640, 480, S420, quality=5, noise=0, seed=24),         # almost all EOB
+        "dense_escapes": dense_escape_case(),  # worst-case entries per subsequence of the write pass
         "q16_tables": e(328, 248, S420, restart_interval=7, quality=3, noise=30, seed=31, qmax=65535),  # 16-bit DQT (Pq = 1)
         # more than one sequence without restart markers (inter-sequence flows), ~150 KB of scan
         "multi_seq_nodri": e(1024, 768, S420, quality=92, noise=12, seed=25),

@@ -214,16 +214,22 @@ def test_batch_decode_equals_single(torch_cuda):
     names = names * 3 + list(m.keys())[:12]  # > 32 scans: enough for four concurrent parts (set_overlap)
     keep, entries, refs = [], [], []
     total_scans = 0
+    sizes = set()
     for k, name in enumerate(names):
-        dec = jpeggpu_amd.Decoder()
+        # the subsequence size is the library's per-image choice (lone or batched call type) or the caller's: a batch
+        # takes any mix of sizes, one group of launches per size
+        dec = jpeggpu_amd.Decoder(128 if k % 5 == 0 else None)
+        dec.set_batched(k % 2 == 0)
         dec.set_device_scan(k % 3 == 1)  # a batch may mix host-walked images and images the device scans for markers
         info = dec.parse_header(m[name])
         n, tmp, base, planes = _alloc(torch, dec, info)
         dec.transfer(base, n, 0)
         total_scans += dec.layout().num_scans
+        sizes.add(dec.layout().subsequence_bytes)
         keep.append((dec, tmp, planes))
         entries.append((dec, [p.data_ptr() for p in planes], [p.stride(0) for p in planes], base, n))
         refs.append(oracle.decode(m[name]))
+    assert len(sizes) >= 3, sizes
     batch = jpeggpu_amd.Batch(total_scans)
     scratch = torch.empty(batch.scratch_size, dtype=torch.uint8, device="cuda:0")
     batch.set_items(entries)
@@ -426,7 +432,8 @@ def test_device_side_marker_scan(torch_cuda):
 def test_device_scan_agrees_with_host_walk_on_refusals(torch_cuda, monkeypatch):
     """What the host walk refuses at parse time gets the same status from the device: an FF FF 00 inside
     the scan (neither fill byte + marker nor stuffing), a scan no marker ends. And the checked mode that
-    JPEGGPU_DEVICE_SCAN=1 selects for callers of the drop-in API alone: decode itself returns that status."""
+    JPEGGPU_DEVICE_SCAN=2 selects for callers of the drop-in API alone: decode itself returns that status
+    (=1 keeps decode asynchronous: success at enqueue time whatever the stream holds)."""
     import jpeggpu_amd
     from jpeggpu_amd import JpegGpuError, Status
 
@@ -450,19 +457,22 @@ def test_device_scan_agrees_with_host_walk_on_refusals(torch_cuda, monkeypatch):
         assert lay.scans[0].device_scan and status == want, (name, status)
         assert want == Status.SUCCESS or all((p == 0x5A).all() for p in planes)
         # checked mode through the environment variable, drop-in calls only
-        monkeypatch.setenv("JPEGGPU_DEVICE_SCAN", "1")
-        dec = jpeggpu_amd.Decoder()
-        monkeypatch.delenv("JPEGGPU_DEVICE_SCAN")
-        info = dec.parse_header(data)
-        n, tmp, base, pl = _alloc(torch, dec, info)
-        dec.transfer(base, n, 0)
-        try:
-            dec.decode([p.data_ptr() for p in pl], [p.stride(0) for p in pl], base, n, 0)
-            got = Status.SUCCESS
-        except JpegGpuError as e:
-            got = e.status
-        assert got == want, (name, got)
-        dec.cleanup()
+        for env, expect in (("2", want), ("1", Status.SUCCESS)):
+            monkeypatch.setenv("JPEGGPU_DEVICE_SCAN", env)
+            dec = jpeggpu_amd.Decoder()
+            monkeypatch.delenv("JPEGGPU_DEVICE_SCAN")
+            info = dec.parse_header(data)
+            assert dec.layout().scans[0].device_scan
+            n, tmp, base, pl = _alloc(torch, dec, info)
+            dec.transfer(base, n, 0)
+            try:
+                dec.decode([p.data_ptr() for p in pl], [p.stride(0) for p in pl], base, n, 0)
+                got = Status.SUCCESS
+            except JpegGpuError as e:
+                got = e.status
+            assert got == expect, (name, env, got)
+            torch.cuda.synchronize()
+            dec.cleanup()
 
 
 def test_batch_with_bad_device_scanned_items(torch_cuda):
@@ -623,7 +633,8 @@ def test_config3_batch_of_64_twelve_megapixel_images(torch_cuda):
         want.append([hashlib.sha256(p.tobytes()).hexdigest() for p in ref.planes])
     keep, entries = [], []
     for i in range(64):
-        dec = jpeggpu_amd.Decoder(jpeggpu_amd.BATCH_SUBSEQ_BYTES)
+        dec = jpeggpu_amd.Decoder()
+        dec.set_batched(True)  # the library picks the subsequence size: 256 bytes for these
         if i % 2:
             dec.set_device_scan(True)
         info = dec.parse_header(datas[i % 8])
@@ -735,6 +746,26 @@ def test_segment_shard_bands_make_the_image(torch_cuda):
                 dec.cleanup()
             for c in range(ref.ncomp):
                 assert np.array_equal(planes[c].cpu().numpy(), ref.planes[c]), (name, world, c)
+    # a decoder that was sharded and is switched back (world = 1) decodes whole images again, device scan included;
+    # the layout says which mode and which walk an image got
+    data = m["dri_row"]
+    ref = oracle.decode(data)
+    dec = jpeggpu_amd.Decoder(64)
+    dec.set_device_scan(True)
+    for rank, world in ((1, 2), (0, 1)):
+        dec.set_segment_shard(rank, world)
+        info = dec.parse_header(data)
+        lay = dec.layout()
+        assert (lay.shard_rank, lay.shard_world) == (rank, world) and bool(lay.scans[0].device_scan) == (world == 1)
+        n, tmp, base, planes = _alloc(torch, dec, info)
+        for p in planes:
+            p.fill_(0xAB)
+        dec.transfer(base, n, 0)
+        dec.decode([p.data_ptr() for p in planes], [p.stride(0) for p in planes], base, n, 0)
+        torch.cuda.synchronize()
+        whole = all(np.array_equal(planes[c][:ref.planes[c].shape[0], :ref.planes[c].shape[1]].cpu().numpy(), ref.planes[c]) for c in range(ref.ncomp))
+        assert whole == (world == 1), (rank, world)
+    dec.cleanup()
     # what cannot be cut into bands says so at parse time
     for name in ("dri_7", "multi_seq_nodri", "ni_420_dri"):
         dec = jpeggpu_amd.Decoder()

@@ -198,6 +198,44 @@ def test_decoder_reuse_and_subsequence_knob(L):
     dec.cleanup()
 
 
+def test_subsequence_size_is_chosen_per_image(L, photo_bytes, monkeypatch):
+    """SURVEY.md 8f-4, the reference's own TODO (src/decoder_defs.hpp:28-34): the size follows the call type, the
+    scan's size and its restart density; an explicit size (call or environment) wins; 0 gives the choice back."""
+    from tools import jpegsynth
+
+    m = cases.matrix()
+    got = {}
+    for batched in (False, True):
+        dec = jpeggpu_amd.Decoder()
+        dec.set_batched(batched)
+        for name, data in (("photo", photo_bytes), ("dri_1", m["dri_1"]), ("dri_7", m["dri_7"]), ("small", m["ss_2x2"]),
+                           ("multi_seq_nodri", m["multi_seq_nodri"]), ("cfg4_small", m["cfg4_small"])):
+            dec.parse_header(data)
+            lay = dec.layout()
+            got[(name, batched)] = lay.subsequence_bytes
+            for s in range(lay.num_scans):  # the tables are those of the chosen size
+                assert lay.scans[s].num_subsequences == oracle.scan_info(data, s, lay.subsequence_bytes).num_subseq
+        dec.cleanup()
+    assert got[("photo", False)] == 64 and got[("photo", True)] == 256        # 12 MP, segments of ~15 KB
+    assert got[("multi_seq_nodri", False)] == 64 and got[("multi_seq_nodri", True)] in (128, 256)
+    assert got[("dri_1", True)] == 32 and got[("dri_1", False)] == 32       # a restart marker behind every MCU: ~60-byte segments
+    assert got[("dri_7", True)] <= 64
+    assert got[("small", True)] == 64                                          # a few kilobytes: not even one sequence
+    dec = jpeggpu_amd.Decoder(128)
+    dec.set_batched(True)
+    dec.parse_header(photo_bytes)
+    assert dec.layout().subsequence_bytes == 128
+    dec.set_subsequence_bytes(0)
+    dec.parse_header(photo_bytes)
+    assert dec.layout().subsequence_bytes == 256
+    dec.cleanup()
+    monkeypatch.setenv("JPEGGPU_SUBSEQ_BYTES", "32")
+    dec = jpeggpu_amd.Decoder()
+    dec.parse_header(photo_bytes)
+    assert dec.layout().subsequence_bytes == 32
+    dec.cleanup()
+
+
 def test_device_scan_knob_and_environment(L, monkeypatch):
     """jpeggpu_ext_set_device_scan / JPEGGPU_DEVICE_SCAN: a file whose first scan holds every component is parsed
     up to the scan header only (capacities instead of counts, a bigger buffer), a file with several scans keeps

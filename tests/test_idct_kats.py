@@ -25,6 +25,37 @@ def kats():
     return z, groups
 
 
+def test_fixture_equals_reference_built_library(kats):
+    """The pin itself: where the reference's sources are present (the authoring container) oracle/_ref/libref_idct.so
+    is rebuilt from /root/reference/src/idct.cu:43-144 (oracle/ref_lift/build.sh) and every vector and block of the
+    committed fixture is pushed through it again; where only the prebuilt library travelled (the GPU box) that one is
+    used; with neither the test is skipped. A fixture that no longer matches the reference's code fails here."""
+    import ctypes as C
+    import subprocess
+
+    from tests.conftest import ROOT
+
+    lib = os.path.join(ROOT, "oracle", "_ref", "libref_idct.so")
+    if os.path.isfile("/root/reference/src/idct.cu"):
+        subprocess.check_call(["bash", os.path.join(ROOT, "oracle", "ref_lift", "build.sh")], stdout=subprocess.DEVNULL)
+    if not os.path.exists(lib):
+        pytest.skip("neither /root/reference nor a prebuilt oracle/_ref/libref_idct.so")
+    L = C.CDLL(lib)
+    L.ref_idct_vectors.argtypes = [C.c_void_p, C.c_void_p, C.c_int]
+    L.ref_idct_blocks.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int]
+    z, groups = kats
+    vin = np.ascontiguousarray(z["vec_in"], np.int32)
+    vout = np.zeros_like(vin)
+    L.ref_idct_vectors(vin.ctypes.data, vout.ctypes.data, len(vin))
+    assert np.array_equal(vout, z["vec_out"])
+    for g in groups:
+        q, coef = np.ascontiguousarray(z[g + "/q"], np.uint8), np.ascontiguousarray(z[g + "/coef"], np.int16)
+        for signed, key in ((1, "/out"), (0, "/out_u")):
+            out = np.zeros((len(coef), 64), np.uint8)
+            L.ref_idct_blocks(coef.ctypes.data, q.ctypes.data, out.ctypes.data, len(coef), signed)
+            assert np.array_equal(out, z[g + key]), (g, key)
+
+
 def test_oracle_idct_vector_equals_reference(kats):
     from oracle import oracle
 

@@ -1,6 +1,8 @@
-"""N > 1 path on CPU: world_size 2 over gloo. Each rank takes its shard (image i -> rank i mod 2),
-produces flat planes (the oracle stands in for the device decode here), rank 0 gathers and checks
-that every image arrives, in global order, intact."""
+"""N > 1 path on CPU: world_size 2 over gloo. Each rank takes its shard (image i -> rank i mod 2) through the host side
+of the real flow -- parse_header, buffer sizing and plane geometry through the C ABI, the flat plane buffer laid out
+as bench.py lays it out -- and only the device decode itself is stood in for by the oracle (there is no GPU here);
+rank 0 gathers and checks that every image arrives, in global order, intact. The flow with the HIP decode in it runs
+as a -m gpu test (tests/test_gpu_api.py::test_bench_multi_rank_control_flow_over_gloo)."""
 import os
 import socket
 
@@ -30,16 +32,29 @@ def _worker(rank, world, port, num_images, result):
     os.environ["MASTER_PORT"] = str(port)
     dist.init_process_group("gloo", rank=rank, world_size=world)
     try:
+        import jpeggpu_amd
         from oracle import oracle
         from tools import jpegsynth
 
         mine = shard.shard_indices(num_images, rank, world)
-        flats = []
-        for g in mine:
-            d = oracle.decode(jpegsynth.encode(48, 32, seed=1000 + g))
-            flats.append(np.concatenate([p.reshape(-1) for p in d.planes]))
-        per_image = flats[0].size
-        local = torch.from_numpy(np.concatenate(flats))
+        per_image, local = None, None
+        for k, g in enumerate(mine):
+            data = jpegsynth.encode(48, 32, seed=1000 + g)
+            dec = jpeggpu_amd.Decoder()
+            dec.set_batched(True)
+            info = dec.parse_header(data)  # host side of the real flow: geometry, plan, buffer size
+            assert dec.get_buffer_size() > 0 and dec.layout().subsequence_bytes in (32, 64, 128, 256)
+            sizes = [(info.sizes_y[c], info.sizes_x[c]) for c in range(info.num_components)]
+            dec.cleanup()
+            if local is None:  # one flat tensor for the rank's planes, image after image, component after component
+                per_image = sum(h * w for h, w in sizes)
+                local = torch.empty(per_image * len(mine), dtype=torch.uint8)
+            d = oracle.decode(data)  # stands in for transfer + decode into the slots of the flat buffer
+            o = k * per_image
+            for c, (h, w) in enumerate(sizes):
+                assert d.planes[c].shape == (h, w)
+                local[o:o + h * w] = torch.from_numpy(d.planes[c].reshape(-1))
+                o += h * w
         gathered = shard.gather_planes(local, rank, world, dst=0)
         if rank == 0:
             images = shard.unshard(gathered, num_images, world, per_image)

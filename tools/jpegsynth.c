@@ -500,13 +500,25 @@ done:
  * [-1024, 1023], AC in [-1023, 1023]) and a given 8-bit quantisation table (natural order), Annex-K luma
  * Huffman tables: blocks_x * blocks_y data units in raster order. Lets a test push chosen coefficients
  * through a decoder's dequantisation + IDCT (tests/golden/idct_kats.npz). */
-size_t js_encode_blocks(const int16_t* coef, int blocks_x, int blocks_y, const uint8_t* q, int restart_interval, uint8_t* out, size_t cap)
+size_t js_encode_blocks_opt(const int16_t* coef, int blocks_x, int blocks_y, const uint8_t* q, int restart_interval, int optimize, uint8_t* out, size_t cap)
 {
     bitw w = {out, 0, cap, 0, 0, 0};
     htab dc, ac;
     if (blocks_x < 1 || blocks_y < 1 || blocks_x > 8191 || blocks_y > 8191) return 0;
-    htab_std(&dc, kDcLumaBits, kDcVals, 12);
-    htab_std(&ac, kAcLumaBits, kAcLumaVals, 162);
+    if (optimize) { /* code tables fitted to these very blocks (T.81 K.2): a test can then force the shortest codes */
+        long fdc[256] = {0}, fac[256] = {0};
+        int pred = 0, count = 0;
+        for (int m = 0; m < blocks_x * blocks_y; ++m) {
+            if (restart_interval && count == restart_interval) { pred = 0; count = 0; }
+            ++count;
+            code_block(NULL, coef + (size_t)m * 64, &pred, NULL, NULL, fdc, fac);
+        }
+        htab_optimal(&dc, fdc);
+        htab_optimal(&ac, fac);
+    } else {
+        htab_std(&dc, kDcLumaBits, kDcVals, 12);
+        htab_std(&ac, kAcLumaBits, kAcLumaVals, 162);
+    }
     put_marker(&w, 0xD8);
     put_marker(&w, 0xDB);
     put_u16(&w, 2 + 65);
@@ -556,4 +568,9 @@ size_t js_encode_blocks(const int16_t* coef, int blocks_x, int blocks_y, const u
     flush_bits(&w);
     put_marker(&w, 0xD9);
     return w.overflow ? 0 : w.n;
+}
+
+size_t js_encode_blocks(const int16_t* coef, int blocks_x, int blocks_y, const uint8_t* q, int restart_interval, uint8_t* out, size_t cap)
+{
+    return js_encode_blocks_opt(coef, blocks_x, blocks_y, q, restart_interval, 0, out, cap);
 }

@@ -31,15 +31,15 @@ def _load():
         _lib = C.CDLL(_LIB)
         _lib.js_encode.restype = C.c_size_t
         _lib.js_encode.argtypes = [C.POINTER(_Params), C.c_void_p, C.c_size_t]
-        _lib.js_encode_blocks.restype = C.c_size_t
-        _lib.js_encode_blocks.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_int, C.c_void_p, C.c_size_t]
+        _lib.js_encode_blocks_opt.restype = C.c_size_t
+        _lib.js_encode_blocks_opt.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_size_t]
     return _lib
 
 
-def encode_blocks(coef, blocks_x, q, restart_interval=0) -> bytes:
+def encode_blocks(coef, blocks_x, q, restart_interval=0, optimize=False) -> bytes:
     """Grayscale JPEG whose data units are the given quantised coefficient blocks: `coef` int16 [n, 64] in
     natural order (n a multiple of blocks_x), `q` uint8 [64] natural order. Block b lands at block row
-    b // blocks_x, column b % blocks_x."""
+    b // blocks_x, column b % blocks_x. `optimize`: Huffman tables fitted to these blocks instead of Annex K's."""
     import numpy as np
 
     coef = np.ascontiguousarray(coef, dtype=np.int16).reshape(-1, 64)
@@ -48,7 +48,7 @@ def encode_blocks(coef, blocks_x, q, restart_interval=0) -> bytes:
     assert n % blocks_x == 0
     cap = 4096 + n * 64 * 4
     buf = C.create_string_buffer(cap)
-    m = _load().js_encode_blocks(coef.ctypes.data, blocks_x, n // blocks_x, q.ctypes.data, restart_interval, buf, cap)
+    m = _load().js_encode_blocks_opt(coef.ctypes.data, blocks_x, n // blocks_x, q.ctypes.data, restart_interval, int(optimize), buf, cap)
     if m == 0:
         raise RuntimeError("jpegsynth: encode_blocks failed")
     return buf.raw[:m]

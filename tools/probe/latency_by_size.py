@@ -3,8 +3,11 @@ sys.path.insert(0, '.')
 import torch, jpeggpu_amd as jp
 from tools import jpegsynth
 S420 = ((2, 2), (1, 1), (1, 1))
-for (w, h) in ((320, 240), (640, 480), (1280, 720), (1920, 1080), (4032, 3024)):
-    data = jpegsynth.encode(w, h, S420, restart_interval=(w + 15) // 16, quality=88, noise=9, seed=5)
+inputs = [((w, h), jpegsynth.encode(w, h, S420, restart_interval=(w + 15) // 16, quality=88, noise=9, seed=5))
+          for (w, h) in ((320, 240), (640, 480), (1280, 720), (1920, 1080), (4032, 3024))]
+inputs.append((("photo", "IMG_6510"), open('tests/golden/IMG_6510.JPG', 'rb').read()))
+inputs.append((("cfg5", "no dri"), jpegsynth.config(5)))
+for (w, h), data in inputs:
     row = []
     for sb in (32, 64, 128, 256):
         dec = jp.Decoder(sb)
