@@ -92,15 +92,17 @@ struct BitWindow {
     JG_HD inline uint32_t peek(const Fetch& fetch)
     {
         if (sh < 0) { // at most 32 bits are consumed between two looks: one step is enough
-            hi = lo;
 #if defined(__HIP_DEVICE_COMPILE__)
-            // A real move at THIS point: left to itself the register coalescer lets `lo` and `next_raw` share a
-            // register, loads the new word into a temporary and copies it over at the loop's back edge -- behind
-            // an s_waitcnt for the load issued a few instructions earlier, which exposes the whole memory latency
-            // in every iteration (measured: write pass +21 %). With the move pinned here the load below targets
-            // next_raw's own register and is waited for one refill later.
-            asm("v_mov_b32 %0, %1" : "=v"(lo) : "v"(fetch.cook(next_raw, pos)));
+            // Two real moves at THIS point, in place: left to itself the register coalescer lets `lo` and `next_raw`
+            // share a register, loads the new word into a temporary and copies it over at the loop's back edge --
+            // behind an s_waitcnt for the load issued a few instructions earlier, which exposes the whole memory
+            // latency in every iteration (measured: write pass +21 %). With the moves pinned here the load below
+            // targets next_raw's own register and is waited for one refill later. Both operands are read-write: as
+            // fresh values the compiler merges them with the untouched `hi` / `lo` of the lanes that did not refill
+            // through two extra register copies per symbol.
+            asm("v_mov_b32 %0, %1\n\tv_mov_b32 %1, %2" : "+v"(hi), "+v"(lo) : "v"(fetch.cook(next_raw, pos)));
 #else
+            hi = lo;
             lo = fetch.cook(next_raw, pos);
 #endif
             sh += 32;
@@ -191,12 +193,7 @@ JG_HD inline uint32_t bits_field(uint32_t peek, int total_len, int s)
 
 /// Sink of the flow passes: nothing is stored; n and the DC sums of the subsequence are accumulated.
 struct NoSink {
-    static constexpr bool kWrite      = false;
-    static constexpr bool kWholeUnits = false;
-    static constexpr bool kSums       = true;
-    JG_HD inline bool full() const { return false; }
-    JG_HD inline void symbol(bool, int, int, int, int, bool) {}
-    JG_HD inline void tick() {}
+    static constexpr bool kSums = true;
 };
 
 /// Sink of the speculative pass: only the exit state (p, c, z) is wanted -- every subsequence is decoded
@@ -220,19 +217,14 @@ JG_HD inline int sym_entry_value(uint32_t e, uint32_t escape) { return static_ca
 /// Bit of a data-unit record's count that says "this unit holds an escape" (a count is at most 127).
 constexpr uint32_t kUnitHasEscape = 0x80u;
 
-/// Decode from `st` up to bit `end_bit` of the segment, committing symbols that end at or before it.
-/// `st.n`, `st.dc01`, `st.dc23` accumulate (not with SpecSink). `tabs` is the scan's table pack (LDS on
-/// the device).
+/// STATE-ONLY decode (speculative pass, flows) from `st` up to bit `end_bit` of the segment, committing the symbols
+/// that end at or before it. `st.n`, `st.dc01`, `st.dc23` accumulate (not with SpecSink). `tabs` is the scan's SYNC
+/// table pack (LDS on the device). The write pass has its own loop (decode_units, below).
 ///
-/// With Sink::kWholeUnits (write pass) a lane owns whole data units: those whose DC symbol its
-/// subsequence commits. It keeps decoding past `end_bit` until the unit it started is complete, and
-/// the sink ignores the symbols that finish the predecessor's unit.
-///
-/// ONE flat loop, one symbol per iteration for every lane: the data-unit boundary is handled with
-/// selects, not with a branch -- a branch there makes the compiler nest the loop, and a nested loop
-/// makes the 64 lanes of a wave wait for the longest data unit among them at every boundary.
-/// Coefficient slots are counted as 64 per closed unit plus the zig-zag index difference, which equals
-/// the reference's per-symbol count (decode_huffman.cu:302-394) on every valid stream.
+/// ONE flat loop for every lane: the data-unit boundary is handled with selects, not with a branch -- a branch
+/// there makes the compiler nest the loop, and a nested loop makes the 64 lanes of a wave wait for the longest
+/// data unit among them at every boundary. Coefficient slots are counted as 64 per closed unit plus the zig-zag
+/// index difference, which equals the reference's per-symbol count (decode_huffman.cu:302-394) on every valid stream.
 template <class Fetch, class Sink>
 JG_HD inline void decode_subsequence(
     LaneState& st,
@@ -241,7 +233,7 @@ JG_HD inline void decode_subsequence(
     int end_bit,
     const uint8_t* tabs,
     const ScanParams& sp,
-    Sink& sink)
+    Sink&)
 {
 #if defined(__HIP_DEVICE_COMPILE__)
     typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
@@ -266,20 +258,6 @@ JG_HD inline void decode_subsequence(
     bool is_dc = st.z == 0;
     uint32_t peek, e;
     int total;
-    // look the symbol under the bit window up: first-level LUT of the unit's DC or AC table, second level if needed
-#define JG_LOOKUP()                                                                                       \
-    do {                                                                                                  \
-        peek               = bw.peek(fetch);                                                              \
-        /* the sink's periodic flush goes right behind the refill: a refill waits for every memory operation  \
-           in flight (one counter for loads and stores on gfx9), so the stores get a whole iteration before   \
-           the next one asks -- at the end of the body they were waited for a few instructions later */       \
-        if (Sink::kWrite) sink.tick();                                                                    \
-        const TabPtr tab   = JG_TAB_AT(tabs, is_dc ? (JG_CUR_TABS & 0xFFFFu) : (JG_CUR_TABS >> 16));      \
-        const uint32_t idx = peek >> (is_dc ? 32 - kLutBitsDc : 32 - kLutBitsAc);                         \
-        e                  = ld_u16(tab + 2 * idx);                                                       \
-        if ((e & 31u) == 0) e = huff_second_level(tab, e, peek, is_dc);                                   \
-        total = e & 31;                                                                                   \
-    } while (0)
     // commit the symbol: advance the window and the zig-zag position, feed the sink / the sums, move the cursor
 #define JG_COMMIT()                                                                                       \
     do {                                                                                                  \
@@ -288,19 +266,7 @@ JG_HD inline void decode_subsequence(
         const int adv     = e >> 9;                                                                       \
         const int zp      = zm + adv; /* index of the symbol's coefficient */                             \
         const bool du_end = zp >= 63;                                                                     \
-        if (Sink::kWrite) {                                                                               \
-            /* branch-free: every lane computes the magnitude, only DC symbols move the sums */          \
-            const int s      = (e >> 5) & 15;                                                             \
-            const int v      = extend_magnitude(bits_field(peek, total, s), s);                           \
-            const int sh     = JG_CUR_META & 63;                                                          \
-            const uint64_t d = static_cast<uint64_t>(is_dc ? static_cast<uint32_t>(v) & 0xFFFFu : 0u) << sh; \
-            dc01             = pk_add_u16(dc01, static_cast<uint32_t>(d));                                \
-            dc23             = pk_add_u16(dc23, static_cast<uint32_t>(d >> 32));                          \
-            /* the component's running sum is the absolute DC value, 16-bit wrap like the reference's   \
-               int16 prefix sum (decode_dc.cu:129-155); an AC coefficient sits at zig-zag index zp */          \
-            const int absdc = static_cast<int>(((static_cast<uint64_t>(dc23) << 32) | dc01) >> sh);       \
-            sink.symbol(is_dc, s, zp, v, absdc, du_end);                                \
-        } else if (Sink::kSums && is_dc) {                                                                \
+        if (Sink::kSums && is_dc) {                                                                       \
             const int s      = (e >> 5) & 15;                                                             \
             const int v      = extend_magnitude(bits_field(peek, total, s), s);                           \
             const uint64_t d = static_cast<uint64_t>(static_cast<uint32_t>(v) & 0xFFFFu) << (JG_CUR_META & 63); \
@@ -308,19 +274,11 @@ JG_HD inline void decode_subsequence(
             dc23             = pk_add_u16(dc23, static_cast<uint32_t>(d >> 32));                          \
         }                                                                                                 \
         zm = du_end ? -1 : zp;                                                                            \
-        if (Sink::kWrite || Sink::kSums) units += du_end ? 1 : 0;                                         \
+        if (Sink::kSums) units += du_end ? 1 : 0;                                                         \
         cur = JG_LOAD_CURSOR(du_end ? JG_CUR_NEXT : JG_CUR_SELF);                                         \
         is_dc = du_end;                /* a unit just ended <=> the next symbol is a DC symbol */         \
     } while (0)
-    if (Sink::kWrite) {
-        // test at the top: measured 5 % faster for the emitting pass than the rotated form below
-        while (true) {
-            JG_LOOKUP();
-            const bool beyond = p + total > end_bit;
-            if (Sink::kWholeUnits ? (is_dc && (beyond || sink.full())) : beyond) break;
-            JG_COMMIT();
-        }
-    } else {
+    {
         // State-only passes walk the SYNC pack (jg_defs.h): 32-bit first-level entries whose high half stands for
         // as many AC symbols as lie inside the index bits. While at least 31 bits are left in front of `end_bit`
         // whatever an entry stands for fits (a symbol takes at most 16 + 15 bits, a multi-symbol entry at most the 11
@@ -362,14 +320,161 @@ JG_HD inline void decode_subsequence(
         }
 #undef JG_LOOKUP_SYNC
     }
-#undef JG_LOOKUP
 #undef JG_COMMIT
-    if (Sink::kWrite || Sink::kSums) st.n += 64 * units + (zm + 1) - st.z;
+    if (Sink::kSums) st.n += 64 * units + (zm + 1) - st.z;
     st.p    = p;
     st.z    = zm + 1;
     st.c    = (JG_CUR_META >> 8) & 0xFF;
     st.dc01 = dc01;
     st.dc23 = dc23;
+#undef JG_LOAD_CURSOR
+#undef JG_CUR_TABS
+#undef JG_CUR_META
+#undef JG_CUR_SELF
+#undef JG_CUR_NEXT
+}
+
+/// Iterations of the write pass's loop between two DC SLOTS (below).
+constexpr int kWriteDcPeriod = 4;
+
+JG_HD inline uint32_t bit_mask(int s)
+{
+    // 2^s - 1, s in 0..31 (one v_bfm_b32 on the device; the compiler makes a shift and a NOT of the C form)
+#if defined(__HIP_DEVICE_COMPILE__)
+    uint32_t m;
+    asm("v_bfm_b32 %0, %1, 0" : "=v"(m) : "v"(s));
+    return m;
+#else
+    return (1u << s) - 1u;
+#endif
+}
+
+/// First-level entry (16 bits) of the table at `tab` for the window `peek`: entry (peek >> (32 - kLutBits)). On the
+/// device the address is a shift and a shift-add; left alone the compiler folds the two shifts into shift, AND, add.
+template <int kLutBits>
+JG_HD inline uint32_t lut16_entry(TabPtr tab, uint32_t peek)
+{
+#if defined(__HIP_DEVICE_COMPILE__) && defined(JG_TABS_IN_LDS)
+    uint32_t a;
+    asm("v_lshrrev_b32 %0, %1, %2\n\tv_lshl_add_u32 %0, %0, 1, %3"
+        : "=&v"(a)
+        : "n"(32 - kLutBits), "v"(peek), "v"(static_cast<uint32_t>(reinterpret_cast<uintptr_t>(tab))));
+    return ld_u16(reinterpret_cast<TabPtr>(static_cast<uintptr_t>(a)));
+#else
+    return ld_u16(tab + 2 * (peek >> (32 - kLutBits)));
+#endif
+}
+
+/// T.81 F.2.2.1 EXTEND as extend_magnitude above, around bit_mask.
+JG_HD inline int extend_bits(uint32_t bits, int s)
+{
+    const uint32_t mask = bit_mask(s);
+    return bits > (mask >> 1) ? static_cast<int>(bits) : static_cast<int>(bits - mask);
+}
+
+/// The symbol loop of the WRITE PASS: decode from `st` and hand every coefficient to `sink`, for the data units the
+/// lane OWNS: those whose DC symbol its subsequence commits. It runs past the end of the subsequence to finish the last
+/// of them and stops in front of the first unit of the next lane -- which the caller knows as a unit INDEX (the
+/// coefficient counts of the synchronisation passes place every lane's first unit: `sink.full()`), so no bit position
+/// is tracked here at all. Same symbols, same rules as decode_subsequence (reference decode_huffman.cu:302-394,
+/// 627-682) -- arranged for a wave that is bound by the number of vector instructions it issues:
+///
+///   * every iteration has an AC SECTION: a lane that is inside a data unit decodes one AC symbol -- table look-up,
+///     magnitude, one 16-bit entry into the sink's ring. Nothing else: no DC arithmetic, no table selection, no unit
+///     bookkeeping, no selects between "DC lane" and "AC lane" values;
+///   * every kWriteDcPeriod-th iteration starts with a DC SLOT: the lanes that stand at the start of a data unit
+///     close the record of the unit they finished, test the stop rule, load the next unit's cursor entry (tables,
+///     component), decode the DC symbol and add it to the component's predictor. A lane that reaches a unit's end
+///     between two slots WAITS for the next one.
+///
+/// In a wave of 64 lanes some lane is at a unit boundary in nearly every iteration, so the one-symbol-per-iteration
+/// loop above pays the DC and boundary work -- about as many instructions as the AC work -- EVERY iteration, as selects.
+/// Here it is paid every fourth, and a lane loses 1.5 iterations per unit (of ~10 symbols) waiting (DESIGN.md section
+/// 3). The results do not depend on the period (a host emulation runs one lane at a time). `max_iters` bounds the loop
+/// whatever the stream holds (a valid one needs fewer than one iteration per bit).
+template <class Fetch, class Sink>
+JG_HD inline void decode_units(
+    const LaneState& st,
+    BitWindow<Fetch>& bw,
+    const Fetch& fetch,
+    const uint8_t* tabs,
+    const ScanParams& sp,
+    Sink& sink,
+    int max_iters,
+    int* iters_out = nullptr) // probe builds: iterations this lane stayed in the loop
+{
+#if defined(__HIP_DEVICE_COMPILE__)
+    typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
+#define JG_LOAD_CURSOR(off) (*reinterpret_cast<JG_TAB_AS const u32x4*>(JG_TAB_AT(tabs, off)))
+#define JG_CUR_TABS cur[0]
+#define JG_CUR_META cur[1]
+#define JG_CUR_SELF cur[2]
+#define JG_CUR_NEXT cur[3]
+    typedef u32x4 Cursor;
+#else
+#define JG_LOAD_CURSOR(off) (*reinterpret_cast<const CursorEntry*>(tabs + (off)))
+#define JG_CUR_TABS cur.tabs
+#define JG_CUR_META cur.meta
+#define JG_CUR_SELF cur.self
+#define JG_CUR_NEXT cur.next
+    typedef CursorEntry Cursor;
+#endif
+    // zig-zag index minus one of the lane's position inside its unit; kAtUnitStart: the next symbol is a DC symbol;
+    // kStopped: the lane is done. Everything >= 63 is "not inside a unit": one compare per section.
+    constexpr int kAtUnitStart = 64, kStopped = 128;
+    int zm;
+    uint32_t actab, unit_entry;                // AC table of the unit the lane is in; cursor entry of the next unit to start
+    {
+        const Cursor cur = JG_LOAD_CURSOR(sp.cursor_off + 16u * static_cast<uint32_t>(st.c));
+        zm               = st.z ? st.z - 1 : kAtUnitStart;
+        actab            = JG_CUR_TABS >> 16;
+        unit_entry       = st.z ? JG_CUR_NEXT : JG_CUR_SELF;
+    }
+    uint32_t dc01 = st.dc01, dc23 = st.dc23;  // predictors: running sums of the DC differences, per component
+    for (int it = 0; it < max_iters; ++it) {
+        if ((it & (kWriteDcPeriod - 1)) == 0) { // the same iterations for every lane of a wave
+            if (zm >= 63) {
+                sink.unit_boundary();           // the unit the lane finished since the last slot, if any, is complete
+                if (sink.full()) {
+                    zm = kStopped;              // the next unit is the next lane's, or lies past the segment
+                } else {
+                    const Cursor cur    = JG_LOAD_CURSOR(unit_entry);
+                    const uint32_t peek = bw.peek(fetch);
+                    const TabPtr tab    = JG_TAB_AT(tabs, JG_CUR_TABS & 0xFFFFu);
+                    uint32_t e          = lut16_entry<kLutBitsDc>(tab, peek);
+                    if ((e & 31u) == 0) e = huff_second_level(tab, e, peek, true);
+                    const int total = e & 31;
+                    bw.skip(total);
+                    const int s      = (e >> 5) & 15;
+                    const int v      = extend_bits(bits_field(peek, total, s), s);
+                    const int sh     = JG_CUR_META & 63;
+                    const uint64_t d = static_cast<uint64_t>(static_cast<uint32_t>(v) & 0xFFFFu) << sh;
+                    dc01             = pk_add_u16(dc01, static_cast<uint32_t>(d));
+                    dc23             = pk_add_u16(dc23, static_cast<uint32_t>(d >> 32));
+                    // the component's running sum is the absolute DC value, 16-bit wrap like the reference's int16
+                    // prefix sum (decode_dc.cu:129-155)
+                    sink.dc(static_cast<int>(((static_cast<uint64_t>(dc23) << 32) | dc01) >> sh));
+                    actab      = JG_CUR_TABS >> 16;
+                    unit_entry = JG_CUR_NEXT;
+                    zm         = 0;
+                }
+            }
+            if (zm == kStopped) break;
+        }
+        if (zm < 63) {
+            const uint32_t peek = bw.peek(fetch);
+            const TabPtr tab    = JG_TAB_AT(tabs, actab);
+            uint32_t e          = lut16_entry<kLutBitsAc>(tab, peek);
+            if ((e & 31u) == 0) e = huff_second_level(tab, e, peek, false);
+            const int total = e & 31;
+            bw.skip(total);
+            const int s = (e >> 5) & 15;
+            zm += static_cast<int>(e >> 9); // index of the symbol's coefficient; 63 or more: the unit is complete
+            sink.ac(s, zm, extend_bits(bits_field(peek, total, s), s));
+        }
+        sink.tick();
+        if (iters_out) *iters_out = it + 1;
+    }
 #undef JG_LOAD_CURSOR
 #undef JG_CUR_TABS
 #undef JG_CUR_META

@@ -20,6 +20,8 @@
 
 #include <hip/hip_runtime.h>
 
+#include <cstdlib>
+
 #include "jg_bytes.h"
 #include "jg_wave.h"
 
@@ -374,6 +376,9 @@ struct GlobalFetch {
     }
     __device__ __forceinline__ uint32_t load(const Pos& q) const
     {
+#if defined(JG_EXP_FAKE_REFILL) // timing experiments only: no memory operation in the symbol loops (results are garbage)
+        if (kCrossRows) return q.off * 2654435761u ^ (q.off >> 7);
+#endif
         return *reinterpret_cast<JG_GLOBAL const uint32_t*>(reinterpret_cast<JG_GLOBAL const uint8_t*>(scan32) + q.off);
     }
     __device__ __forceinline__ uint32_t cook(uint32_t v, const Pos&) const { return v; }
@@ -383,6 +388,8 @@ struct GlobalFetch {
 // Probe builds only (python jpeggpu_amd/build.py out.so -DJG_PROBE): 100 MHz time stamps of the passes of
 // huff_sync_intra, 64 per workgroup; read back with jpeggpu_probe_read (tools/probe/sync_stamps.py).
 __device__ uint32_t g_probe[4096 * 64];
+// huff_write: [0] sum over lanes of loop iterations (low 32 bits), [1] high bits, [2] largest, [3] lanes (tools/probe/write_iters.py)
+__device__ unsigned long long g_probe_write[4];
 #define JG_STAMP(i)                                                                                       \
     do {                                                                                                  \
         if (threadIdx.x == 0 && blockIdx.x < 4096 && (i) < 64) g_probe[blockIdx.x * 64 + (i)] = static_cast<uint32_t>(wall_clock64()); \
@@ -751,28 +758,27 @@ constexpr int kRingWords    = 16;                         // 32-bit words of a l
 constexpr int kRingStride   = (kRingWords + 1) * 4;       // bytes from one lane's ring to the next: 17 words, an odd number of banks
 constexpr int kStageEntries = 2 * kRingWords;             // entries the ring holds (a power of two)
 constexpr int kFlushEntries = kSymSectorEntries;          // entries per flush: 16 = one 32-byte sector
-constexpr int kFlushPeriod  = 8;                          // iterations between two flush points
+constexpr int kFlushPeriod  = 6;                          // iterations between two flush points
 
 /// Sink of the write pass: a compact symbol stream instead of a dense coefficient buffer (jg_defs.h). Every lane
 /// appends 16-bit entries to its own region, contiguous per data unit, and records {first entry, count} per
-/// data unit when the unit completes. A lane owns whole data units (jg_huff_core.h, kWholeUnits), so a unit's
+/// data unit when the unit completes. A lane owns whole data units (jg_huff_core.h, decode_units), so a unit's
 /// entries never span two regions. Compared with scattered 2-byte stores into a pre-zeroed buffer (reference
 /// decode_huffman.cu:360-371 + decoder.cpp:256-263) this needs no zero-fill and writes each byte once.
 ///
 /// A lane's appends must not go to memory one by one: with many images in flight the ~200 k open lines do not fit
 /// in L2 and every append becomes its own 32-byte sector write. Entries are therefore collected in a ring per lane
-/// in LDS (32 entries = 64 bytes, rings 17 words apart: the lanes of a wave hit different banks) and every 8
+/// in LDS (32 entries = 64 bytes, rings 17 words apart: the lanes of a wave hit different banks) and every 6
 /// iterations ALL lanes that have 16 or more waiting flush one whole 32-byte sector: an iteration adds at most two
-/// entries (a coefficient and its escape), so at most 15 stay behind and at most 16 arrive in between.
+/// entries from its AC section (a coefficient and its escape) and every fourth one more from its DC slot, so at most
+/// 15 stay behind and at most 14 arrive in between.
 ///
-/// The kernel is bound by vector-instruction issue, so the per-symbol part is counted in instructions: the ring
-/// address is an AND and a shift-add; the escape flag of the open unit lives in `du_off` (minus 128, so that
-/// entries - du_off comes out with bit 7 set); the counts of finished units are shifted into a 64-bit register from
-/// the top (two funnel shifts and two selects).
+/// The kernel is bound by vector-instruction issue, so the per-symbol part is counted in instructions: an AC symbol
+/// is one ring store and an add-with-carry (zero coefficients, and everything a lane decodes before its first DC
+/// symbol -- the tail of its predecessor's unit --, are stored where the next kept entry will overwrite them: no
+/// select, no test; the first DC symbol rewinds the lane's count). The region cannot overflow on a valid stream
+/// (jg_defs.h, sym_region_entries); on a corrupt one the flush drops what lies beyond it.
 struct StreamSink {
-    static constexpr bool kWrite      = true;
-    static constexpr bool kWholeUnits = true;
-    static constexpr bool kSums       = true;
     JG_GLOBAL uint16_t* sym;
     JG_GLOBAL uint2_t* du_tab;
     uint32_t ring;      // LDS byte address of the lane's ring: entry n at ring + (n % 32) * 2
@@ -783,7 +789,7 @@ struct StreamSink {
     uint32_t du_off;    // first entry of the unit being decoded, minus kUnitHasEscape once it has taken an escape entry
     int du;       // next data unit this lane starts
     int quota;    // first data unit past the segment
-    int ticks;
+    int countdown; // iterations to the next flush point (the same in every lane)
     // Data-unit records {first entry, count} wait here until FOUR of them fill a 32-byte sector of the table: a
     // lane's units are consecutive in the table and contiguous in its region, so the table index and the offset of
     // the first waiting one, plus packed entry counts (up to eight, one byte each), describe them. Stored one by
@@ -794,10 +800,9 @@ struct StreamSink {
     int rec_du;         // its index in the data-unit table
     uint32_t pend_lo, pend_hi; // counts (| kUnitHasEscape) of the waiting units: the TOP pend_n bytes of hi:lo, oldest lowest
     int pend_n;
-    bool started; // false while the first symbols finish the predecessor's data unit
+    bool started; // false until the lane's first DC symbol: what it decodes before finishes the predecessor's data unit
     __device__ __forceinline__ bool full() const { return du >= quota; }
-    /// 16-bit store into the lane's ring. A lane that has nothing to keep stores all the same, into the slot its
-    /// next kept entry will overwrite (at most 31 entries wait, so slot n is free): no select, no spare row.
+    /// 16-bit store into the lane's ring, slot n % 32.
     __device__ __forceinline__ void put(uint32_t n, uint32_t entry)
     {
         typedef __attribute__((address_space(3))) uint16_t LdsHalf;
@@ -805,32 +810,40 @@ struct StreamSink {
         asm("v_and_b32 %0, %1, %2\n\tv_lshl_add_u32 %0, %0, 1, %3" : "=&v"(a) : "n"(kStageEntries - 1), "v"(n), "v"(ring));
         *reinterpret_cast<LdsHalf*>(static_cast<uintptr_t>(a)) = static_cast<uint16_t>(entry);
     }
-    /// One call per decoded symbol: a DC symbol brings the absolute DC value `dc`, an AC symbol the coefficient
-    /// `value` at zig-zag index `zpos`. Zero AC coefficients, symbols that finish the predecessor's unit, and
-    /// anything past the region on a corrupt stream are stored where the next kept entry will go.
-    __device__ __forceinline__ void symbol(bool is_dc, int category, int zpos, int value, int dc, bool unit_end)
+    /// DC slot, a lane at the start of a data unit: the unit it finished since the previous slot (if it has started
+    /// one) is complete -- its entry count joins the waiting records at the top. At most one per slot; a flush point
+    /// every six iterations leaves at most three waiting: eight places are enough.
+    __device__ __forceinline__ void unit_boundary()
     {
-        du_off = is_dc ? emitted : du_off;
-        du += is_dc ? 1 : 0;
-        started         = started || is_dc;
-        const bool emit = started && (is_dc || category != 0) && emitted < cur_end;
-        put(emitted, is_dc ? static_cast<uint32_t>(dc) : sym_entry_ac(zpos, value));
-        emitted += emit ? 1u : 0u;
+        if (started) {
+            const uint32_t cnt = emitted - du_off; // entries | kUnitHasEscape
+            pend_lo            = __builtin_amdgcn_alignbit(pend_hi, pend_lo, 8);
+            pend_hi            = __builtin_amdgcn_alignbit(cnt, pend_hi, 8);
+            ++pend_n;
+        }
+    }
+    /// The DC symbol that opens a unit: its absolute DC value is the unit's first entry.
+    __device__ __forceinline__ void dc(int value)
+    {
+        emitted = started ? emitted : 0u; // what was stored before belongs to the predecessor's lane
+        started = true;
+        du_off  = emitted;
+        ++du;
+        put(emitted, static_cast<uint32_t>(value));
+        ++emitted;
+    }
+    /// An AC symbol of category `category` whose coefficient `value` sits at zig-zag index `zpos`; category 0 (a run
+    /// of zeros, an end of block) keeps nothing.
+    __device__ __forceinline__ void ac(int category, int zpos, int value)
+    {
+        put(emitted, sym_entry_ac(zpos, value));
+        emitted += category != 0 ? 1u : 0u;
         // a coefficient of category 10 or more (no photograph has one) takes a second entry
-        if (__builtin_expect(emit && !is_dc && category >= kEscapeFromCategory, 0)) {
+        if (__builtin_expect(category >= kEscapeFromCategory, 0)) {
             put(emitted, sym_entry_escape(value));
-            emitted += emitted < cur_end ? 1u : 0u;
+            ++emitted;
             du_off -= ((emitted - du_off) & kUnitHasEscape) ? 0u : kUnitHasEscape; // once per unit (a unit has at most 127 entries)
         }
-        // A unit takes at least two symbols, so at most four finish between two flush points (8 iterations); a
-        // flush leaves at most three waiting: eight slots are enough. The count enters at the top.
-        const bool done    = unit_end && started;
-        const uint32_t cnt = emitted - du_off; // entries | kUnitHasEscape
-        const uint32_t lo = __builtin_amdgcn_alignbit(pend_hi, pend_lo, 8);
-        const uint32_t hi = __builtin_amdgcn_alignbit(cnt, pend_hi, 8);
-        pend_lo = done ? lo : pend_lo;
-        pend_hi = done ? hi : pend_hi;
-        pend_n += done ? 1 : 0;
     }
     /// Store the first `n` waiting records (1..4).
     __device__ __forceinline__ void store_units(int n)
@@ -880,7 +893,7 @@ struct StreamSink {
 #if defined(JG_EXP_NO_SECTOR_STORES)
         if (e[0] == 0xFFFFFFFEu && e[1] == 0x12345678u)
 #endif
-        {
+        if (flushed < cur_end) { // a region cannot overflow on a valid stream; a corrupt one loses what lies beyond it
             st_global(dst, make_uint4(e[0], e[1], e[2], e[3]));
             st_global(dst + 1, make_uint4(e[4], e[5], e[6], e[7]));
         }
@@ -888,8 +901,9 @@ struct StreamSink {
     }
     __device__ __forceinline__ void tick()
     {
-        if ((++ticks & (kFlushPeriod - 1)) == 0) { // the same iteration for every lane of the wave
-            if (emitted - flushed >= static_cast<uint32_t>(kFlushEntries)) flush_sector();
+        if (--countdown == 0) { // the same iteration for every lane of the wave
+            countdown = kFlushPeriod;
+            if (started && emitted - flushed >= static_cast<uint32_t>(kFlushEntries)) flush_sector();
             flush_units();
         }
     }
@@ -897,6 +911,7 @@ struct StreamSink {
     /// last valid one are never read: the data-unit table bounds every gather).
     __device__ __forceinline__ void finish()
     {
+        if (!started) return; // the lane's subsequence lies inside one data unit: nothing of it is kept here
         while (flushed < emitted) flush_sector();
         while (pend_n > 0) store_units(pend_n < 4 ? pend_n : 4);
     }
@@ -1007,11 +1022,12 @@ __global__ __launch_bounds__(T) void huff_write(JS js)
     sink.sym     = J.sym;
     sink.du_tab  = J.du_tab;
     sink.ring    = lds_address(s_ring) + static_cast<uint32_t>(t) * kRingStride;
-    int nprefix  = 0;
+    int nprefix  = 0, nnext = 0; // coefficient slots of the segment in front of this lane's subsequence / of the next one's
     uint32_t pred01 = 0, pred23 = 0; // DC predictors at the lane's first symbol: sums over the segment so far
     {
         block_excl_scan_256<false>(active ? static_cast<uint32_t>(J.st_n[sub]) : 0u, s_scan, s_wave);
         nprefix = static_cast<int>(s_scan[t] - s_scan[ts] + (carried ? s_carry[0] : 0u));
+        nnext   = static_cast<int>(s_scan[t + 1] - s_scan[ts] + (carried ? s_carry[0] : 0u));
         block_excl_scan_256<true>(active ? J.st_dc01[sub] : 0u, s_scan, s_wave);
         const uint32_t p01 = pk_add(pk_sub(s_scan[t], s_scan[ts]), carried ? s_carry[1] : 0u);
         block_excl_scan_256<true>(active ? J.st_dc23[sub] : 0u, s_scan, s_wave);
@@ -1024,13 +1040,17 @@ __global__ __launch_bounds__(T) void huff_write(JS js)
     const int seg_mcus0 = seg_i * sp.mcus_per_segment;
     const int seg_mcus1 = min(seg_mcus0 + sp.mcus_per_segment, sp.total_mcus); // Appendix B-5 clamp
     sink.du             = seg_mcus0 * sp.du_per_mcu + ((nprefix + 63) >> 6);
+    // The lane stops in front of the first unit the NEXT lane starts (the same formula one subsequence on: a lane owns
+    // the units whose DC symbol its subsequence commits, reference decode_huffman.cu:350-355), or at the segment's
+    // quota of data units if it is the segment's last (Appendix B-5).
     sink.quota          = seg_mcus1 * sp.du_per_mcu;
+    if (rel + 1 < seg.subseq_count) sink.quota = min(sink.quota, seg_mcus0 * sp.du_per_mcu + ((nnext + 63) >> 6));
     sink.base           = sym_region_base(static_cast<uint32_t>(sub), J.sym_region);
     sink.flushed        = 0;
     sink.emitted        = 0;
     sink.cur_end        = J.sym_region;
     sink.du_off         = 0;
-    sink.ticks          = 0;
+    sink.countdown      = kFlushPeriod;
     sink.rec_off        = 0;
     sink.rec_du         = sink.du; // the first unit this lane starts
     sink.pend_lo        = 0;
@@ -1046,12 +1066,21 @@ __global__ __launch_bounds__(T) void huff_write(JS js)
         st.c         = cz & 0xFF;
         st.z         = cz >> 8;
     }
-    sink.started = st.z == 0;
+    sink.started = false; // until the lane's first DC symbol
     GlobalFetch<W, true> fetch{reinterpret_cast<JG_GLOBAL const uint32_t*>(J.destuffed), 0, 0};
     fetch.set_row(sub, rel);
     BitWindow<GlobalFetch<W, true>> bw{};
     bw.seek(st.p, fetch);
-    decode_subsequence(st, bw, fetch, (rel + 1) * (W * 32), s_tab, sp, sink);
+    // a valid stream takes less than one iteration per bit of the subsequence and of the unit the lane runs on into
+#if defined(JG_PROBE)
+    int iters = 0;
+    decode_units(st, bw, fetch, s_tab, sp, sink, 2 * (W * 32 + 64 * 32), &iters);
+    atomicAdd(&g_probe_write[0], static_cast<unsigned long long>(iters));
+    atomicMax(&g_probe_write[2], static_cast<unsigned long long>(iters));
+    atomicAdd(&g_probe_write[3], 1ull);
+#else
+    decode_units(st, bw, fetch, s_tab, sp, sink, 2 * (W * 32 + 64 * 32));
+#endif
     sink.finish();
 }
 
@@ -1446,9 +1475,15 @@ hipError_t launch_huff(Stage stage, const JS& js, const JobExtent& e, int grid_y
             }
         }
         break;
-    case kStageWrite:
-        huff_write<W, JS><<<dim3(e.max_seq, grid_y), T, WriteLds::kTabs + e.max_tab_bytes, stream>>>(js);
+    case kStageWrite: {
+        size_t lds = WriteLds::kTabs + e.max_tab_bytes;
+#if defined(JG_PROBE) // occupancy experiments: JPEGGPU_EXP_EXTRA_LDS bytes of LDS nobody uses (fewer workgroups per CU)
+        if (const char* x = std::getenv("JPEGGPU_EXP_EXTRA_LDS")) lds += static_cast<size_t>(std::atoi(x));
+        if ((err = allow_lds(huff_write<W, JS>, lds)) != hipSuccess) return err;
+#endif
+        huff_write<W, JS><<<dim3(e.max_seq, grid_y), T, lds, stream>>>(js);
         break;
+    }
     default: return hipErrorInvalidValue;
     }
     return hipGetLastError();
@@ -1490,6 +1525,16 @@ hipError_t launch_any(Stage stage, const JS& js, const JobExtent& e, int grid_y,
 } // namespace
 
 #if defined(JG_PROBE)
+extern "C" __attribute__((visibility("default"))) int jpeggpu_probe_read_write(unsigned long long* dst4, int clear)
+{
+    if (hipMemcpyFromSymbol(dst4, HIP_SYMBOL(g_probe_write), sizeof(g_probe_write)) != hipSuccess) return 1;
+    if (clear) {
+        void* p = nullptr;
+        if (hipGetSymbolAddress(&p, HIP_SYMBOL(g_probe_write)) != hipSuccess || hipMemset(p, 0, sizeof(g_probe_write)) != hipSuccess) return 2;
+    }
+    return 0;
+}
+
 extern "C" __attribute__((visibility("default"))) int jpeggpu_probe_read(void* dst, size_t bytes, int clear)
 {
     if (hipMemcpyFromSymbol(dst, HIP_SYMBOL(g_probe), bytes) != hipSuccess) return 1;

@@ -32,37 +32,38 @@ struct HostFetch {
 };
 
 /// Host twin of the write pass's sink (StreamSink in jg_kernels.hip): symbol stream (jg_defs.h: 16-bit entries,
-/// escapes behind coefficients that do not fit 10 bits) + data-unit table.
+/// escapes behind coefficients that do not fit 10 bits) + data-unit table, fed by decode_units (jg_huff_core.h).
 struct HostSink {
-    static constexpr bool kWrite      = true;
-    static constexpr bool kWholeUnits = true;
-    static constexpr bool kSums       = true;
     uint16_t* sym;
     uint2_t* du_tab;
     uint32_t cur, cur_end, du_off;
     int du_index;
-    int du, quota; // next data unit to start, first data unit past the segment
-    bool started;
+    int du, quota; // next data unit to start; first data unit of the next lane (or past the segment)
+    bool started = false, open = false; // a DC symbol was seen; a unit's record is still to be written
     uint32_t unit_esc = 0;
     bool full() const { return du >= quota; }
-    void symbol(bool is_dc, int category, int zpos, int ac_value, int dc, bool unit_end)
+    void unit_boundary()
     {
-        const bool nonzero = category != 0;
-        const int value = is_dc ? dc : ac_value;
-        if (is_dc) {
-            started  = true;
-            du_off   = cur;
-            du_index = du++;
-            unit_esc = 0;
+        if (open) du_tab[du_index] = uint2_t{du_off, (cur - du_off) | unit_esc};
+        open = false;
+    }
+    void dc(int value)
+    {
+        started  = true;
+        open     = true;
+        du_off   = cur;
+        du_index = du++;
+        unit_esc = 0;
+        if (cur < cur_end) sym[cur++] = static_cast<uint16_t>(static_cast<uint32_t>(value));
+    }
+    void ac(int category, int zpos, int value)
+    {
+        if (!started || category == 0) return; // the tail of the predecessor's unit; runs of zeros and ends of block
+        if (cur < cur_end) sym[cur++] = static_cast<uint16_t>(sym_entry_ac(zpos, value));
+        if (category >= kEscapeFromCategory) {
+            if (cur < cur_end) sym[cur++] = static_cast<uint16_t>(sym_entry_escape(value));
+            unit_esc = kUnitHasEscape;
         }
-        if ((is_dc || (started && nonzero)) && cur < cur_end) {
-            sym[cur++] = static_cast<uint16_t>(is_dc ? static_cast<uint32_t>(value) : sym_entry_ac(zpos, value));
-            if (!is_dc && sym_needs_escape(value)) {
-                if (cur < cur_end) sym[cur++] = static_cast<uint16_t>(sym_entry_escape(value));
-                unit_esc = kUnitHasEscape;
-            }
-        }
-        if (unit_end && started) du_tab[du_index] = uint2_t{du_off, (cur - du_off) | unit_esc};
     }
     void tick() {}
 };
@@ -355,7 +356,9 @@ int emu_decode_scan(
             const auto sub16 = [](uint32_t a, uint32_t b) { return pk_add_u16(a, pk_add_u16(~b, 0x00010001u)); };
             const int m0 = seg_i * sp.mcus_per_segment, m1 = std::min(m0 + sp.mcus_per_segment, sp.total_mcus);
             sink.du    = m0 * sp.du_per_mcu + ((nprefix + 63) >> 6);
+            // the lane stops in front of the next lane's first unit, or at the segment's quota if it is the last
             sink.quota = m1 * sp.du_per_mcu;
+            if (rel + 1 < seg.subseq_count) sink.quota = std::min(sink.quota, m0 * sp.du_per_mcu + ((nprefix + st[sub].n + 63) >> 6));
             LaneState ls{};
             ls.dc01 = pk_add_u16(sub16(ex[t].dc01, ex[ts].dc01), carried ? carry.dc01 : 0u); // predictors so far
             ls.dc23 = pk_add_u16(sub16(ex[t].dc23, ex[ts].dc23), carried ? carry.dc23 : 0u);
@@ -364,11 +367,11 @@ int emu_decode_scan(
                 ls.c = st[sub - 1].cz & 0xFF;
                 ls.z = st[sub - 1].cz >> 8;
             }
-            sink.started = ls.z == 0; // otherwise the first symbols finish the predecessor's data unit
             HostFetch f{dst.data() + static_cast<size_t>(seg.subseq_offset) * subseq_bytes, seg.subseq_count * W};
             BitWindow<HostFetch> bw;
             bw.seek(ls.p, f);
-            decode_subsequence(ls, bw, f, (rel + 1) * bits, tabs, sp, sink);
+            decode_units(ls, bw, f, tabs, sp, sink, 2 * (bits + 64 * 32));
+            sink.unit_boundary(); // nothing is left open when the lane stops (it stops in a DC slot), but say so
         }
     }
     {

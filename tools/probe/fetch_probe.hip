@@ -60,7 +60,7 @@ __global__ __launch_bounds__(256) void rd_u16_units(const uint16_t* __restrict__
     // group g of 8 lanes reads entries 0..7 of sector g
     for (size_t g = (blockIdx.x * 256ull + threadIdx.x) >> 3; g < n_sectors; g += gridDim.x * 32ull)
         acc ^= src[g * 16 + (threadIdx.x & 7u)];
-    if (acc == 0x12345678u) *sink = acc;
+    if (acc == 0x1234u) *sink = acc; // a 16-bit value: a 32-bit constant here lets the compiler drop the loop
 }
 
 __global__ __launch_bounds__(256) void rd_rec8(const uint2* __restrict__ src, size_t n8, uint32_t* sink)

@@ -14,7 +14,7 @@ for (w, h), data in inputs:
         pinned = torch.empty(len(data), dtype=torch.uint8).pin_memory(); pinned.numpy()[:] = memoryview(data)
         info = dec.parse_header(pinned.data_ptr(), pinned.numel()); n = dec.get_buffer_size()
         tmp = torch.empty(n + 256, dtype=torch.uint8, device='cuda'); base = (tmp.data_ptr() + 255) // 256 * 256
-        planes = [torch.empty((info.sizes_y[c], info.sizes_x[c]), dtype=torch.uint8, device='cuda') for c in range(3)]
+        planes = [torch.empty((info.sizes_y[c], info.sizes_x[c]), dtype=torch.uint8, device='cuda') for c in range(info.num_components)]
         ptrs = [p.data_ptr() for p in planes]; pit = [p.stride(0) for p in planes]
         st = torch.cuda.Stream()
         lat = []
