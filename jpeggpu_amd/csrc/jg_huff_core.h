@@ -372,31 +372,46 @@ JG_HD inline int extend_bits(uint32_t bits, int s)
     return bits > (mask >> 1) ? static_cast<int>(bits) : static_cast<int>(bits - mask);
 }
 
+#if defined(__HIP_DEVICE_COMPILE__)
+#define JG_WAVE_ANY(x) (__builtin_amdgcn_ballot_w64(x) != 0ull)
+#else
+#define JG_WAVE_ANY(x) (x) // a host emulation runs one lane at a time
+#endif
+
 /// The symbol loop of the WRITE PASS: decode from `st` and hand every coefficient to `sink`, for the data units the
 /// lane OWNS: those whose DC symbol its subsequence commits. It runs past the end of the subsequence to finish the last
 /// of them and stops in front of the first unit of the next lane -- which the caller knows as a unit INDEX (the
 /// coefficient counts of the synchronisation passes place every lane's first unit: `sink.full()`), so no bit position
 /// is tracked here at all. Same symbols, same rules as decode_subsequence (reference decode_huffman.cu:302-394,
-/// 627-682) -- arranged for a wave that is bound by the number of vector instructions it issues:
+/// 627-682), arranged for what bounds such a loop on gfx950: not the number of vector instructions alone but the
+/// hand-offs between the vector and the scalar unit -- every `if` on a per-lane condition is a vector compare, a
+/// scalar exec-mask update and usually a branch, ~35 cycles before the next vector instruction of the wave can go
+/// (tools/probe/chain_probe.hip; DESIGN.md section 3 has the measurements behind this arrangement).
 ///
-///   * every iteration has an AC SECTION: a lane that is inside a data unit decodes one AC symbol -- table look-up,
-///     magnitude, one 16-bit entry into the sink's ring. Nothing else: no DC arithmetic, no table selection, no unit
-///     bookkeeping, no selects between "DC lane" and "AC lane" values;
-///   * every kWriteDcPeriod-th iteration starts with a DC SLOT: the lanes that stand at the start of a data unit
-///     close the record of the unit they finished, test the stop rule, load the next unit's cursor entry (tables,
-///     component), decode the DC symbol and add it to the component's predictor. A lane that reaches a unit's end
-///     between two slots WAITS for the next one.
+///   * ONE uniform loop: lanes never leave it alone. A lane that is done, a lane that waits, a lane whose look-up
+///     needs the slow path all run the same instructions on a NULL table entry (length, category and advance 0),
+///     which changes nothing; the wave leaves when every lane has stopped.
+///   * The AC step of every iteration has no per-lane branch at all: the window refill is three selects, the reload
+///     of the prefetched word an exec-masked load, the entry is nulled by one select on the sign of an OR of the
+///     three reasons a lane may not step (outside a unit, window not yet refilled, entry without a length).
+///   * Everything rare -- second-level look-up / long code, escape entry of a coefficient of category >= 10, the
+///     window leaving its row -- sits behind ONE wave-uniform test per iteration.
+///   * Every kWriteDcPeriod-th iteration has a DC SLOT: the lanes that stand at the start of a data unit close the
+///     record of the unit they finished, test the stop rule, load the next unit's cursor entry (tables, component),
+///     decode the DC symbol and add it to the component's predictor. A lane that reaches a unit's end between two
+///     slots WAITS for the next one (1.5 iterations per unit of ~15 symbols): in a wave of 64 lanes some lane is at a
+///     unit boundary in nearly every iteration, so a loop that handles boundaries where they fall pays that work
+///     -- about as many instructions as the AC work -- every iteration.
 ///
-/// In a wave of 64 lanes some lane is at a unit boundary in nearly every iteration, so the one-symbol-per-iteration
-/// loop above pays the DC and boundary work -- about as many instructions as the AC work -- EVERY iteration, as selects.
-/// Here it is paid every fourth, and a lane loses 1.5 iterations per unit (of ~10 symbols) waiting (DESIGN.md section
-/// 3). The results do not depend on the period (a host emulation runs one lane at a time). `max_iters` bounds the loop
-/// whatever the stream holds (a valid one needs fewer than one iteration per bit).
-template <class Fetch, class Sink>
+/// `Words` is the source of the bitstream words (device: the tiled rows of the destuffed buffer; host twin: the
+/// segment's bytes): load(off), kStep from a word to the next of its row, cross(off, end) when the row ends, and
+/// seek(word, off, end). The word after the window's two is always in flight one refill ahead (`nxt`). The results
+/// do not depend on the slot period (a host emulation runs one lane at a time). `max_iters` bounds the loop whatever
+/// the stream holds (a valid one needs fewer than one iteration per bit).
+template <class Words, class Sink>
 JG_HD inline void decode_units(
     const LaneState& st,
-    BitWindow<Fetch>& bw,
-    const Fetch& fetch,
+    const Words& words,
     const uint8_t* tabs,
     const ScanParams& sp,
     Sink& sink,
@@ -411,6 +426,7 @@ JG_HD inline void decode_units(
 #define JG_CUR_SELF cur[2]
 #define JG_CUR_NEXT cur[3]
     typedef u32x4 Cursor;
+#define JG_FUNNEL(hi, lo, sh) __builtin_amdgcn_alignbit(hi, lo, static_cast<uint32_t>(sh))
 #else
 #define JG_LOAD_CURSOR(off) (*reinterpret_cast<const CursorEntry*>(tabs + (off)))
 #define JG_CUR_TABS cur.tabs
@@ -418,68 +434,124 @@ JG_HD inline void decode_units(
 #define JG_CUR_SELF cur.self
 #define JG_CUR_NEXT cur.next
     typedef CursorEntry Cursor;
+#define JG_FUNNEL(hi, lo, sh) static_cast<uint32_t>(((static_cast<uint64_t>(hi) << 32) | (lo)) >> ((sh) & 31))
 #endif
-    // zig-zag index minus one of the lane's position inside its unit; kAtUnitStart: the next symbol is a DC symbol;
-    // kStopped: the lane is done. Everything >= 63 is "not inside a unit": one compare per section.
+    // zig-zag index minus one of the lane's position inside its unit, 0..62; 63..127: the unit is complete and the
+    // next symbol is a DC symbol (kAtUnitStart for a lane that starts there); kStopped: the lane is done.
     constexpr int kAtUnitStart = 64, kStopped = 128;
     int zm;
-    uint32_t actab, unit_entry;                // AC table of the unit the lane is in; cursor entry of the next unit to start
+    uint32_t actab, unit_entry; // AC table of the unit the lane is in; cursor entry of the next unit to start
     {
         const Cursor cur = JG_LOAD_CURSOR(sp.cursor_off + 16u * static_cast<uint32_t>(st.c));
         zm               = st.z ? st.z - 1 : kAtUnitStart;
         actab            = JG_CUR_TABS >> 16;
         unit_entry       = st.z ? JG_CUR_NEXT : JG_CUR_SELF;
     }
-    uint32_t dc01 = st.dc01, dc23 = st.dc23;  // predictors: running sums of the DC differences, per component
+    uint32_t dc01 = st.dc01, dc23 = st.dc23; // predictors: running sums of the DC differences, per component
+    // The window: 64 bits in `hi`, `lo`, looked at `sh` bits from the right (BitWindow above); `nxt` is the word behind
+    // them, loaded one refill ahead; `off` is the position of the word behind `nxt`. The pair starts at the word that
+    // holds bit p - 1.
+    uint32_t off, end, hi, lo, nxt;
+    int sh;
+    {
+        const int q = st.p - 1;
+        sh          = 31 - (q & 31);
+        words.seek(q >> 5, off, end);
+        hi = words.load(off);
+        off += Words::kStep;
+        if (off == end) words.cross(off, end);
+        lo = words.load(off);
+        off += Words::kStep;
+        if (off == end) words.cross(off, end);
+        nxt = words.load(off);
+        off += Words::kStep;
+        if (off == end) words.cross(off, end);
+    }
+    int flush_in = Sink::kFlushPeriod; // iterations to the sink's next flush point
     for (int it = 0; it < max_iters; ++it) {
-        if ((it & (kWriteDcPeriod - 1)) == 0) { // the same iterations for every lane of a wave
-            if (zm >= 63) {
-                sink.unit_boundary();           // the unit the lane finished since the last slot, if any, is complete
+        if (iters_out) *iters_out = it + 1;
+        // refill: at most 32 bits are consumed between two looks, one step is enough
+        const bool need = sh < 0;
+        hi              = need ? lo : hi;
+        lo              = need ? nxt : lo;
+        sh &= 31; // + 32 where it was negative (it is never below -32)
+        if (need) { // exec-masked, no branch: the word is wanted one refill from now
+            nxt = words.load(off);
+            off += Words::kStep;
+        }
+        // negative where the position has just left its row (positions are below 2^31): fixed in the rare block
+        const int crossed = static_cast<int>((off ^ end) - 1u);
+        if ((it & (kWriteDcPeriod - 1)) == 0) { // DC slot: the same iterations for every lane of a wave
+            if (static_cast<uint32_t>(zm - 63) < static_cast<uint32_t>(kStopped - 63)) {
+                sink.unit_boundary(); // the unit the lane finished since the last slot, if any, is complete
                 if (sink.full()) {
-                    zm = kStopped;              // the next unit is the next lane's, or lies past the segment
+                    zm = kStopped; // the next unit is the next lane's, or lies past the segment
                 } else {
                     const Cursor cur    = JG_LOAD_CURSOR(unit_entry);
-                    const uint32_t peek = bw.peek(fetch);
+                    const uint32_t peek = JG_FUNNEL(hi, lo, sh);
                     const TabPtr tab    = JG_TAB_AT(tabs, JG_CUR_TABS & 0xFFFFu);
                     uint32_t e          = lut16_entry<kLutBitsDc>(tab, peek);
                     if ((e & 31u) == 0) e = huff_second_level(tab, e, peek, true);
                     const int total = e & 31;
-                    bw.skip(total);
+                    sh -= total; // may go negative: the lane then sits the AC step of this iteration out
                     const int s      = (e >> 5) & 15;
                     const int v      = extend_bits(bits_field(peek, total, s), s);
-                    const int sh     = JG_CUR_META & 63;
-                    const uint64_t d = static_cast<uint64_t>(static_cast<uint32_t>(v) & 0xFFFFu) << sh;
+                    const int csh    = JG_CUR_META & 63;
+                    const uint64_t d = static_cast<uint64_t>(static_cast<uint32_t>(v) & 0xFFFFu) << csh;
                     dc01             = pk_add_u16(dc01, static_cast<uint32_t>(d));
                     dc23             = pk_add_u16(dc23, static_cast<uint32_t>(d >> 32));
                     // the component's running sum is the absolute DC value, 16-bit wrap like the reference's int16
                     // prefix sum (decode_dc.cu:129-155)
-                    sink.dc(static_cast<int>(((static_cast<uint64_t>(dc23) << 32) | dc01) >> sh));
+                    sink.dc(static_cast<int>(((static_cast<uint64_t>(dc23) << 32) | dc01) >> csh));
                     actab      = JG_CUR_TABS >> 16;
                     unit_entry = JG_CUR_NEXT;
                     zm         = 0;
                 }
             }
-            if (zm == kStopped) break;
+            if (!JG_WAVE_ANY(zm != kStopped)) break;
         }
-        if (zm < 63) {
-            const uint32_t peek = bw.peek(fetch);
-            const TabPtr tab    = JG_TAB_AT(tabs, actab);
-            uint32_t e          = lut16_entry<kLutBitsAc>(tab, peek);
-            if ((e & 31u) == 0) e = huff_second_level(tab, e, peek, false);
-            const int total = e & 31;
-            bw.skip(total);
-            const int s = (e >> 5) & 15;
-            zm += static_cast<int>(e >> 9); // index of the symbol's coefficient; 63 or more: the unit is complete
-            sink.ac(s, zm, extend_bits(bits_field(peek, total, s), s));
+        // AC step, every lane
+        const uint32_t peek = JG_FUNNEL(hi, lo, sh);
+        const TabPtr tab    = JG_TAB_AT(tabs, actab);
+        const uint32_t e0   = lut16_entry<kLutBitsAc>(tab, peek);
+        const int len0      = e0 & 31;
+        // no step for a lane outside a unit (zm >= 63), with a window the DC symbol just emptied (sh < 0), or with an
+        // entry without a length (the rare block below takes that step): the sign of one OR says so
+        const int idle   = (62 - zm) | sh | (len0 - 1);
+        const uint32_t e = idle < 0 ? 0u : e0;
+        const int total  = e & 31;
+        sh -= total;
+        const int s = (e >> 5) & 15;
+        zm += static_cast<int>(e >> 9); // index of the symbol's coefficient; 63 or more: the unit is complete
+        const int v = extend_bits(bits_field(peek, total, s), s);
+        sink.ac(s, zm, v);
+        // one test for everything rare, as the sign of one OR (a single compare feeds the wave-wide branch)
+        if (JG_WAVE_ANY(((len0 - 1) | (kEscapeFromCategory - 1 - s) | crossed) < 0)) {
+            if (crossed < 0) words.cross(off, end);
+            if (len0 == 0 && ((62 - zm) | sh) >= 0) { // zm and sh are what they were: the null entry changed nothing
+                const uint32_t e2 = huff_second_level(tab, e0, peek, false);
+                const int total2  = e2 & 31;
+                sh -= total2;
+                const int s2 = (e2 >> 5) & 15;
+                zm += static_cast<int>(e2 >> 9);
+                const int v2 = extend_bits(bits_field(peek, total2, s2), s2);
+                sink.ac(s2, zm, v2);
+                if (s2 >= kEscapeFromCategory) sink.escape(v2);
+            } else if (s >= kEscapeFromCategory) {
+                sink.escape(v);
+            }
         }
-        sink.tick();
-        if (iters_out) *iters_out = it + 1;
+        if (--flush_in == 0) { // the same iteration for every lane of the wave
+            flush_in = Sink::kFlushPeriod;
+            sink.flush_point();
+        }
     }
 #undef JG_LOAD_CURSOR
 #undef JG_CUR_TABS
 #undef JG_CUR_META
 #undef JG_CUR_SELF
 #undef JG_CUR_NEXT
+#undef JG_FUNNEL
 }
 
 } // namespace jg

@@ -384,6 +384,29 @@ struct GlobalFetch {
     __device__ __forceinline__ uint32_t cook(uint32_t v, const Pos&) const { return v; }
 };
 
+/// The rows of the tiled destuffed buffer as the write pass walks them (jg_huff_core.h, decode_units): positions are
+/// byte offsets into the buffer, the next word of a row is one slot further, and behind the row's last slot (W + 2) the
+/// stream goes on at slot 3 of the next row (GlobalFetch<W, true> above: the same addresses).
+template <int W>
+struct RowWords {
+    typedef GlobalFetch<W, true> G;
+    static constexpr uint32_t kStep = G::kSlotBytes;
+    G g;
+    __device__ __forceinline__ void seek(int word, uint32_t& off, uint32_t& end) const
+    {
+        const typename G::Pos q = g.start(word);
+        off                     = q.off;
+        end                     = q.end;
+    }
+    __device__ __forceinline__ uint32_t load(uint32_t off) const { return g.load(typename G::Pos{off, 0u}); }
+    __device__ __forceinline__ void cross(uint32_t& off, uint32_t& end) const
+    {
+        const uint32_t step = (off & (G::kSlotBytes - 1u)) == G::kSlotBytes - 4u ? G::kRowBytes - (G::kSlotBytes - 4u) : 4u; // last row of a tile: on to the next tile
+        off                 = off - W * G::kSlotBytes + step;
+        end += step;
+    }
+};
+
 #if defined(JG_PROBE)
 // Probe builds only (python jpeggpu_amd/build.py out.so -DJG_PROBE): 100 MHz time stamps of the passes of
 // huff_sync_intra, 64 per workgroup; read back with jpeggpu_probe_read (tools/probe/sync_stamps.py).
@@ -758,7 +781,7 @@ constexpr int kRingWords    = 16;                         // 32-bit words of a l
 constexpr int kRingStride   = (kRingWords + 1) * 4;       // bytes from one lane's ring to the next: 17 words, an odd number of banks
 constexpr int kStageEntries = 2 * kRingWords;             // entries the ring holds (a power of two)
 constexpr int kFlushEntries = kSymSectorEntries;          // entries per flush: 16 = one 32-byte sector
-constexpr int kFlushPeriod  = 6;                          // iterations between two flush points
+constexpr int kWriteFlushPeriod = 6;                      // iterations between two flush points
 
 /// Sink of the write pass: a compact symbol stream instead of a dense coefficient buffer (jg_defs.h). Every lane
 /// appends 16-bit entries to its own region, contiguous per data unit, and records {first entry, count} per
@@ -779,6 +802,7 @@ constexpr int kFlushPeriod  = 6;                          // iterations between 
 /// select, no test; the first DC symbol rewinds the lane's count). The region cannot overflow on a valid stream
 /// (jg_defs.h, sym_region_entries); on a corrupt one the flush drops what lies beyond it.
 struct StreamSink {
+    static constexpr int kFlushPeriod = kWriteFlushPeriod;
     JG_GLOBAL uint16_t* sym;
     JG_GLOBAL uint2_t* du_tab;
     uint32_t ring;      // LDS byte address of the lane's ring: entry n at ring + (n % 32) * 2
@@ -789,7 +813,6 @@ struct StreamSink {
     uint32_t du_off;    // first entry of the unit being decoded, minus kUnitHasEscape once it has taken an escape entry
     int du;       // next data unit this lane starts
     int quota;    // first data unit past the segment
-    int countdown; // iterations to the next flush point (the same in every lane)
     // Data-unit records {first entry, count} wait here until FOUR of them fill a 32-byte sector of the table: a
     // lane's units are consecutive in the table and contiguous in its region, so the table index and the offset of
     // the first waiting one, plus packed entry counts (up to eight, one byte each), describe them. Stored one by
@@ -800,7 +823,7 @@ struct StreamSink {
     int rec_du;         // its index in the data-unit table
     uint32_t pend_lo, pend_hi; // counts (| kUnitHasEscape) of the waiting units: the TOP pend_n bytes of hi:lo, oldest lowest
     int pend_n;
-    bool started; // false until the lane's first DC symbol: what it decodes before finishes the predecessor's data unit
+    uint32_t started; // 0 until the lane's first DC symbol: what it decodes before finishes the predecessor's data unit
     __device__ __forceinline__ bool full() const { return du >= quota; }
     /// 16-bit store into the lane's ring, slot n % 32.
     __device__ __forceinline__ void put(uint32_t n, uint32_t entry)
@@ -826,24 +849,25 @@ struct StreamSink {
     __device__ __forceinline__ void dc(int value)
     {
         emitted = started ? emitted : 0u; // what was stored before belongs to the predecessor's lane
-        started = true;
+        started = 1u;
         du_off  = emitted;
         ++du;
         put(emitted, static_cast<uint32_t>(value));
         ++emitted;
     }
     /// An AC symbol of category `category` whose coefficient `value` sits at zig-zag index `zpos`; category 0 (a run
-    /// of zeros, an end of block) keeps nothing.
+    /// of zeros, an end of block, the null entry of a lane that does not step) keeps nothing.
     __device__ __forceinline__ void ac(int category, int zpos, int value)
     {
         put(emitted, sym_entry_ac(zpos, value));
         emitted += category != 0 ? 1u : 0u;
-        // a coefficient of category 10 or more (no photograph has one) takes a second entry
-        if (__builtin_expect(category >= kEscapeFromCategory, 0)) {
-            put(emitted, sym_entry_escape(value));
-            ++emitted;
-            du_off -= ((emitted - du_off) & kUnitHasEscape) ? 0u : kUnitHasEscape; // once per unit (a unit has at most 127 entries)
-        }
+    }
+    /// A coefficient of category 10 or more (no photograph has one) takes a second entry behind the one ac() stored.
+    __device__ __forceinline__ void escape(int value)
+    {
+        put(emitted, sym_entry_escape(value));
+        ++emitted;
+        du_off -= ((emitted - du_off) & kUnitHasEscape) ? 0u : kUnitHasEscape; // once per unit (a unit has at most 127 entries)
     }
     /// Store the first `n` waiting records (1..4).
     __device__ __forceinline__ void store_units(int n)
@@ -899,13 +923,11 @@ struct StreamSink {
         }
         flushed += kFlushEntries;
     }
-    __device__ __forceinline__ void tick()
+    /// Every kFlushPeriod-th iteration, the same one for every lane of the wave.
+    __device__ __forceinline__ void flush_point()
     {
-        if (--countdown == 0) { // the same iteration for every lane of the wave
-            countdown = kFlushPeriod;
-            if (started && emitted - flushed >= static_cast<uint32_t>(kFlushEntries)) flush_sector();
-            flush_units();
-        }
+        if (started && emitted - flushed >= static_cast<uint32_t>(kFlushEntries)) flush_sector();
+        flush_units();
     }
     /// After the loop: everything that is left, rounded up to whole sectors (the entries behind the
     /// last valid one are never read: the data-unit table bounds every gather).
@@ -1050,7 +1072,6 @@ __global__ __launch_bounds__(T) void huff_write(JS js)
     sink.emitted        = 0;
     sink.cur_end        = J.sym_region;
     sink.du_off         = 0;
-    sink.countdown      = kFlushPeriod;
     sink.rec_off        = 0;
     sink.rec_du         = sink.du; // the first unit this lane starts
     sink.pend_lo        = 0;
@@ -1066,20 +1087,19 @@ __global__ __launch_bounds__(T) void huff_write(JS js)
         st.c         = cz & 0xFF;
         st.z         = cz >> 8;
     }
-    sink.started = false; // until the lane's first DC symbol
-    GlobalFetch<W, true> fetch{reinterpret_cast<JG_GLOBAL const uint32_t*>(J.destuffed), 0, 0};
-    fetch.set_row(sub, rel);
-    BitWindow<GlobalFetch<W, true>> bw{};
-    bw.seek(st.p, fetch);
+    sink.started = 0u; // until the lane's first DC symbol
+    RowWords<W> words{GlobalFetch<W, true>{reinterpret_cast<JG_GLOBAL const uint32_t*>(J.destuffed), 0, 0}};
+    words.g.set_row(sub, rel);
     // a valid stream takes less than one iteration per bit of the subsequence and of the unit the lane runs on into
+    constexpr int kMaxIters = 2 * (W * 32 + 64 * 32);
 #if defined(JG_PROBE)
     int iters = 0;
-    decode_units(st, bw, fetch, s_tab, sp, sink, 2 * (W * 32 + 64 * 32), &iters);
+    decode_units(st, words, s_tab, sp, sink, kMaxIters, &iters);
     atomicAdd(&g_probe_write[0], static_cast<unsigned long long>(iters));
     atomicMax(&g_probe_write[2], static_cast<unsigned long long>(iters));
     atomicAdd(&g_probe_write[3], 1ull);
 #else
-    decode_units(st, bw, fetch, s_tab, sp, sink, 2 * (W * 32 + 64 * 32));
+    decode_units(st, words, s_tab, sp, sink, kMaxIters);
 #endif
     sink.finish();
 }

@@ -31,6 +31,19 @@ struct HostFetch {
     uint32_t cook(uint32_t v, const Pos&) const { return v; }
 };
 
+/// Host twin of the write pass's word source (RowWords in jg_kernels.hip): the segment's destuffed bytes, linear.
+struct HostWords {
+    HostFetch f;
+    static constexpr uint32_t kStep = 1;
+    void seek(int word, uint32_t& off, uint32_t& end) const
+    {
+        off = static_cast<uint32_t>(word); // -1 for the word in front of the segment: loaded, never looked at
+        end = 0xFFFFFFFEu;                 // rows do not end here
+    }
+    uint32_t load(uint32_t off) const { return f.load(static_cast<int>(off)); }
+    void cross(uint32_t&, uint32_t&) const {}
+};
+
 /// Host twin of the write pass's sink (StreamSink in jg_kernels.hip): symbol stream (jg_defs.h: 16-bit entries,
 /// escapes behind coefficients that do not fit 10 bits) + data-unit table, fed by decode_units (jg_huff_core.h).
 struct HostSink {
@@ -58,14 +71,17 @@ struct HostSink {
     }
     void ac(int category, int zpos, int value)
     {
-        if (!started || category == 0) return; // the tail of the predecessor's unit; runs of zeros and ends of block
+        if (!started || category == 0) return; // the tail of the predecessor's unit; runs of zeros, ends of block, null entries
         if (cur < cur_end) sym[cur++] = static_cast<uint16_t>(sym_entry_ac(zpos, value));
-        if (category >= kEscapeFromCategory) {
-            if (cur < cur_end) sym[cur++] = static_cast<uint16_t>(sym_entry_escape(value));
-            unit_esc = kUnitHasEscape;
-        }
     }
-    void tick() {}
+    void escape(int value)
+    {
+        if (!started) return;
+        if (cur < cur_end) sym[cur++] = static_cast<uint16_t>(sym_entry_escape(value));
+        unit_esc = kUnitHasEscape;
+    }
+    static constexpr int kFlushPeriod = 6;
+    void flush_point() {}
 };
 
 struct St {
@@ -367,10 +383,8 @@ int emu_decode_scan(
                 ls.c = st[sub - 1].cz & 0xFF;
                 ls.z = st[sub - 1].cz >> 8;
             }
-            HostFetch f{dst.data() + static_cast<size_t>(seg.subseq_offset) * subseq_bytes, seg.subseq_count * W};
-            BitWindow<HostFetch> bw;
-            bw.seek(ls.p, f);
-            decode_units(ls, bw, f, tabs, sp, sink, 2 * (bits + 64 * 32));
+            const HostWords words{HostFetch{dst.data() + static_cast<size_t>(seg.subseq_offset) * subseq_bytes, seg.subseq_count * W}};
+            decode_units(ls, words, tabs, sp, sink, 2 * (bits + 64 * 32));
             sink.unit_boundary(); // nothing is left open when the lane stops (it stops in a DC slot), but say so
         }
     }
