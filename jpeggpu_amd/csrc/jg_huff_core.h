@@ -403,15 +403,16 @@ JG_HD inline int extend_bits(uint32_t bits, int s)
 ///     unit boundary in nearly every iteration, so a loop that handles boundaries where they fall pays that work
 ///     -- about as many instructions as the AC work -- every iteration.
 ///
-/// `Words` is the source of the bitstream words (device: the tiled rows of the destuffed buffer; host twin: the
-/// segment's bytes): load(off), kStep from a word to the next of its row, cross(off, end) when the row ends, and
-/// seek(word, off, end). The word after the window's two is always in flight one refill ahead (`nxt`). The results
-/// do not depend on the slot period (a host emulation runs one lane at a time). `max_iters` bounds the loop whatever
-/// the stream holds (a valid one needs fewer than one iteration per bit).
-template <class Words, class Sink>
+/// `Window` is the lane's view of the bitstream (device: RowWindow over the tiled rows of the destuffed buffer,
+/// jg_kernels.hip; host twin: tests/emu): seek(p), top() -- the refill, once per iteration --, look() -- the 32 bits
+/// at the position, valid while left() >= 0 --, skip(n), left() -- negative when the window wants a refill --,
+/// crossed() -- negative where the position has just left its row --, cross() and done() behind the loop. The results do not depend on the
+/// slot period (a host emulation runs one lane at a time). `max_iters` bounds the loop whatever the stream holds (a
+/// valid one needs fewer than one iteration per bit).
+template <class Window, class Sink>
 JG_HD inline void decode_units(
     const LaneState& st,
-    const Words& words,
+    Window& w,
     const uint8_t* tabs,
     const ScanParams& sp,
     Sink& sink,
@@ -426,7 +427,6 @@ JG_HD inline void decode_units(
 #define JG_CUR_SELF cur[2]
 #define JG_CUR_NEXT cur[3]
     typedef u32x4 Cursor;
-#define JG_FUNNEL(hi, lo, sh) __builtin_amdgcn_alignbit(hi, lo, static_cast<uint32_t>(sh))
 #else
 #define JG_LOAD_CURSOR(off) (*reinterpret_cast<const CursorEntry*>(tabs + (off)))
 #define JG_CUR_TABS cur.tabs
@@ -434,7 +434,6 @@ JG_HD inline void decode_units(
 #define JG_CUR_SELF cur.self
 #define JG_CUR_NEXT cur.next
     typedef CursorEntry Cursor;
-#define JG_FUNNEL(hi, lo, sh) static_cast<uint32_t>(((static_cast<uint64_t>(hi) << 32) | (lo)) >> ((sh) & 31))
 #endif
     // zig-zag index minus one of the lane's position inside its unit, 0..62; 63..127: the unit is complete and the
     // next symbol is a DC symbol (kAtUnitStart for a lane that starts there); kStopped: the lane is done.
@@ -448,52 +447,24 @@ JG_HD inline void decode_units(
         unit_entry       = st.z ? JG_CUR_NEXT : JG_CUR_SELF;
     }
     uint32_t dc01 = st.dc01, dc23 = st.dc23; // predictors: running sums of the DC differences, per component
-    // The window: 64 bits in `hi`, `lo`, looked at `sh` bits from the right (BitWindow above); `nxt` is the word behind
-    // them, loaded one refill ahead; `off` is the position of the word behind `nxt`. The pair starts at the word that
-    // holds bit p - 1.
-    uint32_t off, end, hi, lo, nxt;
-    int sh;
-    {
-        const int q = st.p - 1;
-        sh          = 31 - (q & 31);
-        words.seek(q >> 5, off, end);
-        hi = words.load(off);
-        off += Words::kStep;
-        if (off == end) words.cross(off, end);
-        lo = words.load(off);
-        off += Words::kStep;
-        if (off == end) words.cross(off, end);
-        nxt = words.load(off);
-        off += Words::kStep;
-        if (off == end) words.cross(off, end);
-    }
+    w.seek(st.p);
     int flush_in = Sink::kFlushPeriod; // iterations to the sink's next flush point
     for (int it = 0; it < max_iters; ++it) {
         if (iters_out) *iters_out = it + 1;
-        // refill: at most 32 bits are consumed between two looks, one step is enough
-        const bool need = sh < 0;
-        hi              = need ? lo : hi;
-        lo              = need ? nxt : lo;
-        sh &= 31; // + 32 where it was negative (it is never below -32)
-        if (need) { // exec-masked, no branch: the word is wanted one refill from now
-            nxt = words.load(off);
-            off += Words::kStep;
-        }
-        // negative where the position has just left its row (positions are below 2^31): fixed in the rare block
-        const int crossed = static_cast<int>((off ^ end) - 1u);
+        w.top(); // refill where the window ran out (at most 32 bits are consumed between two looks)
         if ((it & (kWriteDcPeriod - 1)) == 0) { // DC slot: the same iterations for every lane of a wave
-            if (static_cast<uint32_t>(zm - 63) < static_cast<uint32_t>(kStopped - 63)) {
+            if (static_cast<uint32_t>(zm - 63) < static_cast<uint32_t>(kStopped - 63) && w.left() >= 0) {
                 sink.unit_boundary(); // the unit the lane finished since the last slot, if any, is complete
                 if (sink.full()) {
                     zm = kStopped; // the next unit is the next lane's, or lies past the segment
                 } else {
                     const Cursor cur    = JG_LOAD_CURSOR(unit_entry);
-                    const uint32_t peek = JG_FUNNEL(hi, lo, sh);
+                    const uint32_t peek = w.look();
                     const TabPtr tab    = JG_TAB_AT(tabs, JG_CUR_TABS & 0xFFFFu);
                     uint32_t e          = lut16_entry<kLutBitsDc>(tab, peek);
                     if ((e & 31u) == 0) e = huff_second_level(tab, e, peek, true);
                     const int total = e & 31;
-                    sh -= total; // may go negative: the lane then sits the AC step of this iteration out
+                    w.skip(total); // the window may run out: the lane then sits the AC step of this iteration out
                     const int s      = (e >> 5) & 15;
                     const int v      = extend_bits(bits_field(peek, total, s), s);
                     const int csh    = JG_CUR_META & 63;
@@ -511,27 +482,28 @@ JG_HD inline void decode_units(
             if (!JG_WAVE_ANY(zm != kStopped)) break;
         }
         // AC step, every lane
-        const uint32_t peek = JG_FUNNEL(hi, lo, sh);
+        const uint32_t peek = w.look();
         const TabPtr tab    = JG_TAB_AT(tabs, actab);
         const uint32_t e0   = lut16_entry<kLutBitsAc>(tab, peek);
         const int len0      = e0 & 31;
-        // no step for a lane outside a unit (zm >= 63), with a window the DC symbol just emptied (sh < 0), or with an
-        // entry without a length (the rare block below takes that step): the sign of one OR says so
-        const int idle   = (62 - zm) | sh | (len0 - 1);
+        // no step for a lane outside a unit (zm >= 63), with a window that ran out (the DC symbol just emptied it, or
+        // its refill has to wait an iteration), or with an entry without a length (the rare block below takes that
+        // step): the sign of one OR says so
+        const int idle   = (62 - zm) | w.left() | (len0 - 1);
         const uint32_t e = idle < 0 ? 0u : e0;
         const int total  = e & 31;
-        sh -= total;
+        w.skip(total);
         const int s = (e >> 5) & 15;
         zm += static_cast<int>(e >> 9); // index of the symbol's coefficient; 63 or more: the unit is complete
         const int v = extend_bits(bits_field(peek, total, s), s);
         sink.ac(s, zm, v);
         // one test for everything rare, as the sign of one OR (a single compare feeds the wave-wide branch)
-        if (JG_WAVE_ANY(((len0 - 1) | (kEscapeFromCategory - 1 - s) | crossed) < 0)) {
-            if (crossed < 0) words.cross(off, end);
-            if (len0 == 0 && ((62 - zm) | sh) >= 0) { // zm and sh are what they were: the null entry changed nothing
+        if (JG_WAVE_ANY(((len0 - 1) | (kEscapeFromCategory - 1 - s) | w.crossed()) < 0)) {
+            if (w.crossed() < 0) w.cross();
+            if (len0 == 0 && ((62 - zm) | w.left()) >= 0) { // zm and the window are what they were: the null entry changed nothing
                 const uint32_t e2 = huff_second_level(tab, e0, peek, false);
                 const int total2  = e2 & 31;
-                sh -= total2;
+                w.skip(total2);
                 const int s2 = (e2 >> 5) & 15;
                 zm += static_cast<int>(e2 >> 9);
                 const int v2 = extend_bits(bits_field(peek, total2, s2), s2);
@@ -546,12 +518,12 @@ JG_HD inline void decode_units(
             sink.flush_point();
         }
     }
+    w.done();
 #undef JG_LOAD_CURSOR
 #undef JG_CUR_TABS
 #undef JG_CUR_META
 #undef JG_CUR_SELF
 #undef JG_CUR_NEXT
-#undef JG_FUNNEL
 }
 
 } // namespace jg

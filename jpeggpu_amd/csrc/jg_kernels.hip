@@ -384,26 +384,93 @@ struct GlobalFetch {
     __device__ __forceinline__ uint32_t cook(uint32_t v, const Pos&) const { return v; }
 };
 
-/// The rows of the tiled destuffed buffer as the write pass walks them (jg_huff_core.h, decode_units): positions are
-/// byte offsets into the buffer, the next word of a row is one slot further, and behind the row's last slot (W + 2) the
-/// stream goes on at slot 3 of the next row (GlobalFetch<W, true> above: the same addresses).
+/// The write pass's view of the bitstream (jg_huff_core.h, decode_units): a 64-bit window `hi`:`lo` looked at `sh`
+/// bits from the right (BitWindow's funnel shift), `nxt` the word behind it, in flight, and `pos` the byte offset of
+/// that word in the tiled destuffed buffer (GlobalFetch<W, true>: the same rows and addresses; behind the row's last
+/// slot, W + 2, the stream goes on at slot 3 of the next row).
+///
+/// What is special is the refill. Loaded the obvious way -- `if (sh < 0) { hi = lo; lo = nxt; nxt = load(next); }` --
+/// every iteration of the loop waits for the word loaded one iteration earlier: some lane of the wave refills in
+/// nearly every iteration, the wait is the wave's, it is a wait for ALL its loads (s_waitcnt vmcnt(0): the compiler
+/// cannot tell them apart), and under this kernel's load a load takes longer than an iteration: a quarter of the
+/// kernel's time (measured with the loads compiled out). The lane that refills now, though, needs the word it asked for
+/// at its PREVIOUS refill, a handful of iterations ago. So the loads are issued from inline assembly, where the compiler
+/// does not see them, and the wait is for all but the most recent one (vmcnt(1)). That is enough because
+///   * vector memory operations of a wave complete in the order they were issued,
+///   * a lane does not refill in two consecutive iterations (`ok`: a lane that would sits one iteration out; it would
+///     need 33 bits in two symbols), and
+///   * a lane that refilled one iteration ago loads the same word into `nxt` AGAIN (`prev`): behind the load a lane
+///     needs there is therefore always a younger one -- its own --, whatever the other lanes do.
+/// Everything that touches `nxt` lives in that assembly block, with read-write operands: the compiler never copies the
+/// register while a load into it is in flight. Operations the compiler does track (the sink's stores) only make its
+/// own waits stricter. The refill is branch-free: an exec mask around three moves, two adds and the load.
 template <int W>
-struct RowWords {
+struct RowWindow {
     typedef GlobalFetch<W, true> G;
-    static constexpr uint32_t kStep = G::kSlotBytes;
     G g;
-    __device__ __forceinline__ void seek(int word, uint32_t& off, uint32_t& end) const
+    uint32_t hi, lo, nxt;
+    uint32_t pos, last; // byte offset of the word in `nxt`; offset of the row's last slot
+    int sh;
+    uint32_t ok;        // ~0 where the lane may refill in this iteration, 0 where it did in the previous one
+    __device__ __forceinline__ void seek(int p)
     {
-        const typename G::Pos q = g.start(word);
-        off                     = q.off;
-        end                     = q.end;
+        const int q             = p - 1; // the pair starts at the word that holds bit p - 1: sh stays in 0..31
+        sh                      = 31 - (q & 31);
+        typename G::Pos at      = g.start(q >> 5); // arithmetic shift: -1 for q == -1
+        hi                      = g.load(at);
+        g.advance(at);
+        lo = g.load(at);
+        g.advance(at);
+        nxt  = g.load(at);
+        pos  = at.off;
+        last = at.end - G::kSlotBytes;
+        ok   = ~0u;
+        // the three words must have ARRIVED before the loop: its own waits count loads, and these are not among them
+        asm volatile("v_mov_b32 %0, %0\n\tv_mov_b32 %1, %1\n\tv_mov_b32 %2, %2" : "+v"(hi), "+v"(lo), "+v"(nxt));
     }
-    __device__ __forceinline__ uint32_t load(uint32_t off) const { return g.load(typename G::Pos{off, 0u}); }
-    __device__ __forceinline__ void cross(uint32_t& off, uint32_t& end) const
+    __device__ __forceinline__ void top()
     {
-        const uint32_t step = (off & (G::kSlotBytes - 1u)) == G::kSlotBytes - 4u ? G::kRowBytes - (G::kSlotBytes - 4u) : 4u; // last row of a tile: on to the next tile
-        off                 = off - W * G::kSlotBytes + step;
-        end += step;
+        const uint32_t t              = static_cast<uint32_t>(sh) & ok;
+        const unsigned long long need = __builtin_amdgcn_ballot_w64(static_cast<int>(t) < 0);
+        const unsigned long long both = __builtin_amdgcn_ballot_w64(static_cast<int>(t | ~ok) < 0); // + the lanes that refilled one iteration ago
+        unsigned long long save;
+        ok = ~0u;
+        asm volatile(
+            "s_mov_b64 %[save], exec\n\t"
+            "s_and_b64 exec, %[save], %[need]\n\t"
+#if defined(JG_EXP_VMCNT0)
+            "s_waitcnt vmcnt(0)\n\t"
+#else
+            "s_waitcnt vmcnt(1)\n\t"
+#endif
+            "v_mov_b32 %[hi], %[lo]\n\t"
+            "v_mov_b32 %[lo], %[nxt]\n\t"
+            "v_add_u32 %[pos], %[step], %[pos]\n\t"
+            "v_add_u32 %[sh], 32, %[sh]\n\t"
+            "v_mov_b32 %[ok], 0\n\t"
+            "s_and_b64 exec, %[save], %[both]\n\t"
+            "global_load_dword %[nxt], %[pos], %[base]\n\t"
+            "s_mov_b64 exec, %[save]"
+            : [hi] "+v"(hi), [lo] "+v"(lo), [nxt] "+v"(nxt), [pos] "+v"(pos), [sh] "+v"(sh), [ok] "+v"(ok), [save] "=&s"(save)
+            : [need] "s"(need), [both] "s"(both), [step] "s"(G::kSlotBytes), [base] "s"(g.scan32)
+            : "memory", "scc");
+    }
+    /// Behind the loop: the last loads into `nxt` may still be in flight, and the compiler, which does not know of them,
+    /// is free to give the register to something else from here on.
+    __device__ __forceinline__ void done() { asm volatile("s_waitcnt vmcnt(0)" : "+v"(nxt) : : "memory"); }
+    __device__ __forceinline__ uint32_t look() const { return __builtin_amdgcn_alignbit(hi, lo, static_cast<uint32_t>(sh)); }
+    __device__ __forceinline__ void skip(int n) { sh -= n; }
+    __device__ __forceinline__ int left() const { return sh; }
+    /// Negative where `nxt` is the word of the row's last slot: the next refill must not step to the slot behind it.
+    __device__ __forceinline__ int crossed() const { return static_cast<int>((pos ^ last) - 1u); } // offsets are below 2^31
+    __device__ __forceinline__ void cross()
+    {
+        // `pos` is the row's last slot, W + 2, whose word is also slot 2 of the next row (jg_defs.h: the mirrored words):
+        // go there, the next refill then steps to slot 3, where the stream goes on (GlobalFetch::advance). A lane that
+        // loads `nxt` again after this (top(), `prev`) gets the same word from the new place.
+        const uint32_t step = (pos & (G::kSlotBytes - 1u)) == G::kSlotBytes - 4u ? G::kRowBytes - (G::kSlotBytes - 4u) : 4u; // last row of a tile: on to the next tile
+        pos                 = pos - W * G::kSlotBytes + step;
+        last += step;
     }
 };
 
@@ -1088,7 +1155,7 @@ __global__ __launch_bounds__(T) void huff_write(JS js)
         st.z         = cz >> 8;
     }
     sink.started = 0u; // until the lane's first DC symbol
-    RowWords<W> words{GlobalFetch<W, true>{reinterpret_cast<JG_GLOBAL const uint32_t*>(J.destuffed), 0, 0}};
+    RowWindow<W> words{GlobalFetch<W, true>{reinterpret_cast<JG_GLOBAL const uint32_t*>(J.destuffed), 0, 0}};
     words.g.set_row(sub, rel);
     // a valid stream takes less than one iteration per bit of the subsequence and of the unit the lane runs on into
     constexpr int kMaxIters = 2 * (W * 32 + 64 * 32);

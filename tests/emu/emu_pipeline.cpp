@@ -31,17 +31,41 @@ struct HostFetch {
     uint32_t cook(uint32_t v, const Pos&) const { return v; }
 };
 
-/// Host twin of the write pass's word source (RowWords in jg_kernels.hip): the segment's destuffed bytes, linear.
-struct HostWords {
+/// Host twin of the write pass's window (RowWindow in jg_kernels.hip): the segment's destuffed bytes, linear; the same
+/// refill rule (not in two consecutive iterations), which the results must not depend on.
+struct HostWindow {
     HostFetch f;
-    static constexpr uint32_t kStep = 1;
-    void seek(int word, uint32_t& off, uint32_t& end) const
+    uint32_t hi, lo, nxt;
+    int pos, sh;
+    bool ok;
+    void seek(int p)
     {
-        off = static_cast<uint32_t>(word); // -1 for the word in front of the segment: loaded, never looked at
-        end = 0xFFFFFFFEu;                 // rows do not end here
+        const int q = p - 1;
+        sh          = 31 - (q & 31);
+        pos         = q >> 5; // -1 for the word in front of the segment: loaded, never looked at
+        hi          = f.load(pos);
+        lo          = f.load(pos + 1);
+        nxt         = f.load(pos + 2);
+        pos += 2;
+        ok = true;
     }
-    uint32_t load(uint32_t off) const { return f.load(static_cast<int>(off)); }
-    void cross(uint32_t&, uint32_t&) const {}
+    void top()
+    {
+        const bool need = sh < 0 && ok;
+        if (need) {
+            hi  = lo;
+            lo  = nxt;
+            nxt = f.load(++pos);
+            sh += 32;
+        }
+        ok = !need;
+    }
+    uint32_t look() const { return static_cast<uint32_t>(((static_cast<uint64_t>(hi) << 32) | lo) >> (sh & 31)); }
+    void skip(int n) { sh -= n; }
+    int left() const { return sh; }
+    int crossed() const { return 0; } // rows do not end here
+    void cross() {}
+    void done() {}
 };
 
 /// Host twin of the write pass's sink (StreamSink in jg_kernels.hip): symbol stream (jg_defs.h: 16-bit entries,
@@ -383,8 +407,8 @@ int emu_decode_scan(
                 ls.c = st[sub - 1].cz & 0xFF;
                 ls.z = st[sub - 1].cz >> 8;
             }
-            const HostWords words{HostFetch{dst.data() + static_cast<size_t>(seg.subseq_offset) * subseq_bytes, seg.subseq_count * W}};
-            decode_units(ls, words, tabs, sp, sink, 2 * (bits + 64 * 32));
+            HostWindow win{HostFetch{dst.data() + static_cast<size_t>(seg.subseq_offset) * subseq_bytes, seg.subseq_count * W}};
+            decode_units(ls, win, tabs, sp, sink, 2 * (bits + 64 * 32));
             sink.unit_boundary(); // nothing is left open when the lane stops (it stops in a DC slot), but say so
         }
     }
