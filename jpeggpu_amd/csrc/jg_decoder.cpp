@@ -74,6 +74,8 @@ struct ScanPlan {
     size_t destuffed = 0, seg_idx = 0, st_p = 0, st_n = 0, st_cz = 0, st_dc01 = 0, st_dc23 = 0;
     size_t tails_n = 0, tails_dc01 = 0, tails_dc23 = 0, pending = 0, flow_list = 0;
     size_t sym = 0, du_tab = 0;
+    size_t mh_p = 0, mh_cz = 0, mh_link = 0, mh_known = 0; // multi-hypothesis speculation (jg_defs.h), if mh > 1
+    int mh = 0, max_seg_subseq = 0;
     int num_seq = 0;
     // device-side front end (jg_front.hip): tables built on the device, scratch, the job and the status word
     size_t d_segments = 0, d_chunks = 0, d_parts = 0;
@@ -105,6 +107,7 @@ struct Decoder {
     // (jpeggpu_ext_set_subsequence_bytes, JPEGGPU_SUBSEQ_BYTES). `subseq_bytes` is the size of the last parsed image.
     int subseq_request  = 0;     // 0: choose per image; else 32 / 64 / 128 / 256
     bool batched        = false;
+    bool mh_enabled     = true;  // JPEGGPU_MULTI_HYPOTHESIS=0 at startup: plain speculation for lone decodes as well
     int subseq_bytes    = 64;
     bool parsed         = false;
     int shard_rank = 0, shard_world = 1; // jpeggpu_ext_set_segment_shard
@@ -191,6 +194,26 @@ void Decoder::make_plan()
         o += align_up(static_cast<size_t>(sp.num_seq) * 4, 256);
         sp.tails_dc23 = o;
         o += align_up(static_cast<size_t>(sp.num_seq) * 4, 256);
+        // Multi-hypothesis speculation (jg_defs.h) for an image decoded on its own: several data units per MCU,
+        // restart segments the chain walk can hold in LDS, tables from the host walk.
+        sp.mh = 0;
+        if (!batched && !sc.device_walk && sc.du_per_mcu >= 2 && sc.du_per_mcu <= kMhMaxHyp && s.restart_interval != 0 && mh_enabled) {
+            int longest = 0;
+            for (const Segment& g : sc.segments) longest = std::max(longest, g.subseq_count);
+            if (longest <= kMhMaxSegSubseq) {
+                sp.mh             = sc.du_per_mcu;
+                sp.max_seg_subseq = longest;
+                const size_t N    = S * static_cast<size_t>(sp.mh);
+                sp.mh_p           = o;
+                o += align_up(N * 4, 256);
+                sp.mh_cz = o;
+                o += align_up(N * 4, 256);
+                sp.mh_link = o;
+                o += align_up(N * 4, 256);
+                sp.mh_known = o;
+                o += align_up(S, 256);
+            }
+        }
         if (sc.device_walk) {
             const size_t E   = static_cast<size_t>(sc.expect_segments);
             sp.num_windows   = static_cast<uint32_t>(align_up(p.bytes_len, kDestuffWin) / kDestuffWin);
@@ -334,6 +357,11 @@ jpeggpu_status build_jobs(
         sp.cursor_off       = sc.cursor_off;
         sp.tab_bytes_sync   = static_cast<uint32_t>(sc.table_pack_sync.size());
         sp.cursor_off_sync  = sc.cursor_off_sync;
+        sp.mh               = pl.mh;
+        job.mh_p            = reinterpret_cast<int*>(base + pl.mh_p);
+        job.mh_cz           = reinterpret_cast<int*>(base + pl.mh_cz);
+        job.mh_link         = reinterpret_cast<uint32_t*>(base + pl.mh_link);
+        job.mh_known        = base + pl.mh_known;
         IdctParams& ip = job.ip;
         ip.num_du      = sc.num_du;
         ip.du_per_mcu  = sc.du_per_mcu;
@@ -497,6 +525,8 @@ jpeggpu_status do_decode(Decoder& d, jpeggpu_img* img, void* d_tmp, size_t tmp_s
             "scan %d: %d chunks, %d subsequences of %d bytes, %d sequences, %d segments\n",
             static_cast<int>(i), job.num_chunks, job.sp.num_subseq, d.subseq_bytes, job.num_seq, job.sp.num_segments);
         for (int stage = 0; stage < kNumStages; ++stage) {
+            // multi-hypothesis speculation in front of the sequence kernel, which then starts from its table
+            if (stage == kStageSyncIntra && job.sp.mh > 1) JG_CHECK_HIP(launch_mh(job, d.plan.scan[i].max_seg_subseq, stream));
             JG_CHECK_HIP(launch_stage(static_cast<Stage>(stage), job, stream));
             d.mark(stage, stream);
         }
@@ -535,6 +565,7 @@ enum jpeggpu_status jpeggpu_decoder_startup(jpeggpu_decoder_t* decoder)
     // asynchronous like every other mode (a truncated scan then shows as untouched planes, the reference's own
     // behaviour for corrupt entropy data); =2 is the CHECKED mode, in which decode waits for the stream and returns
     // the device's verdict -- the only way such a caller can learn it, at the price of a blocking call (jpeggpu_ext.h).
+    if (const char* e = std::getenv("JPEGGPU_MULTI_HYPOTHESIS")) (*decoder)->d.mh_enabled = std::atoi(e) != 0;
     if (const char* e = std::getenv("JPEGGPU_DEVICE_SCAN")) {
         const int v = std::atoi(e);
         (*decoder)->d.device_scan = v == 1 || v == 2 ? v : 0;

@@ -252,6 +252,7 @@ struct ScanParams {
     uint32_t tab_bytes;   // size of the scan's Huffman table pack (tables + cursor ring) the kernel at hand uses
     uint32_t cursor_off;  // byte offset of the cursor ring in that pack
     uint32_t tab_bytes_sync, cursor_off_sync; // the same for the sync pack (state-only passes)
+    int mh;               // hypotheses per subsequence of the multi-hypothesis speculation (below); 0: off
     /// The state-only kernels call this on their copy of the parameters before loading the tables.
     JG_HD inline void use_sync_pack()
     {
@@ -259,6 +260,28 @@ struct ScanParams {
         cursor_off = cursor_off_sync;
     }
 };
+
+/// MULTI-HYPOTHESIS SPECULATION (one image at a time). The synchronisation of the reference (decode_huffman.cu:413-524)
+/// guesses that every subsequence starts a data unit of index 0; a flow then runs until its state meets a stored one,
+/// and with several data units per MCU that takes long for one reason: position and zig-zag index of two decoders of the
+/// same bits fall into step within a unit or two, the data-unit INDEX never does -- it stays off by a constant until a
+/// table mismatch (luma bits read with the chroma tables) throws the decoder out of step and it comes back at another
+/// offset. The longest flow of a 12 MP 4:2:0 image passes 17 subsequences of 64 bytes, 32 on the reference's photo, and
+/// one image alone waits for exactly that chain. So every subsequence is speculated once per data unit of the MCU
+/// (kernel huff_mh_spec: hypothesis h = "a unit of index h starts at my first bit"); a second kernel (huff_mh_flow)
+/// decodes, for every candidate exit state, the FOLLOWING subsequence and notes which of ITS candidates it reaches (99 %
+/// after one subsequence: one of the candidates has the right index); a third (huff_mh_resolve) walks these links from
+/// each restart segment's first subsequence, whose hypothesis 0 is exact, and writes the chain's states as the table
+/// huff_sync_intra starts from. That kernel then runs the reference's algorithm unchanged -- its flows verify every
+/// entry and supply the coefficient counts -- and meets agreement at once nearly everywhere: 3 passes instead of 17, 6
+/// instead of 32. Correctness does not depend on any of this: the flows reach the sequential decoder's states from ANY
+/// initial table (tests/test_emulation.py runs it on the host twin).
+///   candidates: mh_p / mh_cz [h * num_subseq + sub]; link of a candidate: steps (1..kMhSteps, 0 = none) | the candidate
+///   reached << 4; mh_known[sub]: the chain passed through sub (an entry it hopped over is filled by the flow upstream).
+constexpr int kMhMaxHyp        = 8;    // 4-bit candidate index; more data units per MCU: plain speculation
+constexpr int kMhSteps         = 4;    // subsequences a candidate's flow runs before it gives up
+constexpr int kMhMaxSegSubseq  = 1024; // the chain walk of a segment happens in LDS
+constexpr uint32_t kMhNoLink   = 0;
 
 struct CursorEntry {
     uint32_t tabs; // dc table offset | ac table offset << 16
@@ -330,6 +353,10 @@ struct ScanJob {
     int* tails_n;                // per-sequence aggregates used to place the write pass
     uint32_t* tails_dc01;
     uint32_t* tails_dc23;
+    int* mh_p;                   // multi-hypothesis speculation (above): candidate states [mh][num_subseq],
+    int* mh_cz;
+    uint32_t* mh_link;           //   their links,
+    uint8_t* mh_known;           //   [num_subseq]: the resolved chain passed through
     uint16_t* sym;               // symbol stream: one region of `sym_region` 16-bit entries per subsequence, interleaved (above)
     uint2_t* du_tab;             // per data unit (stream order): {physical index of the first entry, number of entries}
     uint32_t sym_region;         // entries per subsequence region

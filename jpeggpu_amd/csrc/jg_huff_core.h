@@ -335,7 +335,10 @@ JG_HD inline void decode_subsequence(
 }
 
 /// Iterations of the write pass's loop between two DC SLOTS (below).
-constexpr int kWriteDcPeriod = 4;
+#ifndef JG_WRITE_DC_PERIOD
+#define JG_WRITE_DC_PERIOD 4
+#endif
+constexpr int kWriteDcPeriod = JG_WRITE_DC_PERIOD; // a power of two
 
 JG_HD inline uint32_t bit_mask(int s)
 {

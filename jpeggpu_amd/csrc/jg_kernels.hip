@@ -82,6 +82,10 @@ struct JobView {
     JG_GLOBAL int* tails_n;
     JG_GLOBAL uint32_t* tails_dc01;
     JG_GLOBAL uint32_t* tails_dc23;
+    JG_GLOBAL int* mh_p;
+    JG_GLOBAL int* mh_cz;
+    JG_GLOBAL uint32_t* mh_link;
+    JG_GLOBAL uint8_t* mh_known;
     JG_GLOBAL uint16_t* sym;
     JG_GLOBAL uint2_t* du_tab;
     uint32_t sym_region;
@@ -97,6 +101,7 @@ struct JobView {
           st_dc01(as_global(j.st_dc01)), st_dc23(as_global(j.st_dc23)), pending(as_global(j.pending)),
           flow_list(as_global(j.flow_list)), tail_parts(as_global(j.tail_parts)), num_tail_parts(j.num_tail_parts),
           tails_n(as_global(j.tails_n)), tails_dc01(as_global(j.tails_dc01)), tails_dc23(as_global(j.tails_dc23)),
+          mh_p(as_global(j.mh_p)), mh_cz(as_global(j.mh_cz)), mh_link(as_global(j.mh_link)), mh_known(as_global(j.mh_known)),
           sym(as_global(j.sym)), du_tab(as_global(j.du_tab)), sym_region(j.sym_region), sym_entries(j.sym_entries),
           num_chunks(j.num_chunks), num_seq(j.num_seq), sp(j.sp), ip(j.ip)
     {
@@ -570,27 +575,43 @@ __global__ __launch_bounds__(T) void huff_sync_intra(JS js)
     constexpr int kBits = W * 32;
     const int sub       = img_first + t;
     const bool active   = sub >= 0 && t < img_end;
+    // Multi-hypothesis speculation (jg_defs.h): the table this kernel starts from was written by huff_mh_resolve -- for
+    // every subsequence the candidate state the chain of links passes through -- instead of being speculated here. The
+    // flows below then are the reference's, from that table; an entry the chain hopped over (not `known`) starts no
+    // flow and stops none: the flow from upstream fills it in.
+    const bool mh = !JS::kSpeculateStateOnly && sp.mh > 1;
     LaneState st{};
     BitWindow<GlobalFetch<W>> bw{};
     GlobalFetch<W> fetch{reinterpret_cast<JG_GLOBAL const uint32_t*>(J.destuffed), 0, 0};
     Segment seg{0, 0};
     int rel = 0;
+    bool known = true;
     if (active) {
-        // speculative pass: the own subsequence from the guessed state (c, z) = (0, 0), exit state only
-        seg  = ld_global(J.segments + J.seg_idx[sub]);
-        rel  = sub - seg.subseq_offset;
-        st.p = rel * kBits;
-        fetch.set_row(sub, rel);
-        bw.seek(st.p, fetch);
-        if (JS::kSpeculateStateOnly) {
-            SpecSink none;
-            decode_subsequence(st, bw, fetch, (rel + 1) * kBits, s_tab, sp, none);
+        seg = ld_global(J.segments + J.seg_idx[sub]);
+        rel = sub - seg.subseq_offset;
+        if (mh) {
+            st.p         = J.st_p[sub];
+            const int cz = J.st_cz[sub];
+            st.c         = cz & 0xFF;
+            st.z         = cz >> 8;
+            known        = J.mh_known[sub] != 0;
+            s_pend[t]    = known ? 2 : 0; // bit 1: the entry is a state some flow may stop at
         } else {
-            NoSink sums; // exact for a subsequence that opens a segment, replaced by a flow everywhere else
-            decode_subsequence(st, bw, fetch, (rel + 1) * kBits, s_tab, sp, sums);
-            s_n[t]    = st.n;
-            s_dc01[t] = st.dc01;
-            s_dc23[t] = st.dc23;
+            // speculative pass: the own subsequence from the guessed state (c, z) = (0, 0), exit state only
+            st.p = rel * kBits;
+            fetch.set_row(sub, rel);
+            bw.seek(st.p, fetch);
+            if (JS::kSpeculateStateOnly) {
+                SpecSink none;
+                decode_subsequence(st, bw, fetch, (rel + 1) * kBits, s_tab, sp, none);
+            } else {
+                NoSink sums; // exact for a subsequence that opens a segment, replaced by a flow everywhere else
+                decode_subsequence(st, bw, fetch, (rel + 1) * kBits, s_tab, sp, sums);
+                s_n[t]    = st.n;
+                s_dc01[t] = st.dc01;
+                s_dc23[t] = st.dc23;
+            }
+            s_pend[t] = 2;
         }
         s_p[t]  = st.p;
         s_cz[t] = st.c | (st.z << 8);
@@ -599,19 +620,22 @@ __global__ __launch_bounds__(T) void huff_sync_intra(JS js)
     JG_STAMP(2);
 
     // Flow passes. Lane t first decodes subsequence j = t + 1 from the own exit state. With a state-only
-    // speculative pass it also does so if j opens a restart segment -- from the segment's start state,
-    // which is known, not guessed -- so that every subsequence gets its n and DC sums from a decode
-    // that started in a real state; otherwise the speculative pass of such a j was already exact.
-    bool flowing = JS::kSpeculateStateOnly ? t + 1 < img_end && img_first + t + 1 >= 0 : active;
+    // speculative pass (and with the multi-hypothesis table) it also does so if j opens a restart segment -- from the
+    // segment's start state, which is known, not guessed -- so that every subsequence gets its n and DC sums from a
+    // decode that started in a real state; otherwise the speculative pass of such a j was already exact.
+    const bool covers_starts = JS::kSpeculateStateOnly || mh;
+    bool flowing = covers_starts ? t + 1 < img_end && img_first + t + 1 >= 0 : active;
     int lim      = 0; // flows stay below this lane index: end of the segment or of the image
     if (flowing) {
         const int sub_j = img_first + t + 1;
-        if (JS::kSpeculateStateOnly && (!active || rel + 1 == seg.subseq_count)) { // j opens the next segment
-            seg = ld_global(J.segments + J.seg_idx[sub_j]);
-            rel = -1;
-            st  = LaneState{};
+        if (covers_starts && (!active || rel + 1 == seg.subseq_count)) { // j opens the next segment
+            seg   = ld_global(J.segments + J.seg_idx[sub_j]);
+            rel   = -1;
+            st    = LaneState{};
+            known = true;
         }
         lim = min(img_end, seg.subseq_offset + seg.subseq_count - img_first);
+        flowing = known;
     }
     NoSink sink;
     int iter = 0;
@@ -627,12 +651,13 @@ __global__ __launch_bounds__(T) void huff_sync_intra(JS js)
             bw.seek(st.p, fetch);
             decode_subsequence(st, bw, fetch, (rel + 1) * kBits, s_tab, sp, sink);
             const int cz = st.c | (st.z << 8);
-            if (st.p == s_p[j] && cz == s_cz[j]) flowing = false; // synchronised; still store n / dc
+            if (st.p == s_p[j] && cz == s_cz[j] && (s_pend[j] & 2)) flowing = false; // synchronised; still store n / dc
             s_p[j]    = st.p;
             s_n[j]    = st.n;
             s_cz[j]   = cz;
             s_dc01[j] = st.dc01;
             s_dc23[j] = st.dc23;
+            s_pend[j] = 2; // from here on a state a flow may stop at
         } else {
             flowing = false;
         }
@@ -642,16 +667,157 @@ __global__ __launch_bounds__(T) void huff_sync_intra(JS js)
     }
     // Flows cut short by the iteration cap continue in huff_sync_tail from the entry they reached
     // last: mark that entry (flows still inside the overlap zone belong to the previous workgroup).
-    if (iter == sp.max_intra_iters && flowing && t + 1 + iter < lim && t + iter >= OV) s_pend[t + iter] = 1;
+    if (iter == sp.max_intra_iters && flowing && t + 1 + iter < lim && t + iter >= OV) s_pend[t + iter] |= 1;
     __syncthreads();
 
     if (active && t >= OV) {
-        J.pending[sub] = static_cast<uint8_t>(s_pend[t]);
+        J.pending[sub] = static_cast<uint8_t>(s_pend[t] & 1);
         J.st_p[sub]    = s_p[t];
         J.st_n[sub]    = s_n[t];
         J.st_cz[sub]   = s_cz[t];
         J.st_dc01[sub] = s_dc01[t];
         J.st_dc23[sub] = s_dc23[t];
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+// Huffman: multi-hypothesis speculation (one image at a time; jg_defs.h)
+// ------------------------------------------------------------------------------------------------
+
+/// Candidate exit states: lane (sub, h = blockIdx.y) decodes subsequence `sub` as if a data unit of index h started at
+/// its first bit (hypothesis 0 is the reference's speculation, decode_huffman.cu:457-467).
+template <int W, class JS>
+__global__ __launch_bounds__(T) void huff_mh_spec(JS js)
+{
+    extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
+    const JobView J(js.get());
+    ScanParams sp = J.sp;
+    sp.use_sync_pack();
+    load_tables(smem, J.tables_sync, sp);
+    __syncthreads();
+    const int sub = blockIdx.x * T + threadIdx.x, h = blockIdx.y;
+    if (sub >= sp.num_subseq) return;
+    const Segment seg = ld_global(J.segments + J.seg_idx[sub]);
+    const int rel     = sub - seg.subseq_offset;
+    LaneState st{};
+    st.p = rel * (W * 32);
+    st.c = h;
+    GlobalFetch<W> fetch{reinterpret_cast<JG_GLOBAL const uint32_t*>(J.destuffed), 0, 0};
+    fetch.set_row(sub, rel);
+    BitWindow<GlobalFetch<W>> bw{};
+    bw.seek(st.p, fetch);
+    SpecSink none;
+    decode_subsequence(st, bw, fetch, (rel + 1) * (W * 32), smem, sp, none);
+    const size_t at = static_cast<size_t>(h) * sp.num_subseq + sub;
+    J.mh_p[at]      = st.p;
+    J.mh_cz[at]     = st.c | (st.z << 8);
+}
+
+/// Links: lane (sub, h) decodes the subsequences behind `sub` from candidate h's exit state until the state it reaches
+/// is one of the candidates of the subsequence it has just decoded (or that subsequence opens a restart segment, whose
+/// hypothesis 0 is exact), kMhSteps at most.
+template <int W, class JS>
+__global__ __launch_bounds__(T) void huff_mh_flow(JS js)
+{
+    extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
+    const JobView J(js.get());
+    ScanParams sp = J.sp;
+    sp.use_sync_pack();
+    load_tables(smem, J.tables_sync, sp);
+    __syncthreads();
+    const int sub = blockIdx.x * T + threadIdx.x, h = blockIdx.y;
+    const int S = sp.num_subseq, H = sp.mh;
+    if (sub >= S) return;
+    const size_t at   = static_cast<size_t>(h) * S + sub;
+    const Segment seg = ld_global(J.segments + J.seg_idx[sub]);
+    const int seg_end = seg.subseq_offset + seg.subseq_count;
+    LaneState st{};
+    st.p = J.mh_p[at];
+    {
+        const int cz = J.mh_cz[at];
+        st.c         = cz & 0xFF;
+        st.z         = cz >> 8;
+    }
+    GlobalFetch<W> fetch{reinterpret_cast<JG_GLOBAL const uint32_t*>(J.destuffed), 0, 0};
+    SpecSink none;
+    uint32_t link = kMhNoLink;
+    for (int k = 1; k <= kMhSteps; ++k) {
+        const int t = sub + k;
+        if (t >= S) break;       // the scan ends here
+        if (t >= seg_end) {      // t opens the next segment: its hypothesis 0 starts in the true state
+            link = static_cast<uint32_t>(k);
+            break;
+        }
+        const int rel = t - seg.subseq_offset;
+        fetch.set_row(t, rel);
+        BitWindow<GlobalFetch<W>> bw{};
+        bw.seek(st.p, fetch);
+        decode_subsequence(st, bw, fetch, (rel + 1) * (W * 32), smem, sp, none);
+        const int cz = st.c | (st.z << 8);
+        int g        = -1;
+        for (int q = 0; q < H; ++q) {
+            const size_t c = static_cast<size_t>(q) * S + t;
+            if (J.mh_p[c] == st.p && J.mh_cz[c] == cz) g = q;
+        }
+        if (g >= 0) {
+            link = static_cast<uint32_t>(k) | static_cast<uint32_t>(g) << 4;
+            break;
+        }
+    }
+    J.mh_link[at] = link;
+}
+
+/// The chain: one workgroup per restart segment loads the segment's links into LDS, one lane walks them from the first
+/// subsequence's hypothesis 0, and everybody writes the table huff_sync_intra starts from: the candidate the chain
+/// passes through where it does (`mh_known`), hypothesis 0 as a placeholder where it hopped over a subsequence, and
+/// the plain speculation from where it broke off (a candidate that met none within kMhSteps).
+template <class JS>
+__global__ __launch_bounds__(256) void huff_mh_resolve(JS js)
+{
+    extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
+    const JobView J(js.get());
+    const ScanParams& sp = J.sp;
+    if (static_cast<int>(blockIdx.x) >= sp.num_segments) return;
+    const Segment seg = ld_global(J.segments + blockIdx.x);
+    const int n = seg.subseq_count, base = seg.subseq_offset, S = sp.num_subseq, H = sp.mh;
+    uint32_t* s_link = reinterpret_cast<uint32_t*>(smem);                // [H][n]
+    uint8_t* s_hyp   = smem + static_cast<size_t>(H) * n * 4;            // [n]: candidate the chain passes through, 0xFF none
+    const int t = threadIdx.x;
+    for (int i = t; i < H * n; i += 256) {
+        const int q = i / n, r = i - q * n;
+        s_link[i]   = J.mh_link[static_cast<size_t>(q) * S + base + r];
+    }
+    __shared__ int s_broke; // first subsequence behind the point where the chain broke off (n: it did not)
+    for (int r = t; r < n; r += 256) s_hyp[r] = 0xFF;
+    __syncthreads();
+    if (t == 0) {
+        int r = 0, h = 0, broke = n;
+        while (r < n) {
+            s_hyp[r]         = static_cast<uint8_t>(h);
+            const uint32_t l = s_link[h * n + r];
+            if ((l & 15u) == kMhNoLink) {
+                broke = r + 1;
+                break;
+            }
+            r += static_cast<int>(l & 15u);
+            h = static_cast<int>((l >> 4) & 15u);
+        }
+        s_broke = broke;
+    }
+    __syncthreads();
+    // Behind a break the table is the reference's plain speculation (hypothesis 0, every lane flows): only entries the
+    // chain HOPPED over stay unknown -- at most kMhSteps - 1 in a row, right behind a lane that flows through them; a
+    // longer run of entries nobody derives could leave the inter-sequence pass a stored state to stop at that nothing
+    // downstream was derived from.
+    for (int r = s_broke + t; r < n; r += 256) s_hyp[r] = 0;
+    __syncthreads();
+    for (int r = t; r < n; r += 256) {
+        const int h      = s_hyp[r];
+        const bool known = h != 0xFF;
+        const size_t at  = static_cast<size_t>(known ? h : 0) * S + base + r;
+        J.st_p[base + r]     = J.mh_p[at];
+        J.st_cz[base + r]    = J.mh_cz[at];
+        J.mh_known[base + r] = known ? 1 : 0;
     }
 }
 
@@ -1134,6 +1300,7 @@ __global__ __launch_bounds__(T) void huff_write(JS js)
     // quota of data units if it is the segment's last (Appendix B-5).
     sink.quota          = seg_mcus1 * sp.du_per_mcu;
     if (rel + 1 < seg.subseq_count) sink.quota = min(sink.quota, seg_mcus0 * sp.du_per_mcu + ((nnext + 63) >> 6));
+    sink.du = min(sink.du, sink.quota); // both follow from consistent counts; should they ever not, nothing leaves the table
     sink.base           = sym_region_base(static_cast<uint32_t>(sub), J.sym_region);
     sink.flushed        = 0;
     sink.emitted        = 0;
@@ -1646,6 +1813,35 @@ void extend(JobExtent& e, const ScanJob& job)
     e.subseq_words    = job.sp.subseq_words;
     e.max_tail_parts  = job.num_tail_parts > e.max_tail_parts ? job.num_tail_parts : e.max_tail_parts;
     e.max_tail_part   = job.max_tail_part > e.max_tail_part ? job.max_tail_part : e.max_tail_part;
+}
+
+template <int W>
+hipError_t launch_mh_w(const ScanJob& job, int max_seg_subseq, hipStream_t stream)
+{
+    typedef JobByValue JS;
+    const JS js{job};
+    const dim3 grid((job.sp.num_subseq + T - 1) / T, job.sp.mh);
+    const size_t lds = job.sp.tab_bytes_sync;
+    hipError_t err;
+    if ((err = allow_lds(huff_mh_spec<W, JS>, lds)) != hipSuccess) return err;
+    if ((err = allow_lds(huff_mh_flow<W, JS>, lds)) != hipSuccess) return err;
+    huff_mh_spec<W, JS><<<grid, T, lds, stream>>>(js);
+    huff_mh_flow<W, JS><<<grid, T, lds, stream>>>(js);
+    huff_mh_resolve<JS><<<job.sp.num_segments, 256, static_cast<size_t>(job.sp.mh) * max_seg_subseq * 4 + max_seg_subseq + 16, stream>>>(js);
+    return hipGetLastError();
+}
+
+hipError_t launch_mh(const ScanJob& job, int max_seg_subseq, hipStream_t stream)
+{
+    if (job.sp.mh < 2 || job.sp.mh > kMhMaxHyp || max_seg_subseq > kMhMaxSegSubseq || job.sp.num_subseq == 0) return hipErrorInvalidValue;
+    if (job.sp.tab_bytes_sync > kMaxTablePackSync) return hipErrorInvalidValue;
+    switch (job.sp.subseq_words) {
+    case 8: return launch_mh_w<8>(job, max_seg_subseq, stream);
+    case 16: return launch_mh_w<16>(job, max_seg_subseq, stream);
+    case 32: return launch_mh_w<32>(job, max_seg_subseq, stream);
+    case 64: return launch_mh_w<64>(job, max_seg_subseq, stream);
+    }
+    return hipErrorInvalidValue;
 }
 
 hipError_t launch_stage(Stage stage, const ScanJob& job, hipStream_t stream)

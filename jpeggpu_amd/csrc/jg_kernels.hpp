@@ -39,6 +39,10 @@ void extend(JobExtent& e, const ScanJob& job);
 /// One stage for ONE job passed by value as a kernel argument (the drop-in single-image API).
 hipError_t launch_stage(Stage stage, const ScanJob& job, hipStream_t stream);
 
+/// The three kernels of the multi-hypothesis speculation (jg_defs.h) for ONE job with sp.mh > 1, in front of
+/// kStageSyncIntra. `max_seg_subseq`: subsequences of the job's largest restart segment.
+hipError_t launch_mh(const ScanJob& job, int max_seg_subseq, hipStream_t stream);
+
 /// One stage for `num_jobs` jobs stored in device memory, one per blockIdx.y (the batch API).
 hipError_t launch_stage_batch(
     Stage stage, const ScanJob* d_jobs, int num_jobs, const JobExtent& extent, hipStream_t stream);
