@@ -74,7 +74,7 @@ struct ScanPlan {
     size_t destuffed = 0, seg_idx = 0, st_p = 0, st_n = 0, st_cz = 0, st_dc01 = 0, st_dc23 = 0;
     size_t tails_n = 0, tails_dc01 = 0, tails_dc23 = 0, pending = 0, flow_list = 0;
     size_t sym = 0, du_tab = 0;
-    size_t mh_p = 0, mh_cz = 0, mh_link = 0, mh_known = 0; // multi-hypothesis speculation (jg_defs.h), if mh > 1
+    size_t mh_p = 0, mh_cz = 0, mh_link = 0, mh_pool = 0, mh_known = 0; // multi-hypothesis speculation (jg_defs.h), if mh > 1
     int mh = 0, max_seg_subseq = 0;
     int num_seq = 0;
     // device-side front end (jg_front.hip): tables built on the device, scratch, the job and the status word
@@ -210,6 +210,8 @@ void Decoder::make_plan()
                 o += align_up(N * 4, 256);
                 sp.mh_link = o;
                 o += align_up(N * 4, 256);
+                sp.mh_pool = o;
+                o += align_up((1 + static_cast<size_t>(mh_pool_entries(static_cast<uint32_t>(S)))) * sizeof(uint2_t), 256);
                 sp.mh_known = o;
                 o += align_up(S, 256);
             }
@@ -361,6 +363,7 @@ jpeggpu_status build_jobs(
         job.mh_p            = reinterpret_cast<int*>(base + pl.mh_p);
         job.mh_cz           = reinterpret_cast<int*>(base + pl.mh_cz);
         job.mh_link         = reinterpret_cast<uint32_t*>(base + pl.mh_link);
+        job.mh_pool         = reinterpret_cast<uint2_t*>(base + pl.mh_pool);
         job.mh_known        = base + pl.mh_known;
         IdctParams& ip = job.ip;
         ip.num_du      = sc.num_du;

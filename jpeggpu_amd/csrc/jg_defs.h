@@ -277,11 +277,17 @@ struct ScanParams {
 /// instead of 32. Correctness does not depend on any of this: the flows reach the sequential decoder's states from ANY
 /// initial table (tests/test_emulation.py runs it on the host twin).
 ///   candidates: mh_p / mh_cz [h * num_subseq + sub]; link of a candidate: steps (1..kMhSteps, 0 = none) | the candidate
-///   reached << 4; mh_known[sub]: the chain passed through sub (an entry it hopped over is filled by the flow upstream).
+///   reached << 4 | where the states it passed on the way are kept << 8 (a flow that needs more than one subsequence --
+///   2 % do, in detailed regions whose data units are longer than a subsequence -- leaves the exact states of the
+///   subsequences it hops over in a pool, mh_pool: kMhSteps - 1 entries {p, c | z << 8} from that index on; the index is
+///   kMhNoPool when the pool was full); mh_known[sub]: the table entry of sub is a state of the chain (an entry the
+///   chain hopped over without pool entries is filled by the flow from upstream).
 constexpr int kMhMaxHyp        = 8;    // 4-bit candidate index; more data units per MCU: plain speculation
-constexpr int kMhSteps         = 4;    // subsequences a candidate's flow runs before it gives up
+constexpr int kMhSteps         = 8;    // subsequences a candidate's flow runs before it gives up
 constexpr int kMhMaxSegSubseq  = 1024; // the chain walk of a segment happens in LDS
 constexpr uint32_t kMhNoLink   = 0;
+constexpr uint32_t kMhNoPool   = 0xFFFFFFu; // 24-bit pool index
+JG_HD inline uint32_t mh_pool_entries(uint32_t num_subseq) { return 2u * num_subseq + 64u; } // states; one counter in front
 
 struct CursorEntry {
     uint32_t tabs; // dc table offset | ac table offset << 16
@@ -356,7 +362,8 @@ struct ScanJob {
     int* mh_p;                   // multi-hypothesis speculation (above): candidate states [mh][num_subseq],
     int* mh_cz;
     uint32_t* mh_link;           //   their links,
-    uint8_t* mh_known;           //   [num_subseq]: the resolved chain passed through
+    uint2_t* mh_pool;            //   [1 + mh_pool_entries]: entry 0.x counts the states handed out, states from entry 1 on
+    uint8_t* mh_known;           //   [num_subseq]: the table entry is a state of the resolved chain
     uint16_t* sym;               // symbol stream: one region of `sym_region` 16-bit entries per subsequence, interleaved (above)
     uint2_t* du_tab;             // per data unit (stream order): {physical index of the first entry, number of entries}
     uint32_t sym_region;         // entries per subsequence region

@@ -85,6 +85,7 @@ struct JobView {
     JG_GLOBAL int* mh_p;
     JG_GLOBAL int* mh_cz;
     JG_GLOBAL uint32_t* mh_link;
+    JG_GLOBAL uint2_t* mh_pool;
     JG_GLOBAL uint8_t* mh_known;
     JG_GLOBAL uint16_t* sym;
     JG_GLOBAL uint2_t* du_tab;
@@ -101,7 +102,7 @@ struct JobView {
           st_dc01(as_global(j.st_dc01)), st_dc23(as_global(j.st_dc23)), pending(as_global(j.pending)),
           flow_list(as_global(j.flow_list)), tail_parts(as_global(j.tail_parts)), num_tail_parts(j.num_tail_parts),
           tails_n(as_global(j.tails_n)), tails_dc01(as_global(j.tails_dc01)), tails_dc23(as_global(j.tails_dc23)),
-          mh_p(as_global(j.mh_p)), mh_cz(as_global(j.mh_cz)), mh_link(as_global(j.mh_link)), mh_known(as_global(j.mh_known)),
+          mh_p(as_global(j.mh_p)), mh_cz(as_global(j.mh_cz)), mh_link(as_global(j.mh_link)), mh_pool(as_global(j.mh_pool)), mh_known(as_global(j.mh_known)),
           sym(as_global(j.sym)), du_tab(as_global(j.du_tab)), sym_region(j.sym_region), sym_entries(j.sym_entries),
           num_chunks(j.num_chunks), num_seq(j.num_seq), sp(j.sp), ip(j.ip)
     {
@@ -696,6 +697,7 @@ __global__ __launch_bounds__(T) void huff_mh_spec(JS js)
     load_tables(smem, J.tables_sync, sp);
     __syncthreads();
     const int sub = blockIdx.x * T + threadIdx.x, h = blockIdx.y;
+    if (sub == 0 && h == 0) st_global(J.mh_pool, uint2_t{0u, 0u}); // nothing handed out yet (huff_mh_flow counts)
     if (sub >= sp.num_subseq) return;
     const Segment seg = ld_global(J.segments + J.seg_idx[sub]);
     const int rel     = sub - seg.subseq_offset;
@@ -740,12 +742,13 @@ __global__ __launch_bounds__(T) void huff_mh_flow(JS js)
     }
     GlobalFetch<W> fetch{reinterpret_cast<JG_GLOBAL const uint32_t*>(J.destuffed), 0, 0};
     SpecSink none;
-    uint32_t link = kMhNoLink;
+    uint32_t link = kMhNoLink, pool = kMhNoPool;
+    const uint32_t pool_cap = mh_pool_entries(static_cast<uint32_t>(S));
     for (int k = 1; k <= kMhSteps; ++k) {
         const int t = sub + k;
         if (t >= S) break;       // the scan ends here
         if (t >= seg_end) {      // t opens the next segment: its hypothesis 0 starts in the true state
-            link = static_cast<uint32_t>(k);
+            link = static_cast<uint32_t>(k) | pool << 8;
             break;
         }
         const int rel = t - seg.subseq_offset;
@@ -760,63 +763,131 @@ __global__ __launch_bounds__(T) void huff_mh_flow(JS js)
             if (J.mh_p[c] == st.p && J.mh_cz[c] == cz) g = q;
         }
         if (g >= 0) {
-            link = static_cast<uint32_t>(k) | static_cast<uint32_t>(g) << 4;
+            link = static_cast<uint32_t>(k) | static_cast<uint32_t>(g) << 4 | pool << 8;
             break;
         }
+        // no candidate of t is this state: keep it -- if this flow is the chain's, it is the true state of t
+        if (k == 1) {
+            const uint32_t first = __hip_atomic_fetch_add(reinterpret_cast<JG_GLOBAL uint32_t*>(J.mh_pool), static_cast<uint32_t>(kMhSteps - 1), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            if (first + (kMhSteps - 1) <= pool_cap) pool = first;
+        }
+        if (pool != kMhNoPool && k < kMhSteps) st_global(J.mh_pool + 1 + pool + (k - 1), uint2_t{static_cast<uint32_t>(st.p), static_cast<uint32_t>(cz)});
     }
     J.mh_link[at] = link;
 }
 
-/// The chain: one workgroup per restart segment loads the segment's links into LDS, one lane walks them from the first
-/// subsequence's hypothesis 0, and everybody writes the table huff_sync_intra starts from: the candidate the chain
-/// passes through where it does (`mh_known`), hypothesis 0 as a placeholder where it hopped over a subsequence, and
-/// the plain speculation from where it broke off (a candidate that met none within kMhSteps).
+/// LDS of huff_mh_resolve for a segment of n subsequences with H candidates each.
+__host__ __device__ constexpr size_t mh_resolve_lds(int H, int n)
+{
+    return static_cast<size_t>(H) * n * 8 + static_cast<size_t>(n) * 5 + static_cast<size_t>(n / 16 + 4) * 2 + 64;
+}
+
+/// The chain: one workgroup per restart segment loads the segment's links into LDS and follows them from the first
+/// subsequence's hypothesis 0; everybody then writes the table huff_sync_intra starts from: the candidate the chain
+/// passes through where it does, the state a hopping flow left in the pool where the chain hopped over a subsequence
+/// (both `mh_known`), hypothesis 0 as a placeholder where it hopped and the pool was full, and the plain speculation
+/// from where the chain broke off (a candidate that met none within kMhSteps).
+///
+/// Followed link by link by one lane the chain of a 21 KB segment is 334 dependent LDS reads, 20 us for a kernel whose
+/// whole point is a shorter critical path. So the links are squared four times first (every node gets its 16th
+/// successor: pointer jumping, all lanes), one lane walks those -- n / 16 steps -- and leaves an ANCHOR every 16
+/// links, and the lanes then walk the 16 links behind each anchor in parallel.
 template <class JS>
 __global__ __launch_bounds__(256) void huff_mh_resolve(JS js)
 {
     extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
+    __shared__ int s_broke, s_anchors; // first subsequence behind the point where the chain broke off (n: nowhere); anchors
     const JobView J(js.get());
     const ScanParams& sp = J.sp;
     if (static_cast<int>(blockIdx.x) >= sp.num_segments) return;
     const Segment seg = ld_global(J.segments + blockIdx.x);
     const int n = seg.subseq_count, base = seg.subseq_offset, S = sp.num_subseq, H = sp.mh;
-    uint32_t* s_link = reinterpret_cast<uint32_t*>(smem);                // [H][n]
-    uint8_t* s_hyp   = smem + static_cast<size_t>(H) * n * 4;            // [n]: candidate the chain passes through, 0xFF none
+    const int nodes  = H * n;                                               // node (h, r) = h * n + r
+    uint32_t* s_link = reinterpret_cast<uint32_t*>(smem);                    // [nodes]
+    uint32_t* s_src  = s_link + nodes;                                       // [n]: 1 + pool entry of a subsequence the chain hopped over, 0 none
+    uint16_t* s_ja   = reinterpret_cast<uint16_t*>(s_src + n);               // [nodes] successor tables (ping-pong)
+    uint16_t* s_jb   = s_ja + nodes;
+    uint16_t* s_anc  = s_jb + nodes;                                         // [n / 16 + 2]: h << 12 | r of every 16th node of the chain
+    uint8_t* s_hyp   = reinterpret_cast<uint8_t*>(s_anc + (n / 16 + 4));     // [n]: candidate the chain passes through, 0xFF none
+    constexpr uint32_t kEnd = 0xFFFFu, kBreak = 0xFFFEu;
     const int t = threadIdx.x;
-    for (int i = t; i < H * n; i += 256) {
+    for (int i = t; i < nodes; i += 256) {
         const int q = i / n, r = i - q * n;
-        s_link[i]   = J.mh_link[static_cast<size_t>(q) * S + base + r];
+        const uint32_t l = J.mh_link[static_cast<size_t>(q) * S + base + r];
+        s_link[i]        = l;
+        const int k = static_cast<int>(l & 15u), r2 = r + k;
+        s_ja[i] = static_cast<uint16_t>(k == 0 ? kBreak : r2 >= n ? kEnd : ((l >> 4) & 15u) * n + r2);
     }
-    __shared__ int s_broke; // first subsequence behind the point where the chain broke off (n: it did not)
-    for (int r = t; r < n; r += 256) s_hyp[r] = 0xFF;
+    for (int r = t; r < n; r += 256) {
+        s_hyp[r] = 0xFF;
+        s_src[r] = 0;
+    }
+    if (t == 0) s_broke = n;
     __syncthreads();
+    for (int round = 0; round < 4; ++round) { // successor -> 16th successor
+        for (int i = t; i < nodes; i += 256) {
+            const uint32_t a = s_ja[i];
+            s_jb[i]          = static_cast<uint16_t>(a >= kBreak ? a : s_ja[a]);
+        }
+        __syncthreads();
+        uint16_t* sw = s_ja;
+        s_ja         = s_jb;
+        s_jb         = sw;
+    }
     if (t == 0) {
-        int r = 0, h = 0, broke = n;
-        while (r < n) {
+        int m = 0;
+        uint32_t a = 0; // node (0, 0): hypothesis 0 of the segment's first subsequence is exact
+        while (a < kBreak) {
+            const uint32_t h = a / n;
+            s_anc[m++]       = static_cast<uint16_t>(h << 12 | (a - h * n));
+            a                = s_ja[a];
+        }
+        s_anchors = m;
+    }
+    __syncthreads();
+    for (int i = t; i < s_anchors; i += 256) {
+        int h = s_anc[i] >> 12, r = s_anc[i] & 0xFFF;
+        for (int step = 0; step < 16; ++step) {
             s_hyp[r]         = static_cast<uint8_t>(h);
             const uint32_t l = s_link[h * n + r];
-            if ((l & 15u) == kMhNoLink) {
-                broke = r + 1;
+            const int k      = static_cast<int>(l & 15u);
+            if (k == 0) {
+                s_broke = r + 1;
                 break;
             }
-            r += static_cast<int>(l & 15u);
+            const uint32_t pool = l >> 8;
+            for (int q = 1; q < k && r + q < n; ++q) s_src[r + q] = pool == kMhNoPool ? 0u : 1u + pool + static_cast<uint32_t>(q - 1);
+            r += k;
+            if (r >= n) break;
             h = static_cast<int>((l >> 4) & 15u);
         }
-        s_broke = broke;
     }
     __syncthreads();
     // Behind a break the table is the reference's plain speculation (hypothesis 0, every lane flows): only entries the
-    // chain HOPPED over stay unknown -- at most kMhSteps - 1 in a row, right behind a lane that flows through them; a
-    // longer run of entries nobody derives could leave the inter-sequence pass a stored state to stop at that nothing
+    // chain HOPPED over may stay unknown -- at most kMhSteps - 1 in a row, right behind a lane that flows through them;
+    // a longer run of entries nobody derives could leave the inter-sequence pass a stored state to stop at that nothing
     // downstream was derived from.
     for (int r = s_broke + t; r < n; r += 256) s_hyp[r] = 0;
     __syncthreads();
     for (int r = t; r < n; r += 256) {
-        const int h      = s_hyp[r];
-        const bool known = h != 0xFF;
-        const size_t at  = static_cast<size_t>(known ? h : 0) * S + base + r;
-        J.st_p[base + r]     = J.mh_p[at];
-        J.st_cz[base + r]    = J.mh_cz[at];
+        const int h = s_hyp[r];
+        int p, cz;
+        bool known = true;
+        if (h != 0xFF) {
+            const size_t at = static_cast<size_t>(h) * S + base + r;
+            p               = J.mh_p[at];
+            cz              = J.mh_cz[at];
+        } else if (s_src[r] != 0) {
+            const uint2_t e = ld_global(J.mh_pool + s_src[r]);
+            p               = static_cast<int>(e.x);
+            cz              = static_cast<int>(e.y);
+        } else {
+            p     = J.mh_p[base + r];
+            cz    = J.mh_cz[base + r];
+            known = false;
+        }
+        J.st_p[base + r]     = p;
+        J.st_cz[base + r]    = cz;
         J.mh_known[base + r] = known ? 1 : 0;
     }
 }
@@ -1827,13 +1898,16 @@ hipError_t launch_mh_w(const ScanJob& job, int max_seg_subseq, hipStream_t strea
     if ((err = allow_lds(huff_mh_flow<W, JS>, lds)) != hipSuccess) return err;
     huff_mh_spec<W, JS><<<grid, T, lds, stream>>>(js);
     huff_mh_flow<W, JS><<<grid, T, lds, stream>>>(js);
-    huff_mh_resolve<JS><<<job.sp.num_segments, 256, static_cast<size_t>(job.sp.mh) * max_seg_subseq * 4 + max_seg_subseq + 16, stream>>>(js);
+    const size_t rlds = mh_resolve_lds(job.sp.mh, max_seg_subseq);
+    if ((err = allow_lds(huff_mh_resolve<JS>, rlds)) != hipSuccess) return err;
+    huff_mh_resolve<JS><<<job.sp.num_segments, 256, rlds, stream>>>(js);
     return hipGetLastError();
 }
 
 hipError_t launch_mh(const ScanJob& job, int max_seg_subseq, hipStream_t stream)
 {
-    if (job.sp.mh < 2 || job.sp.mh > kMhMaxHyp || max_seg_subseq > kMhMaxSegSubseq || job.sp.num_subseq == 0) return hipErrorInvalidValue;
+    if (job.sp.num_subseq == 0 || job.sp.num_segments == 0) return hipSuccess; // an empty share of the segments: nothing to speculate
+    if (job.sp.mh < 2 || job.sp.mh > kMhMaxHyp || max_seg_subseq < 1 || max_seg_subseq > kMhMaxSegSubseq) return hipErrorInvalidValue;
     if (job.sp.tab_bytes_sync > kMaxTablePackSync) return hipErrorInvalidValue;
     switch (job.sp.subseq_words) {
     case 8: return launch_mh_w<8>(job, max_seg_subseq, stream);
