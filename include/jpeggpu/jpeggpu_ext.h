@@ -79,6 +79,11 @@ struct jpeggpu_ext_scan_layout {
      * tail parts), and off_segments / off_chunks point at tables the device has built. */
     int device_scan;
     size_t off_device_status;
+    /* Candidates per subsequence of the multi-hypothesis speculation that a lone decode (jpeggpu_decoder_decode) of this
+     * scan runs in front of its synchronisation -- one per data unit of the MCU --, 0 where it does not apply (one data
+     * unit per MCU, no restart segments, a decoder for batches, device scan) or JPEGGPU_MULTI_HYPOTHESIS=0 switched it
+     * off at startup. */
+    int hypotheses;
 };
 
 struct jpeggpu_ext_layout {

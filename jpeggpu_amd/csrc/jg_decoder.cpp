@@ -785,6 +785,7 @@ enum jpeggpu_status jpeggpu_ext_get_layout(jpeggpu_decoder_t decoder, struct jpe
         o.off_du_table       = pl.du_tab;
         o.symbol_region_entries = static_cast<int>(jg::sym_region_entries(d.subseq_bytes));
         o.device_scan           = sc.device_walk ? 1 : 0;
+        o.hypotheses            = pl.mh;
         if (sc.device_walk) {
             o.num_segments      = sc.expect_segments;
             o.num_chunks        = sc.max_chunks;

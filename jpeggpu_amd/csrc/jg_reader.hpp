@@ -96,10 +96,13 @@ struct Stream {
 constexpr int kSubseqAutoLone = 0, kSubseqAutoBatched = -1;
 
 /// Subsequence size for an image whose first scan has `scan_bytes_bound` bytes at most, in `segments` restart segments.
-///   * One image at a time: the sequence kernel's flows are a chain whose length in BITS is what the content makes it,
-///     so a shorter subsequence only shortens the lanes' serial decode around it: 64 bytes measured best from 0.08 to
-///     12 MP and on the reference's photo (tools/probe/latency_by_size.py; 32 bytes doubles the state traffic for no
-///     shorter chain).
+///   * One image at a time: what such a decode waits for is a handful of dependent passes over a subsequence (the
+///     multi-hypothesis speculation and the one or two flow passes behind it, jg_defs.h), so shorter subsequences are
+///     shorter passes -- as long as the extra lanes still fit the chip side by side and data units are not longer than
+///     subsequences (then candidates stop meeting and flows get long: the reference's photo takes 0.81 ms at 32 bytes,
+///     0.47 at 64). Measured (tools/probe/latency_by_size.py, p50 at 32 / 64 / 128 bytes): 0.08 MP 0.18 / 0.22 / 0.27 ms,
+///     2 MP 0.23 / 0.28 / 0.40, 12 MP 0.44 / 0.41 / 0.49: 32 bytes for scans below 1 MB that have restart segments,
+///     64 otherwise (without restart segments there is no multi-hypothesis table, and 64 was best at every size).
 ///   * Images that share launches: the chip is full anyway and every subsequence costs a fixed amount of state,
 ///     table loads and scan work, so the longest size wins -- 256 bytes -- unless the restart segments are so short
 ///     that padding each of them to whole subsequences would be a visible share of the decode (kept below 1/16: a
@@ -109,6 +112,7 @@ inline int choose_subseq_bytes(bool batched, size_t scan_bytes_bound, size_t seg
     if (segments == 0) segments = 1;
     const size_t per_segment = scan_bytes_bound / segments;
     int b = batched ? 256 : 64;
+    if (!batched && segments > 1 && scan_bytes_bound < (1u << 20)) b = 32;
     while (b > 32 && per_segment < static_cast<size_t>(8 * b)) b >>= 1;
     while (b > 64 && scan_bytes_bound < static_cast<size_t>(2 * kSeqSubseq) * static_cast<size_t>(b)) b >>= 1;
     return b;

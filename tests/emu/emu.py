@@ -28,8 +28,12 @@ class EmuScan:
     pass
 
 
-def decode_scan(data: bytes, scan_idx: int, subseq_bytes: int, max_intra_iters: int = 256):
+def decode_scan(data: bytes, scan_idx: int, subseq_bytes: int, max_intra_iters: int = 256, multi_hypothesis: bool = False):
+    """`multi_hypothesis`: the lone-decode path that starts the flows from the multi-hypothesis table (jg_defs.h), where
+    the scan qualifies (several data units per MCU, restart segments); r.mh_known / r.mh_subseq then say how much of
+    the table the chain of links supplied."""
     ns, nd, it = C.c_int(), C.c_int(), C.c_int()
+    lib().emu_set_multi_hypothesis(int(multi_hypothesis))
     rc = lib().emu_decode_scan(data, len(data), subseq_bytes, max_intra_iters, scan_idx, C.byref(ns), C.byref(nd),
                                None, None, None, None, None, None, None, None)
     if rc:
@@ -46,4 +50,6 @@ def decode_scan(data: bytes, scan_idx: int, subseq_bytes: int, max_intra_iters: 
                                ptr(r.seg_index), ptr(r.p), ptr(r.n), ptr(r.cz), ptr(r.dc), r.coef.ctypes.data,
                                C.byref(it))
     r.max_flow_iters = it.value
+    r.mh_known = C.c_int.in_dll(lib(), "g_mh_known").value if multi_hypothesis else 0
+    r.mh_subseq = C.c_int.in_dll(lib(), "g_mh_subseq").value if multi_hypothesis else 0
     return rc, r

@@ -140,6 +140,9 @@ void emu_destuff(const uint8_t* bytes, const Scan& sc, int subseq_bytes, std::ve
 extern "C" {
 
 int g_active_hist[512];
+int g_multi_hypothesis = 0; // emu_set_multi_hypothesis: the lone-decode path with the multi-hypothesis table (jg_defs.h)
+int g_mh_known = 0, g_mh_subseq = 0; // of the last scan decoded that way: entries the chain supplied / subsequences
+void emu_set_multi_hypothesis(int on) { g_multi_hypothesis = on; }
 
 /// Returns a jpeggpu_status. Outputs are for scan `scan_idx`; pointers may be null.
 int emu_decode_scan(
@@ -228,6 +231,72 @@ int emu_decode_scan(
         st[sub].p  = ls.p;
         st[sub].cz = ls.c | (ls.z << 8);
     }
+    // ---- multi-hypothesis speculation (huff_mh_spec / _flow / _resolve): the table the flows below start from ----
+    std::vector<uint8_t> known(S, 1);
+    bool mh = false;
+    g_mh_known = g_mh_subseq = 0;
+    if (g_multi_hypothesis && max_intra_iters >= kSeqLanes && sc.du_per_mcu >= 2 && sc.du_per_mcu <= kMhMaxHyp && s.restart_interval != 0) {
+        int longest = 0;
+        for (const Segment& g : sc.segments) longest = std::max(longest, g.subseq_count);
+        mh = longest <= kMhMaxSegSubseq;
+    }
+    if (mh) {
+        const int H = sc.du_per_mcu;
+        const auto decode_from = [&](int sub, int p, int cz) { // exit state of `sub` decoded from (p, c, z)
+            const Segment seg = sc.segments[segi[sub]];
+            const int rel     = sub - seg.subseq_offset;
+            HostFetch f{dst.data() + static_cast<size_t>(seg.subseq_offset) * subseq_bytes, seg.subseq_count * W};
+            LaneState ls{};
+            ls.p = p;
+            ls.c = cz & 0xFF;
+            ls.z = cz >> 8;
+            BitWindow<HostFetch> bw;
+            bw.seek(ls.p, f);
+            SpecSink spec_sink;
+            decode_subsequence(ls, bw, f, (rel + 1) * bits, tabs_sync, sp_sync, spec_sink);
+            return St{ls.p, 0, ls.c | (ls.z << 8), 0u, 0u};
+        };
+        std::vector<St> cand(static_cast<size_t>(H) * S);
+        for (int sub = 0; sub < S; ++sub)
+            for (int h = 0; h < H; ++h) cand[static_cast<size_t>(h) * S + sub] = decode_from(sub, (sub - sc.segments[segi[sub]].subseq_offset) * bits, h);
+        struct Link { int k, g; std::vector<St> passed; };
+        const auto link_of = [&](int sub, int h) {
+            Link l{0, 0, {}};
+            const Segment seg = sc.segments[segi[sub]];
+            St x = cand[static_cast<size_t>(h) * S + sub];
+            for (int k = 1; k <= kMhSteps; ++k) {
+                const int t = sub + k;
+                if (t >= S) break;
+                if (t >= seg.subseq_offset + seg.subseq_count) { l.k = k; l.g = 0; break; }
+                x = decode_from(t, x.p, x.cz);
+                int g = -1;
+                for (int q = 0; q < H; ++q)
+                    if (cand[static_cast<size_t>(q) * S + t].p == x.p && cand[static_cast<size_t>(q) * S + t].cz == x.cz) g = q;
+                if (g >= 0) { l.k = k; l.g = g; break; }
+                l.passed.push_back(x);
+            }
+            if (l.k == 0) l.passed.clear();
+            return l;
+        };
+        g_mh_known = 0;
+        g_mh_subseq = S;
+        for (const Segment& seg : sc.segments) {
+            const int n = seg.subseq_count, base = seg.subseq_offset;
+            for (int r = 0; r < n; ++r) { st[base + r] = cand[base + r]; known[base + r] = 0; } // placeholders: hypothesis 0
+            int r = 0, h = 0, broke = n;
+            while (r < n) {
+                st[base + r]    = cand[static_cast<size_t>(h) * S + base + r];
+                known[base + r] = 1;
+                const Link l    = link_of(base + r, h);
+                if (l.k == 0) { broke = r + 1; break; }
+                for (int q = 1; q < l.k && r + q < n; ++q) { st[base + r + q] = l.passed[q - 1]; known[base + r + q] = 1; }
+                r += l.k;
+                h = l.g;
+            }
+            for (int q = broke; q < n; ++q) known[base + q] = 1; // plain speculation behind a break
+            for (int q = 0; q < n; ++q) g_mh_known += known[base + q] && q < broke;
+        }
+    }
     const std::vector<St> spec = st;
 
     // ---- flow passes inside a sequence (second half of huff_sync_intra) ----
@@ -253,7 +322,7 @@ int emu_decode_scan(
             }
             L.end_bit = rel * bits;
             L.bw.seek(L.s.p, L.f);
-            L.flowing = true;
+            L.flowing = rel == 0 || known[j - 1] != 0; // an entry the chain hopped over starts no flow
         }
         int iter = 0;
         for (; iter < max_intra_iters; ++iter) {
@@ -269,9 +338,10 @@ int emu_decode_scan(
                     decode_subsequence(L.s, L.bw, L.f, L.end_bit, tabs_sync, sp_sync, nosink);
                     St& o        = st[first + j];
                     const int cz = L.s.c | (L.s.z << 8);
-                    if (L.s.p == o.p && cz == o.cz) L.flowing = false;
+                    if (L.s.p == o.p && cz == o.cz && known[first + j]) L.flowing = false; // ... and stops none
                     o.p = L.s.p; o.n = L.s.n; o.cz = cz;
                     o.dc01 = L.s.dc01; o.dc23 = L.s.dc23;
+                    known[first + j] = 1;
                 } else {
                     L.flowing = false;
                 }

@@ -28,6 +28,29 @@ def test_emulated_pipeline_equals_sequential_decode(subseq_bytes, max_intra_iter
             assert np.array_equal(r.coef, tw.stream_coef), (name, "coefficients")
 
 
+def test_multi_hypothesis_table_is_exact_and_shortens_the_flows():
+    """The lone-decode path (jg_defs.h, multi-hypothesis speculation): candidates per data unit of the MCU, links,
+    chain walk, and the reference's flows started from the chain's table. Whatever the table holds the flows must
+    reach the sequential decoder's states; where restart segments let the chain run (it starts at a segment's first
+    subsequence) it supplies the whole table and one flow pass verifies it."""
+    m = cases.matrix()
+    for name, data in m.items():
+        for s in range(oracle.decode(data).nscans):
+            for subseq_bytes in (64, 32):
+                rc, r = emu.decode_scan(data, s, subseq_bytes, 256, multi_hypothesis=True)
+                assert rc == 0, name
+                tw = oracle.scan_stages(data, s, subseq_bytes)
+                ok = tw.p >= 0
+                assert np.array_equal(r.p[ok], tw.p[ok]) and np.array_equal(r.n[ok], tw.n[ok]) and np.array_equal(r.cz[ok], tw.cz[ok]), name
+                assert np.array_equal(r.coef, tw.stream_coef), name
+                if name in ("multi_seq_dri", "cfg2_small", "dri_row", "dri_7") and subseq_bytes == 64:
+                    _, plain = emu.decode_scan(data, s, subseq_bytes, 256)
+                    assert r.mh_subseq == len(tw.p) and r.mh_known >= 0.95 * r.mh_subseq, (name, r.mh_known, r.mh_subseq)
+                    assert r.max_flow_iters <= 2 < plain.max_flow_iters, (name, r.max_flow_iters, plain.max_flow_iters)
+                if name in ("multi_seq_nodri", "gray", "ni_444"):  # no restart segments / one data unit per MCU: plain speculation
+                    assert r.mh_subseq == 0
+
+
 def test_emulated_photo(photo_bytes):
     tw = oracle.scan_stages(photo_bytes, 0, 128)
     for cap in (256, 3):

@@ -1,4 +1,6 @@
 """GPU parity: the HIP path, called through the C ABI, against the CPU oracle. Bit-exact."""
+import os
+
 import numpy as np
 import pytest
 
@@ -115,6 +117,23 @@ def test_reference_photo_full_size(gpu_lib, torch_cuda, photo_bytes):
     assert list(info.sizes_x)[:3] == [4032, 2016, 2016] and list(info.sizes_y)[:3] == [3024, 1512, 1512]
     for c in range(3):
         assert np.array_equal(got[c], ref.planes[c]), "component %d" % c
+    # that decode ran the multi-hypothesis speculation (six candidates per subsequence); with it switched off, and at
+    # the other subsequence sizes, the planes are the same
+    _, _, _tmp, _base, lay = jpeggpu_amd.decode_to_planes(photo_bytes, return_tmp=True)
+    assert lay.scans[0].hypotheses == 6 and lay.subsequence_bytes == 64
+    for sb in (32, 128):
+        planes, _, _tmp, _base, lay = jpeggpu_amd.decode_to_planes(photo_bytes, subseq_bytes=sb, return_tmp=True)
+        assert lay.scans[0].hypotheses == 6
+        for c in range(3):
+            assert np.array_equal(planes[c].cpu().numpy(), ref.planes[c]), "multi-hypothesis, %d bytes, component %d" % (sb, c)
+    os.environ["JPEGGPU_MULTI_HYPOTHESIS"] = "0"
+    try:
+        planes, _, _tmp, _base, lay = jpeggpu_amd.decode_to_planes(photo_bytes, return_tmp=True)
+    finally:
+        del os.environ["JPEGGPU_MULTI_HYPOTHESIS"]
+    assert lay.scans[0].hypotheses == 0
+    for c in range(3):
+        assert np.array_equal(planes[c].cpu().numpy(), ref.planes[c]), "plain speculation, component %d" % c
     # the same with the marker scan on the device. The 1.17 MB of padding behind EOI is not transferred (host search
     # for the last EOI from the back, reference src/decoder.cpp:175-180 copies the whole file) ...
     planes, _, _tmp, _base, lay = jpeggpu_amd.decode_to_planes(photo_bytes, device_scan=True, return_tmp=True)
