@@ -81,7 +81,7 @@ struct jpeggpu_ext_scan_layout {
     size_t off_device_status;
     /* Candidates per subsequence of the multi-hypothesis speculation that a lone decode (jpeggpu_decoder_decode) of this
      * scan runs in front of its synchronisation -- one per data unit of the MCU --, 0 where it does not apply (one data
-     * unit per MCU, no restart segments, a decoder for batches, device scan) or JPEGGPU_MULTI_HYPOTHESIS=0 switched it
+     * unit per MCU, no restart segments, a decoder for batches) or JPEGGPU_MULTI_HYPOTHESIS=0 switched it
      * off at startup. */
     int hypotheses;
 };

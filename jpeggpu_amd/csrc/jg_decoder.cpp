@@ -195,10 +195,10 @@ void Decoder::make_plan()
         sp.tails_dc23 = o;
         o += align_up(static_cast<size_t>(sp.num_seq) * 4, 256);
         // Multi-hypothesis speculation (jg_defs.h) for an image decoded on its own: several data units per MCU,
-        // restart segments the chain walk can hold in LDS, tables from the host walk.
+        // restart segments the chain walk can hold in LDS.
         sp.mh = 0;
-        if (!batched && !sc.device_walk && sc.du_per_mcu >= 2 && sc.du_per_mcu <= kMhMaxHyp && s.restart_interval != 0 && mh_enabled) {
-            int longest = 0;
+        if (!batched && sc.du_per_mcu >= 2 && sc.du_per_mcu <= kMhMaxHyp && s.restart_interval != 0 && mh_enabled) {
+            int longest = sc.device_walk ? kMhMaxSegSubseq : 0; // the device finds the segments: it falls back where one is longer
             for (const Segment& g : sc.segments) longest = std::max(longest, g.subseq_count);
             if (longest <= kMhMaxSegSubseq) {
                 sp.mh             = sc.du_per_mcu;
@@ -328,7 +328,7 @@ jpeggpu_status do_transfer(Decoder& d, void* d_tmp, size_t tmp_size, hipStream_t
 
 /// Validate the arguments of a decode and describe every scan of the image as a ScanJob.
 jpeggpu_status build_jobs(
-    Decoder& d, const jpeggpu_img* img, void* d_tmp, size_t tmp_size, int max_intra_iters, std::vector<jg::ScanJob>& jobs)
+    Decoder& d, const jpeggpu_img* img, void* d_tmp, size_t tmp_size, int max_intra_iters, bool lone, std::vector<jg::ScanJob>& jobs)
 {
     using namespace jg;
     if (!d.parsed) return JPEGGPU_INVALID_ARGUMENT;
@@ -359,7 +359,7 @@ jpeggpu_status build_jobs(
         sp.cursor_off       = sc.cursor_off;
         sp.tab_bytes_sync   = static_cast<uint32_t>(sc.table_pack_sync.size());
         sp.cursor_off_sync  = sc.cursor_off_sync;
-        sp.mh               = pl.mh;
+        sp.mh               = lone ? pl.mh : 0; // the multi-hypothesis kernels run in front of a lone decode's sequence kernel only
         job.mh_p            = reinterpret_cast<int*>(base + pl.mh_p);
         job.mh_cz           = reinterpret_cast<int*>(base + pl.mh_cz);
         job.mh_link         = reinterpret_cast<uint32_t*>(base + pl.mh_link);
@@ -494,7 +494,7 @@ jpeggpu_status do_decode(Decoder& d, jpeggpu_img* img, void* d_tmp, size_t tmp_s
     using namespace jg;
     d.jobs.clear();
     // one image: latency matters, keep every flow inside the sequence's workgroup
-    const jpeggpu_status st = build_jobs(d, img, d_tmp, tmp_size, jg::kSeqLanes, d.jobs);
+    const jpeggpu_status st = build_jobs(d, img, d_tmp, tmp_size, jg::kSeqLanes, true, d.jobs);
     if (st != JPEGGPU_SUCCESS) return st;
     d.next_event_set();
     d.mark(-1, stream);
@@ -508,6 +508,7 @@ jpeggpu_status do_decode(Decoder& d, jpeggpu_img* img, void* d_tmp, size_t tmp_s
         JobExtent extent;
         extend(extent, d.jobs[0]);
         for (int stage = 0; stage < kNumStages; ++stage) {
+            if (stage == kStageSyncIntra && d.jobs[0].sp.mh > 1) JG_CHECK_HIP(launch_mh(d.jobs[0], d_job, d.plan.scan[0].max_seg_subseq, stream));
             JG_CHECK_HIP(launch_stage_batch(static_cast<Stage>(stage), d_job, 1, extent, stream));
             d.mark(stage, stream);
         }
@@ -529,7 +530,7 @@ jpeggpu_status do_decode(Decoder& d, jpeggpu_img* img, void* d_tmp, size_t tmp_s
             static_cast<int>(i), job.num_chunks, job.sp.num_subseq, d.subseq_bytes, job.num_seq, job.sp.num_segments);
         for (int stage = 0; stage < kNumStages; ++stage) {
             // multi-hypothesis speculation in front of the sequence kernel, which then starts from its table
-            if (stage == kStageSyncIntra && job.sp.mh > 1) JG_CHECK_HIP(launch_mh(job, d.plan.scan[i].max_seg_subseq, stream));
+            if (stage == kStageSyncIntra && job.sp.mh > 1) JG_CHECK_HIP(launch_mh(job, nullptr, d.plan.scan[i].max_seg_subseq, stream));
             JG_CHECK_HIP(launch_stage(static_cast<Stage>(stage), job, stream));
             d.mark(stage, stream);
         }
@@ -914,7 +915,7 @@ enum jpeggpu_status jpeggpu_ext_decode_batch(
             group_begin.push_back(static_cast<int>(batch->jobs.size()));
         }
         const size_t first_job = batch->jobs.size();
-        const jpeggpu_status st = build_jobs(it.decoder->d, it.img, it.d_tmp, it.tmp_size, batch->sync_iters, batch->jobs);
+        const jpeggpu_status st = build_jobs(it.decoder->d, it.img, it.d_tmp, it.tmp_size, batch->sync_iters, false, batch->jobs);
         if (st != JPEGGPU_SUCCESS) return st;
         if (it.decoder->d.reader.s.scans[0].device_walk) {
             // device-side front end (jpeggpu_ext_set_device_scan): the counts of this job are filled in on the device

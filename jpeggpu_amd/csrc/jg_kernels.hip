@@ -123,6 +123,14 @@ struct JobArray {
     __device__ __forceinline__ const ScanJob& get() const { return jobs[blockIdx.y]; }
 };
 
+struct JobSingle {
+    // One job that lives in device memory, whatever blockIdx.y is (the multi-hypothesis kernels of a device-scanned
+    // image: their grid's second dimension is the hypothesis).
+    static constexpr bool kSpeculateStateOnly = false;
+    const ScanJob* job;
+    __device__ __forceinline__ const ScanJob& get() const { return *job; }
+};
+
 // ------------------------------------------------------------------------------------------------
 // destuff
 // ------------------------------------------------------------------------------------------------
@@ -580,7 +588,7 @@ __global__ __launch_bounds__(T) void huff_sync_intra(JS js)
     // every subsequence the candidate state the chain of links passes through -- instead of being speculated here. The
     // flows below then are the reference's, from that table; an entry the chain hopped over (not `known`) starts no
     // flow and stops none: the flow from upstream fills it in.
-    const bool mh = !JS::kSpeculateStateOnly && sp.mh > 1;
+    const bool mh = sp.mh > 1; // set for decodes that ran the three kernels in front of this one (lone decodes)
     LaneState st{};
     BitWindow<GlobalFetch<W>> bw{};
     GlobalFetch<W> fetch{reinterpret_cast<JG_GLOBAL const uint32_t*>(J.destuffed), 0, 0};
@@ -802,6 +810,14 @@ __global__ __launch_bounds__(256) void huff_mh_resolve(JS js)
     if (static_cast<int>(blockIdx.x) >= sp.num_segments) return;
     const Segment seg = ld_global(J.segments + blockIdx.x);
     const int n = seg.subseq_count, base = seg.subseq_offset, S = sp.num_subseq, H = sp.mh;
+    if (n > kMhMaxSegSubseq) { // (only a device-scanned image can get here: the host walk knows its segments) plain speculation
+        for (int r = threadIdx.x; r < n; r += 256) {
+            J.st_p[base + r]     = J.mh_p[base + r];
+            J.st_cz[base + r]    = J.mh_cz[base + r];
+            J.mh_known[base + r] = 1;
+        }
+        return;
+    }
     const int nodes  = H * n;                                               // node (h, r) = h * n + r
     uint32_t* s_link = reinterpret_cast<uint32_t*>(smem);                    // [nodes]
     uint32_t* s_src  = s_link + nodes;                                       // [n]: 1 + pool entry of a subsequence the chain hopped over, 0 none
@@ -1886,11 +1902,9 @@ void extend(JobExtent& e, const ScanJob& job)
     e.max_tail_part   = job.max_tail_part > e.max_tail_part ? job.max_tail_part : e.max_tail_part;
 }
 
-template <int W>
-hipError_t launch_mh_w(const ScanJob& job, int max_seg_subseq, hipStream_t stream)
+template <int W, class JS>
+hipError_t launch_mh_w(const JS& js, const ScanJob& job, int max_seg_subseq, hipStream_t stream)
 {
-    typedef JobByValue JS;
-    const JS js{job};
     const dim3 grid((job.sp.num_subseq + T - 1) / T, job.sp.mh);
     const size_t lds = job.sp.tab_bytes_sync;
     hipError_t err;
@@ -1904,18 +1918,27 @@ hipError_t launch_mh_w(const ScanJob& job, int max_seg_subseq, hipStream_t strea
     return hipGetLastError();
 }
 
-hipError_t launch_mh(const ScanJob& job, int max_seg_subseq, hipStream_t stream)
+template <class JS>
+hipError_t launch_mh_any(const JS& js, const ScanJob& job, int max_seg_subseq, hipStream_t stream)
 {
     if (job.sp.num_subseq == 0 || job.sp.num_segments == 0) return hipSuccess; // an empty share of the segments: nothing to speculate
     if (job.sp.mh < 2 || job.sp.mh > kMhMaxHyp || max_seg_subseq < 1 || max_seg_subseq > kMhMaxSegSubseq) return hipErrorInvalidValue;
     if (job.sp.tab_bytes_sync > kMaxTablePackSync) return hipErrorInvalidValue;
     switch (job.sp.subseq_words) {
-    case 8: return launch_mh_w<8>(job, max_seg_subseq, stream);
-    case 16: return launch_mh_w<16>(job, max_seg_subseq, stream);
-    case 32: return launch_mh_w<32>(job, max_seg_subseq, stream);
-    case 64: return launch_mh_w<64>(job, max_seg_subseq, stream);
+    case 8: return launch_mh_w<8>(js, job, max_seg_subseq, stream);
+    case 16: return launch_mh_w<16>(js, job, max_seg_subseq, stream);
+    case 32: return launch_mh_w<32>(js, job, max_seg_subseq, stream);
+    case 64: return launch_mh_w<64>(js, job, max_seg_subseq, stream);
     }
     return hipErrorInvalidValue;
+}
+
+hipError_t launch_mh(const ScanJob& job, const ScanJob* d_job, int max_seg_subseq, hipStream_t stream)
+{
+    // `job`: the host's copy (sizes: for a device-scanned image the capacities from the header); d_job: where the kernels
+    // read the job from if the device has filled in its counts (jg_front.hip), else null: passed by value
+    if (d_job) return launch_mh_any(JobSingle{d_job}, job, max_seg_subseq, stream);
+    return launch_mh_any(JobByValue{job}, job, max_seg_subseq, stream);
 }
 
 hipError_t launch_stage(Stage stage, const ScanJob& job, hipStream_t stream)

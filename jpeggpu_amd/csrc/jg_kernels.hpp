@@ -40,8 +40,10 @@ void extend(JobExtent& e, const ScanJob& job);
 hipError_t launch_stage(Stage stage, const ScanJob& job, hipStream_t stream);
 
 /// The three kernels of the multi-hypothesis speculation (jg_defs.h) for ONE job with sp.mh > 1, in front of
-/// kStageSyncIntra. `max_seg_subseq`: subsequences of the job's largest restart segment.
-hipError_t launch_mh(const ScanJob& job, int max_seg_subseq, hipStream_t stream);
+/// kStageSyncIntra. `max_seg_subseq`: subsequences of the job's largest restart segment (kMhMaxSegSubseq for a
+/// device-scanned image, whose segments the host does not know: longer ones fall back on the device). `d_job`: the
+/// job's copy in device memory if the device-side front end has filled in its counts, else null.
+hipError_t launch_mh(const ScanJob& job, const ScanJob* d_job, int max_seg_subseq, hipStream_t stream);
 
 /// One stage for `num_jobs` jobs stored in device memory, one per blockIdx.y (the batch API).
 hipError_t launch_stage_batch(

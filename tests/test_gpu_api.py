@@ -687,6 +687,10 @@ def test_bench_multi_rank_control_flow_over_gloo(torch_cuda):
     g = d["gather"]
     assert g["images_per_round"] == 64 or g["images_per_round"] == 16  # 64 // 2 per rank, capped by the batch
     assert g["gathered_buffers_match_senders"] is True and g["value"] > 0
+    # the leg is timed three ways -- decode alone, gather alone, and the pipeline in which the gather of round k runs
+    # beside the decode of round k + 1 (two plane buffers) --, all present and consistent
+    assert g["decode_ms"] > 0 and g["gather_ms"] > 0 and g["overlapped_ms"] > 0
+    assert g["ms_per_round"] == g["overlapped_ms"] and abs(g["value"] - g["images_per_round"] / (g["overlapped_ms"] * 1e-3)) < 1e-6 * g["value"]
     assert d["roofline"]["frac"] > 0
     sh = d["segment_shard"]  # one 39 MP image over the two ranks by restart segments
     assert sh["assembled_equals_whole_decode"] is True and len(sh["rows_of_plane_0_per_rank"]) == 2 and sh["value"] > 0

@@ -238,8 +238,8 @@ def test_subsequence_size_is_chosen_per_image(L, photo_bytes, monkeypatch):
 
 def test_multi_hypothesis_applies_to_lone_decodes_of_interleaved_restart_scans(L, photo_bytes, monkeypatch):
     """jpeggpu_ext_scan_layout.hypotheses (jg_defs.h, multi-hypothesis speculation): one candidate per data unit of the
-    MCU for an image decoded on its own whose scan has restart segments; not for batches, single-unit MCUs, scans
-    without restart markers, device-scanned images, or when the environment switches it off."""
+    MCU for an image decoded on its own whose scan has restart segments (device-scanned or not); not for batches,
+    single-unit MCUs, scans without restart markers, or when the environment switches it off."""
     m = cases.matrix()
 
     def hyp(data, batched=False, device_scan=False):
@@ -253,7 +253,7 @@ def test_multi_hypothesis_applies_to_lone_decodes_of_interleaved_restart_scans(L
         return out
 
     assert hyp(photo_bytes) == [6] and hyp(m["dri_row"]) == [6] and hyp(m["cfg2_small"]) == [6]
-    assert hyp(photo_bytes, batched=True) == [0] and hyp(photo_bytes, device_scan=True) == [0]
+    assert hyp(photo_bytes, batched=True) == [0] and hyp(photo_bytes, device_scan=True) == [6]
     assert hyp(m["multi_seq_nodri"]) == [0] and hyp(m["gray"]) == [0] and hyp(m["cfg5_small"]) == [0]
     assert hyp(m["ni_420_dri"]) == [0, 0, 0]          # one data unit per MCU in every scan
     assert hyp(m["dri_7"]) == [6]

@@ -6,6 +6,7 @@
 # 3. the same of a run whose batched launches are all SERIALIZED (one stream, 64 images per launch: the shape
 #    of bench.py's roofline leg)                                         -> gpurun_out/<round>_stats_serialized/
 # 4. counter passes over the serialized run, one --pmc group per pass     -> gpurun_out/<round>_pmc_<i>/
+# 5. the FETCH_SIZE / WRITE_SIZE calibration of tools/probe/fetch_probe.hip  -> gpurun_out/fetch_calibration.json
 # tools/summarize_profiles.py then writes the summaries into profiles/ (run it here, commit the result).
 set -e
 rnd=$1
@@ -31,3 +32,8 @@ for group in "FETCH_SIZE" "WRITE_SIZE" "SQ_WAVES SQ_INSTS_VALU SQ_INSTS_SALU SQ_
     python3 "$root/tools/pmc_summary.py" "$d" | tee "$d.txt"
     i=$((i + 1))
 done
+/opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 "$root/tools/probe/fetch_probe.hip" -o "$out/fetch_probe"
+rm -rf "$out/fetch_probe_rd" "$out/fetch_probe_wr"
+timeout -k 10 200 rocprofv3 --kernel-trace --pmc FETCH_SIZE -d "$out/fetch_probe_rd" -o p --output-format csv -- "$out/fetch_probe" > "$out/fetch_probe_rd.log" 2>&1
+timeout -k 10 200 rocprofv3 --kernel-trace --pmc WRITE_SIZE -d "$out/fetch_probe_wr" -o p --output-format csv -- "$out/fetch_probe" > "$out/fetch_probe_wr.log" 2>&1
+python3 "$root/tools/probe/fetch_probe_summary.py" "$out/fetch_probe_rd" "$out/fetch_probe_wr" "$out/fetch_calibration.json"

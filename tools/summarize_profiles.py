@@ -4,11 +4,12 @@
   python tools/summarize_profiles.py <round>
 
 HBM traffic per the guide's recipe (/opt/skills/guides/MI355X_MICROARCH.md, "HBM"): FETCH_SIZE and WRITE_SIZE from
-separate --pmc passes, in KiB. On gfx950 FETCH_SIZE counts half of a WIDE COALESCED streaming read (16 B per lane):
-that holds for destuff_kernel, which is the only kernel here that reads that way; the Huffman kernels fetch the
-bitstream in 4-byte refills and the IDCT gathers 4-byte entries, so their raw figure is taken as it is (it matches
-their algorithmic bytes). Both are recorded: per_image_bytes uses the per-kernel rule, per_image_bytes_doubled the
-blanket 2 x FETCH of round 1.
+separate --pmc passes, in KiB. The guide says FETCH_SIZE counts half of a wide coalesced streaming read on gfx950 and
+that every other shape has to be calibrated: tools/probe/fetch_probe.hip does that for the shapes these kernels read
+and write with (16 B per lane; 4 B per lane along the rows of a tile; 2-byte gathers of half sectors; 8-byte records;
+32-byte sector stores; 8-byte pixel rows) and finds FETCH_SIZE = 0.500 x the bytes moved for EVERY read shape and
+WRITE_SIZE = 1.000 x for both store shapes (profiles/<round>_fetch_calibration.json). So every kernel's fetch is
+divided by its shape's factor -- round 2 doubled destuff_kernel's only and took the others raw.
 """
 import collections
 import csv
@@ -20,7 +21,10 @@ import shutil
 import sys
 
 KERNELS = r"(destuff_kernel|huff_sync_intra|huff_sync_tail|huff_seq_tails|huff_write|idct_kernel)"
-WIDE_READERS = {"destuff_kernel"}
+# the read / write shape of each kernel in tools/probe/fetch_probe.hip's terms
+READ_SHAPE = {"destuff_kernel": "rd_wide16", "huff_sync_intra": "rd_dword_rows", "huff_sync_tail": "rd_dword_rows",
+              "huff_seq_tails": "rd_dword_rows", "huff_write": "rd_dword_rows", "idct_kernel": "rd_u16_units"}
+WRITE_SHAPE = {"huff_write": "wr_sector32", "idct_kernel": "wr_row8"}
 IMAGES_PER_LAUNCH = 64
 
 
@@ -56,14 +60,24 @@ def main():
         t = d + ".txt"
         if os.path.exists(t):
             shutil.copy(t, os.path.join(prof, "%s_pmc_pass_%d.txt" % (rnd, i)))
+    calib = {}
+    cal_src = os.path.join(go, "fetch_calibration.json")
+    if os.path.exists(cal_src):
+        shutil.copy(cal_src, os.path.join(prof, "%s_fetch_calibration.json" % rnd))
+    cal_path = os.path.join(prof, "%s_fetch_calibration.json" % rnd)
+    if os.path.exists(cal_path):
+        calib = json.load(open(cal_path))
     traffic, total = {}, 0.0
     for name, v in sorted(merged.items()):
         fetch, write = v.get("FETCH_SIZE", 0.0), v.get("WRITE_SIZE", 0.0)
-        mult = 2 if name in WIDE_READERS else 1
-        per = (mult * fetch + write) * 1024 / IMAGES_PER_LAUNCH
+        rf = calib.get(READ_SHAPE.get(name, "rd_dword_rows"), {}).get("counter_over_known", 0.5)
+        wf = calib.get(WRITE_SHAPE.get(name, "wr_sector32"), {}).get("counter_over_known", 1.0)
+        mult = 1.0 / rf
+        per = (fetch / rf + write / wf) * 1024 / IMAGES_PER_LAUNCH
         total += per
-        traffic[name] = {"per_image_bytes": per, "per_image_bytes_doubled": (2 * fetch + write) * 1024 / IMAGES_PER_LAUNCH,
+        traffic[name] = {"per_image_bytes": per, "per_image_bytes_raw": (fetch + write) * 1024 / IMAGES_PER_LAUNCH,
                          "fetch_kib_per_launch_raw": fetch, "write_kib_per_launch": write, "fetch_multiplier": mult,
+                         "read_shape": READ_SHAPE.get(name), "write_shape": WRITE_SHAPE.get(name),
                          "images_per_launch": IMAGES_PER_LAUNCH,
                          "valu_insts_per_image": v.get("SQ_INSTS_VALU", 0.0) / IMAGES_PER_LAUNCH,
                          "command": "tools/collect_profiles.sh %s (serialized run: one stream, 64 images per launch)" % rnd}
@@ -73,6 +87,7 @@ def main():
     json.dump(traffic, open(os.path.join(prof, "pmc_traffic.json"), "w"), indent=1)
     json.dump(traffic, open(os.path.join(prof, "%s_pmc_traffic_batch64.json" % rnd), "w"), indent=1)
     json.dump({k: v for k, v in sorted(merged.items())}, open(os.path.join(prof, "%s_pmc_counters_batch64.json" % rnd), "w"), indent=1)
+    json.dump({k: v for k, v in sorted(merged.items())}, open(os.path.join(prof, "pmc_counters.json"), "w"), indent=1)  # bench.py reads this one
 
 
 if __name__ == "__main__":
