@@ -528,12 +528,16 @@ jpeggpu_status do_decode(Decoder& d, jpeggpu_img* img, void* d_tmp, size_t tmp_s
         d.logger.log(
             "scan %d: %d chunks, %d subsequences of %d bytes, %d sequences, %d segments\n",
             static_cast<int>(i), job.num_chunks, job.sp.num_subseq, d.subseq_bytes, job.num_seq, job.sp.num_segments);
-        for (int stage = 0; stage < kNumStages; ++stage) {
+    }
+    // every stage once, for all scans of the image at a time (they are independent: grid.y = scan)
+    for (int stage = 0; stage < kNumStages; ++stage) {
+        if (stage == kStageSyncIntra) {
             // multi-hypothesis speculation in front of the sequence kernel, which then starts from its table
-            if (stage == kStageSyncIntra && job.sp.mh > 1) JG_CHECK_HIP(launch_mh(job, nullptr, d.plan.scan[i].max_seg_subseq, stream));
-            JG_CHECK_HIP(launch_stage(static_cast<Stage>(stage), job, stream));
-            d.mark(stage, stream);
+            for (size_t i = 0; i < d.jobs.size(); ++i)
+                if (d.jobs[i].sp.mh > 1) JG_CHECK_HIP(launch_mh(d.jobs[i], nullptr, d.plan.scan[i].max_seg_subseq, stream));
         }
+        JG_CHECK_HIP(launch_stage_scans(static_cast<Stage>(stage), d.jobs.data(), static_cast<int>(d.jobs.size()), stream));
+        d.mark(stage, stream);
     }
     return JPEGGPU_SUCCESS;
 }

@@ -39,6 +39,9 @@ void extend(JobExtent& e, const ScanJob& job);
 /// One stage for ONE job passed by value as a kernel argument (the drop-in single-image API).
 hipError_t launch_stage(Stage stage, const ScanJob& job, hipStream_t stream);
 
+/// One stage for ALL scans of one image (1..kMaxScans jobs, by value, one per blockIdx.y; the same subsequence size).
+hipError_t launch_stage_scans(Stage stage, const ScanJob* jobs, int num_jobs, hipStream_t stream);
+
 /// The three kernels of the multi-hypothesis speculation (jg_defs.h) for ONE job with sp.mh > 1, in front of
 /// kStageSyncIntra. `max_seg_subseq`: subsequences of the job's largest restart segment (kMhMaxSegSubseq for a
 /// device-scanned image, whose segments the host does not know: longer ones fall back on the device). `d_job`: the
