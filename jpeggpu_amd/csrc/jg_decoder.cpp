@@ -500,7 +500,7 @@ jpeggpu_status do_decode(Decoder& d, jpeggpu_img* img, void* d_tmp, size_t tmp_s
     d.mark(-1, stream);
     if (d.reader.s.scans[0].device_walk) {
         // Device-side front end: the job lives in device memory, front_plan fills in its counts, and the
-        // stages run as a one-job batch with launch extents from the header's upper bounds.
+        // stages read it from there, with launch extents from the header's upper bounds.
         ScanJob* d_job = reinterpret_cast<ScanJob*>(static_cast<uint8_t*>(d_tmp) + d.plan.scan[0].d_job);
         const FrontParams P = front_params(d, d_tmp, d_job);
         // the job travels as a kernel argument of the first front-end kernel, which stores it to d_job
@@ -509,7 +509,7 @@ jpeggpu_status do_decode(Decoder& d, jpeggpu_img* img, void* d_tmp, size_t tmp_s
         extend(extent, d.jobs[0]);
         for (int stage = 0; stage < kNumStages; ++stage) {
             if (stage == kStageSyncIntra && d.jobs[0].sp.mh > 1) JG_CHECK_HIP(launch_mh(d.jobs[0], d_job, d.plan.scan[0].max_seg_subseq, stream));
-            JG_CHECK_HIP(launch_stage_batch(static_cast<Stage>(stage), d_job, 1, extent, stream));
+            JG_CHECK_HIP(launch_stage_device_job(static_cast<Stage>(stage), d_job, extent, stream));
             d.mark(stage, stream);
         }
         if (d.device_scan == 2) {

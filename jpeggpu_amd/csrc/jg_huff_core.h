@@ -420,7 +420,8 @@ JG_HD inline void decode_units(
     const ScanParams& sp,
     Sink& sink,
     int max_iters,
-    int* iters_out = nullptr) // probe builds: iterations this lane stayed in the loop
+    int* iters_out = nullptr) // probe builds: [0] iterations the lane's wave stayed in the loop, [1] symbols the lane decoded,
+                              // [2] times the wave took the rare block, [3] times this lane was a reason for it
 {
 #if defined(__HIP_DEVICE_COMPILE__)
     typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
@@ -452,8 +453,9 @@ JG_HD inline void decode_units(
     uint32_t dc01 = st.dc01, dc23 = st.dc23; // predictors: running sums of the DC differences, per component
     w.seek(st.p);
     int flush_in = Sink::kFlushPeriod; // iterations to the sink's next flush point
+    int flush_no = 0;                  // how many there have been
     for (int it = 0; it < max_iters; ++it) {
-        if (iters_out) *iters_out = it + 1;
+        if (iters_out) iters_out[0] = it + 1;
         w.top(); // refill where the window ran out (at most 32 bits are consumed between two looks)
         if ((it & (kWriteDcPeriod - 1)) == 0) { // DC slot: the same iterations for every lane of a wave
             if (static_cast<uint32_t>(zm - 63) < static_cast<uint32_t>(kStopped - 63) && w.left() >= 0) {
@@ -480,6 +482,7 @@ JG_HD inline void decode_units(
                     actab      = JG_CUR_TABS >> 16;
                     unit_entry = JG_CUR_NEXT;
                     zm         = 0;
+                    if (iters_out) ++iters_out[1];
                 }
             }
             if (!JG_WAVE_ANY(zm != kStopped)) break;
@@ -495,6 +498,7 @@ JG_HD inline void decode_units(
         const int idle   = (62 - zm) | w.left() | (len0 - 1);
         const uint32_t e = idle < 0 ? 0u : e0;
         const int total  = e & 31;
+        if (iters_out && e != 0) ++iters_out[1];
         w.skip(total);
         const int s = (e >> 5) & 15;
         zm += static_cast<int>(e >> 9); // index of the symbol's coefficient; 63 or more: the unit is complete
@@ -502,10 +506,15 @@ JG_HD inline void decode_units(
         sink.ac(s, zm, v);
         // one test for everything rare, as the sign of one OR (a single compare feeds the wave-wide branch)
         if (JG_WAVE_ANY(((len0 - 1) | (kEscapeFromCategory - 1 - s) | w.crossed()) < 0)) {
+            if (iters_out) {
+                ++iters_out[2];
+                if (((len0 - 1) | (kEscapeFromCategory - 1 - s) | w.crossed()) < 0) ++iters_out[3];
+            }
             if (w.crossed() < 0) w.cross();
             if (len0 == 0 && ((62 - zm) | w.left()) >= 0) { // zm and the window are what they were: the null entry changed nothing
                 const uint32_t e2 = huff_second_level(tab, e0, peek, false);
                 const int total2  = e2 & 31;
+                if (iters_out) ++iters_out[1];
                 w.skip(total2);
                 const int s2 = (e2 >> 5) & 15;
                 zm += static_cast<int>(e2 >> 9);
@@ -518,7 +527,7 @@ JG_HD inline void decode_units(
         }
         if (--flush_in == 0) { // the same iteration for every lane of the wave
             flush_in = Sink::kFlushPeriod;
-            sink.flush_point();
+            sink.flush_point(flush_no++);
         }
     }
     w.done();

@@ -132,8 +132,8 @@ struct JobArray {
 };
 
 struct JobSingle {
-    // One job that lives in device memory, whatever blockIdx.y is (the multi-hypothesis kernels of a device-scanned
-    // image: their grid's second dimension is the hypothesis).
+    // One job that lives in device memory, whatever blockIdx.y is: the lone decode of a device-scanned image (the
+    // second dimension of the multi-hypothesis kernels' grid is the hypothesis).
     static constexpr bool kSpeculateStateOnly = false;
     const ScanJob* job;
     __device__ __forceinline__ const ScanJob& get() const { return *job; }
@@ -502,6 +502,10 @@ struct RowWindow {
 __device__ uint32_t g_probe[4096 * 64];
 // huff_write: [0] sum over lanes of loop iterations (low 32 bits), [1] high bits, [2] largest, [3] lanes (tools/probe/write_iters.py)
 __device__ unsigned long long g_probe_write[4];
+// huff_write, the launch's first job, by subsequence: loop iterations of the lane's wave, then (from 1 << 16) symbols the
+// lane decoded (tools/probe/write_lane_iters.py)
+__device__ uint16_t g_probe_lane_iters[1 << 17];
+__device__ uint32_t g_probe_lane_rare[1 << 15]; // times the lane's wave took the rare block | times the lane asked for it << 16
 #define JG_STAMP(i)                                                                                       \
     do {                                                                                                  \
         if (threadIdx.x == 0 && blockIdx.x < 4096 && (i) < 64) g_probe[blockIdx.x * 64 + (i)] = static_cast<uint32_t>(wall_clock64()); \
@@ -1110,6 +1114,12 @@ constexpr int kRingStride   = (kRingWords + 1) * 4;       // bytes from one lane
 constexpr int kStageEntries = 2 * kRingWords;             // entries the ring holds (a power of two)
 constexpr int kFlushEntries = kSymSectorEntries;          // entries per flush: 16 = one 32-byte sector
 constexpr int kWriteFlushPeriod = 6;                      // iterations between two flush points
+#ifndef JG_UNIT_TURN
+#define JG_UNIT_TURN 2
+#endif
+constexpr int kUnitTurn = JG_UNIT_TURN;                   // flush points between two stores of data-unit records (a power of two)
+// A DC slot adds at most one waiting record, a turn leaves at most three, StreamSink holds eight.
+static_assert(3 + kUnitTurn * ((kWriteFlushPeriod + kWriteDcPeriod - 1) / kWriteDcPeriod) <= 8, "waiting unit records would overflow");
 
 /// Sink of the write pass: a compact symbol stream instead of a dense coefficient buffer (jg_defs.h). Every lane
 /// appends 16-bit entries to its own region, contiguous per data unit, and records {first entry, count} per
@@ -1162,8 +1172,8 @@ struct StreamSink {
         *reinterpret_cast<LdsHalf*>(static_cast<uintptr_t>(a)) = static_cast<uint16_t>(entry);
     }
     /// DC slot, a lane at the start of a data unit: the unit it finished since the previous slot (if it has started
-    /// one) is complete -- its entry count joins the waiting records at the top. At most one per slot; a flush point
-    /// every six iterations leaves at most three waiting: eight places are enough.
+    /// one) is complete -- its entry count joins the waiting records at the top. At most one per slot, two between
+    /// flush points; every kUnitTurn-th flush point leaves at most three waiting: eight places are enough.
     __device__ __forceinline__ void unit_boundary()
     {
         if (started) {
@@ -1251,11 +1261,13 @@ struct StreamSink {
         }
         flushed += kFlushEntries;
     }
-    /// Every kFlushPeriod-th iteration, the same one for every lane of the wave.
-    __device__ __forceinline__ void flush_point()
+    /// Every kFlushPeriod-th iteration, the same one for every lane of the wave; `no` counts them. The unit records
+    /// take every kUnitTurn-th: in a wave of 64 some lane has four waiting at nearly every flush point, and what the
+    /// wave pays is how often it enters that code, not how many lanes store there.
+    __device__ __forceinline__ void flush_point(int no)
     {
         if (started && emitted - flushed >= static_cast<uint32_t>(kFlushEntries)) flush_sector();
-        flush_units();
+        if ((no & (kUnitTurn - 1)) == 0) flush_units();
     }
     /// After the loop: everything that is left, rounded up to whole sectors (the entries behind the
     /// last valid one are never read: the data-unit table bounds every gather).
@@ -1422,11 +1434,16 @@ __global__ __launch_bounds__(T) void huff_write(JS js)
     // a valid stream takes less than one iteration per bit of the subsequence and of the unit the lane runs on into
     constexpr int kMaxIters = 2 * (W * 32 + 64 * 32);
 #if defined(JG_PROBE)
-    int iters = 0;
-    decode_units(st, words, s_tab, sp, sink, kMaxIters, &iters);
-    atomicAdd(&g_probe_write[0], static_cast<unsigned long long>(iters));
-    atomicMax(&g_probe_write[2], static_cast<unsigned long long>(iters));
+    int iters[4] = {0, 0, 0, 0};
+    decode_units(st, words, s_tab, sp, sink, kMaxIters, iters);
+    atomicAdd(&g_probe_write[0], static_cast<unsigned long long>(iters[0]));
+    atomicMax(&g_probe_write[2], static_cast<unsigned long long>(iters[0]));
     atomicAdd(&g_probe_write[3], 1ull);
+    if (blockIdx.y == 0 && sub < (1 << 16)) {
+        g_probe_lane_iters[sub]             = static_cast<uint16_t>(iters[0]);
+        g_probe_lane_iters[(1 << 16) + sub] = static_cast<uint16_t>(iters[1]);
+        if (sub < (1 << 15)) g_probe_lane_rare[sub] = static_cast<uint32_t>(iters[2]) | static_cast<uint32_t>(iters[3]) << 16;
+    }
 #else
     decode_units(st, words, s_tab, sp, sink, kMaxIters);
 #endif
@@ -1884,6 +1901,16 @@ extern "C" __attribute__((visibility("default"))) int jpeggpu_probe_read_write(u
     return 0;
 }
 
+extern "C" __attribute__((visibility("default"))) int jpeggpu_probe_read_lane_iters(uint16_t* dst, size_t count)
+{
+    return hipMemcpyFromSymbol(dst, HIP_SYMBOL(g_probe_lane_iters), count * 2) == hipSuccess ? 0 : 1;
+}
+
+extern "C" __attribute__((visibility("default"))) int jpeggpu_probe_read_lane_rare(uint32_t* dst, size_t count)
+{
+    return hipMemcpyFromSymbol(dst, HIP_SYMBOL(g_probe_lane_rare), count * 4) == hipSuccess ? 0 : 1;
+}
+
 extern "C" __attribute__((visibility("default"))) int jpeggpu_probe_read(void* dst, size_t bytes, int clear)
 {
     if (hipMemcpyFromSymbol(dst, HIP_SYMBOL(g_probe), bytes) != hipSuccess) return 1;
@@ -1967,6 +1994,11 @@ hipError_t launch_stage_scans(Stage stage, const ScanJob* jobs, int num_jobs, hi
         extend(e, jobs[i]);
     }
     return launch_any(stage, js, e, num_jobs, stream);
+}
+
+hipError_t launch_stage_device_job(Stage stage, const ScanJob* d_job, const JobExtent& extent, hipStream_t stream)
+{
+    return launch_any(stage, JobSingle{d_job}, extent, 1, stream);
 }
 
 hipError_t launch_stage_batch(

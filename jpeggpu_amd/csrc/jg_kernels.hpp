@@ -48,6 +48,10 @@ hipError_t launch_stage_scans(Stage stage, const ScanJob* jobs, int num_jobs, hi
 /// job's copy in device memory if the device-side front end has filled in its counts, else null.
 hipError_t launch_mh(const ScanJob& job, const ScanJob* d_job, int max_seg_subseq, hipStream_t stream);
 
+/// One stage for ONE job stored in device memory (the lone decode of a device-scanned image: the device-side front end
+/// has filled in its counts; `extent` holds the header's upper bounds), with the kernels' lone-decode variants.
+hipError_t launch_stage_device_job(Stage stage, const ScanJob* d_job, const JobExtent& extent, hipStream_t stream);
+
 /// One stage for `num_jobs` jobs stored in device memory, one per blockIdx.y (the batch API).
 hipError_t launch_stage_batch(
     Stage stage, const ScanJob* d_jobs, int num_jobs, const JobExtent& extent, hipStream_t stream);

@@ -105,7 +105,7 @@ struct HostSink {
         unit_esc = kUnitHasEscape;
     }
     static constexpr int kFlushPeriod = 6;
-    void flush_point() {}
+    void flush_point(int) {}
 };
 
 struct St {
