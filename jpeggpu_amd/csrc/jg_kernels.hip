@@ -506,12 +506,20 @@ __device__ unsigned long long g_probe_write[4];
 // lane decoded (tools/probe/write_lane_iters.py)
 __device__ uint16_t g_probe_lane_iters[1 << 17];
 __device__ uint32_t g_probe_lane_rare[1 << 15]; // times the lane's wave took the rare block | times the lane asked for it << 16
+// huff_sync_tail, jobs 0..15 x parts 0..7 of a launch: 100 MHz stamps [0] start, [1] flow list built, [2 + k] after
+// trip k of the flow loop (all groups), [63] = flows | trips << 16 (tools/probe/tail_stamps.py)
+__device__ uint32_t g_probe_tail[128 * 64];
+#define JG_TAIL_STAMP(i, v)                                                                               \
+    do {                                                                                                  \
+        if (threadIdx.x == 0 && blockIdx.y < 16 && blockIdx.x < 8 && (i) < 64) g_probe_tail[(blockIdx.y * 8 + blockIdx.x) * 64 + (i)] = (v); \
+    } while (0)
 #define JG_STAMP(i)                                                                                       \
     do {                                                                                                  \
         if (threadIdx.x == 0 && blockIdx.x < 4096 && (i) < 64) g_probe[blockIdx.x * 64 + (i)] = static_cast<uint32_t>(wall_clock64()); \
     } while (0)
 #else
 #define JG_STAMP(i) do { } while (0)
+#define JG_TAIL_STAMP(i, v) do { } while (0)
 #endif
 
 /// LDS address of a pointer into the workgroup's shared memory.
@@ -986,6 +994,7 @@ __global__ __launch_bounds__(TL) void huff_sync_tail(JS js)
     const int lo           = J.tail_parts[blockIdx.x];
     const int hi           = J.tail_parts[blockIdx.x + 1];
     const int tid          = threadIdx.x;
+    JG_TAIL_STAMP(0, static_cast<uint32_t>(wall_clock64()));
     load_tables(s_tab, J.tables_sync, sp);
 
     // ordered list of flow origins in [lo, hi)
@@ -999,6 +1008,8 @@ __global__ __launch_bounds__(TL) void huff_sync_tail(JS js)
         count += total;
     }
     __syncthreads(); // list and tables visible to the whole workgroup
+    JG_TAIL_STAMP(1, static_cast<uint32_t>(wall_clock64()));
+    [[maybe_unused]] int trips = 0;
 
     NoSink sink;
     for (int g = 0; g < count; g += TL) {
@@ -1042,6 +1053,8 @@ __global__ __launch_bounds__(TL) void huff_sync_tail(JS js)
             // that makes this iteration's state stores visible to the next one)
             int rank;
             const int total = block_rank<TL>(flowing, s_wave, rank);
+            JG_TAIL_STAMP(2 + trips, static_cast<uint32_t>(wall_clock64()));
+            ++trips;
             if (total == 0) break;
             if (flowing) {
                 s_j[rank]  = j;
@@ -1058,6 +1071,7 @@ __global__ __launch_bounds__(TL) void huff_sync_tail(JS js)
         }
         __syncthreads();
     }
+    JG_TAIL_STAMP(63, static_cast<uint32_t>(count) | static_cast<uint32_t>(trips) << 16);
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -1909,6 +1923,11 @@ extern "C" __attribute__((visibility("default"))) int jpeggpu_probe_read_lane_it
 extern "C" __attribute__((visibility("default"))) int jpeggpu_probe_read_lane_rare(uint32_t* dst, size_t count)
 {
     return hipMemcpyFromSymbol(dst, HIP_SYMBOL(g_probe_lane_rare), count * 4) == hipSuccess ? 0 : 1;
+}
+
+extern "C" __attribute__((visibility("default"))) int jpeggpu_probe_read_tail(uint32_t* dst, size_t count)
+{
+    return hipMemcpyFromSymbol(dst, HIP_SYMBOL(g_probe_tail), count * 4) == hipSuccess ? 0 : 1;
 }
 
 extern "C" __attribute__((visibility("default"))) int jpeggpu_probe_read(void* dst, size_t bytes, int clear)
