@@ -283,7 +283,10 @@ struct ScanParams {
 ///   kMhNoPool when the pool was full); mh_known[sub]: the table entry of sub is a state of the chain (an entry the
 ///   chain hopped over without pool entries is filled by the flow from upstream).
 constexpr int kMhMaxHyp        = 8;    // 4-bit candidate index; more data units per MCU: plain speculation
-constexpr int kMhSteps         = 8;    // subsequences a candidate's flow runs before it gives up
+#ifndef JG_MH_STEPS
+#define JG_MH_STEPS 8
+#endif
+constexpr int kMhSteps         = JG_MH_STEPS; // subsequences a candidate's flow runs before it gives up
 constexpr int kMhMaxSegSubseq  = 1024; // the chain walk of a segment happens in LDS
 constexpr uint32_t kMhNoLink   = 0;
 constexpr uint32_t kMhNoPool   = 0xFFFFFFu; // 24-bit pool index
