@@ -1127,9 +1127,16 @@ constexpr int kRingWords    = 16;                         // 32-bit words of a l
 constexpr int kRingStride   = (kRingWords + 1) * 4;       // bytes from one lane's ring to the next: 17 words, an odd number of banks
 constexpr int kStageEntries = 2 * kRingWords;             // entries the ring holds (a power of two)
 constexpr int kFlushEntries = kSymSectorEntries;          // entries per flush: 16 = one 32-byte sector
-constexpr int kWriteFlushPeriod = 6;                      // iterations between two flush points
+#ifndef JG_WRITE_FLUSH_PERIOD
+#define JG_WRITE_FLUSH_PERIOD 12
+#endif
+constexpr int kWriteFlushPeriod = JG_WRITE_FLUSH_PERIOD;  // iterations between two flush points
+// what a flush point leaves behind (less than a sector) + what arrives until the next one (one entry per iteration and
+// one per DC slot; an ESCAPE entry, which no photograph has, flushes for itself when a sector is waiting: one more)
+// must fit the ring
+static_assert(kFlushEntries - 1 + kWriteFlushPeriod + (kWriteFlushPeriod + kWriteDcPeriod - 1) / kWriteDcPeriod + 1 <= kStageEntries, "the write-combining ring would overflow");
 #ifndef JG_UNIT_TURN
-#define JG_UNIT_TURN 2
+#define JG_UNIT_TURN 1
 #endif
 constexpr int kUnitTurn = JG_UNIT_TURN;                   // flush points between two stores of data-unit records (a power of two)
 // A DC slot adds at most one waiting record, a turn leaves at most three, StreamSink holds eight.
@@ -1143,10 +1150,12 @@ static_assert(3 + kUnitTurn * ((kWriteFlushPeriod + kWriteDcPeriod - 1) / kWrite
 ///
 /// A lane's appends must not go to memory one by one: with many images in flight the ~200 k open lines do not fit
 /// in L2 and every append becomes its own 32-byte sector write. Entries are therefore collected in a ring per lane
-/// in LDS (32 entries = 64 bytes, rings 17 words apart: the lanes of a wave hit different banks) and every 6
-/// iterations ALL lanes that have 16 or more waiting flush one whole 32-byte sector: an iteration adds at most two
-/// entries from its AC section (a coefficient and its escape) and every fourth one more from its DC slot, so at most
-/// 15 stay behind and at most 14 arrive in between.
+/// in LDS (32 entries = 64 bytes, rings 17 words apart: the lanes of a wave hit different banks) and every 12
+/// iterations ALL lanes that have 16 or more waiting flush one whole 32-byte sector: an iteration adds one entry from
+/// its AC section and every fourth one more from its DC slot, so at most 15 stay behind and at most 15 arrive in
+/// between (an escape entry, the second of its iteration, flushes for itself if a sector is waiting). The period is as
+/// long as the ring allows: in a wave of 64 some lane has a sector waiting at every flush point, and what the wave
+/// pays is how often it enters that code (4 / 6 / 7 / 8 / 10 / 12 iterations: 800 / 791 / 790 / 780 / 785 / 770 µs).
 ///
 /// The kernel is bound by vector-instruction issue, so the per-symbol part is counted in instructions: an AC symbol
 /// is one ring store and an add-with-carry (zero coefficients, and everything a lane decodes before its first DC
@@ -1186,7 +1195,7 @@ struct StreamSink {
         *reinterpret_cast<LdsHalf*>(static_cast<uintptr_t>(a)) = static_cast<uint16_t>(entry);
     }
     /// DC slot, a lane at the start of a data unit: the unit it finished since the previous slot (if it has started
-    /// one) is complete -- its entry count joins the waiting records at the top. At most one per slot, two between
+    /// one) is complete -- its entry count joins the waiting records at the top. At most one per slot, three between
     /// flush points; every kUnitTurn-th flush point leaves at most three waiting: eight places are enough.
     __device__ __forceinline__ void unit_boundary()
     {
@@ -1220,6 +1229,8 @@ struct StreamSink {
         put(emitted, sym_entry_escape(value));
         ++emitted;
         du_off -= ((emitted - du_off) & kUnitHasEscape) ? 0u : kUnitHasEscape; // once per unit (a unit has at most 127 entries)
+        // the flush points are spaced for one entry per iteration: this second one makes room for itself
+        if (started && emitted - flushed >= static_cast<uint32_t>(kFlushEntries)) flush_sector();
     }
     /// Store the first `n` waiting records (1..4).
     __device__ __forceinline__ void store_units(int n)
@@ -1276,8 +1287,7 @@ struct StreamSink {
         flushed += kFlushEntries;
     }
     /// Every kFlushPeriod-th iteration, the same one for every lane of the wave; `no` counts them. The unit records
-    /// take every kUnitTurn-th: in a wave of 64 some lane has four waiting at nearly every flush point, and what the
-    /// wave pays is how often it enters that code, not how many lanes store there.
+    /// take every kUnitTurn-th.
     __device__ __forceinline__ void flush_point(int no)
     {
         if (started && emitted - flushed >= static_cast<uint32_t>(kFlushEntries)) flush_sector();

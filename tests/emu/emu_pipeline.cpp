@@ -104,7 +104,7 @@ struct HostSink {
         if (cur < cur_end) sym[cur++] = static_cast<uint16_t>(sym_entry_escape(value));
         unit_esc = kUnitHasEscape;
     }
-    static constexpr int kFlushPeriod = 6;
+    static constexpr int kFlushPeriod = 12;
     void flush_point(int) {}
 };
 
