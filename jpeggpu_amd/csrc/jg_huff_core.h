@@ -339,6 +339,11 @@ JG_HD inline void decode_subsequence(
 #define JG_WRITE_DC_PERIOD 4
 #endif
 constexpr int kWriteDcPeriod = JG_WRITE_DC_PERIOD; // a power of two
+/// ... and between two RARE SLOTS.
+#ifndef JG_WRITE_RARE_PERIOD
+#define JG_WRITE_RARE_PERIOD 8
+#endif
+constexpr int kWriteRarePeriod = JG_WRITE_RARE_PERIOD; // a power of two
 
 JG_HD inline uint32_t bit_mask(int s)
 {
@@ -397,8 +402,11 @@ JG_HD inline int extend_bits(uint32_t bits, int s)
 ///   * The AC step of every iteration has no per-lane branch at all: the window refill is three selects, the reload
 ///     of the prefetched word an exec-masked load, the entry is nulled by one select on the sign of an OR of the
 ///     three reasons a lane may not step (outside a unit, window not yet refilled, entry without a length).
-///   * Everything rare -- second-level look-up / long code, escape entry of a coefficient of category >= 10, the
-///     window leaving its row -- sits behind ONE wave-uniform test per iteration.
+///   * Everything rare -- second-level look-up / long code, a coefficient of category >= 10 with its escape entry, the
+///     window leaving its row -- WAITS for a rare slot, every kWriteRarePeriod-th iteration, and only there the wave
+///     asks whether any lane has such a thing. A lane meets one less than three times per 256-byte subsequence, so the
+///     waiting is cheap (3.5 iterations each); asked in every iteration the wave found some lane's in 27 % of them and
+///     ran the block's ~40 instructions (tools/probe/write_lane_iters.py).
 ///   * Every kWriteDcPeriod-th iteration has a DC SLOT: the lanes that stand at the start of a data unit close the
 ///     record of the unit they finished, test the stop rule, load the next unit's cursor entry (tables, component),
 ///     decode the DC symbol and add it to the component's predictor. A lane that reaches a unit's end between two
@@ -458,7 +466,9 @@ JG_HD inline void decode_units(
         if (iters_out) iters_out[0] = it + 1;
         w.top(); // refill where the window ran out (at most 32 bits are consumed between two looks)
         if ((it & (kWriteDcPeriod - 1)) == 0) { // DC slot: the same iterations for every lane of a wave
-            if (static_cast<uint32_t>(zm - 63) < static_cast<uint32_t>(kStopped - 63) && w.left() >= 0) {
+            // (a lane whose window is about to leave its row first waits for the rare slot: the DC symbol may empty the
+            // window, and the refill behind it would step out of the row)
+            if (static_cast<uint32_t>(zm - 63) < static_cast<uint32_t>(kStopped - 63) && (w.left() | w.crossed()) >= 0) {
                 sink.unit_boundary(); // the unit the lane finished since the last slot, if any, is complete
                 if (sink.full()) {
                     zm = kStopped; // the next unit is the next lane's, or lies past the segment
@@ -492,11 +502,14 @@ JG_HD inline void decode_units(
         const TabPtr tab    = JG_TAB_AT(tabs, actab);
         const uint32_t e0   = lut16_entry<kLutBitsAc>(tab, peek);
         const int len0      = e0 & 31;
-        // no step for a lane outside a unit (zm >= 63), with a window that ran out (the DC symbol just emptied it, or
-        // its refill has to wait an iteration), or with an entry without a length (the rare block below takes that
-        // step): the sign of one OR says so
-        const int idle   = (62 - zm) | w.left() | (len0 - 1);
-        const uint32_t e = idle < 0 ? 0u : e0;
+        const int cat0      = (e0 >> 5) & 15;
+        // No step for a lane outside a unit (zm >= 63) or with a window that ran out (the DC symbol just emptied it, or
+        // its refill has to wait an iteration): `ready`. None here for a symbol that is `slow` -- an entry without a
+        // length, a category with an escape entry, a window about to leave its row: the lane waits for the rare slot.
+        // The sign of one OR says so.
+        const int ready  = (62 - zm) | w.left();
+        const int slow   = (len0 - 1) | (kEscapeFromCategory - 1 - cat0) | w.crossed();
+        const uint32_t e = (ready | slow) < 0 ? 0u : e0;
         const int total  = e & 31;
         if (iters_out && e != 0) ++iters_out[1];
         w.skip(total);
@@ -504,25 +517,26 @@ JG_HD inline void decode_units(
         zm += static_cast<int>(e >> 9); // index of the symbol's coefficient; 63 or more: the unit is complete
         const int v = extend_bits(bits_field(peek, total, s), s);
         sink.ac(s, zm, v);
-        // one test for everything rare, as the sign of one OR (a single compare feeds the wave-wide branch)
-        if (JG_WAVE_ANY(((len0 - 1) | (kEscapeFromCategory - 1 - s) | w.crossed()) < 0)) {
-            if (iters_out) {
-                ++iters_out[2];
-                if (((len0 - 1) | (kEscapeFromCategory - 1 - s) | w.crossed()) < 0) ++iters_out[3];
-            }
-            if (w.crossed() < 0) w.cross();
-            if (len0 == 0 && ((62 - zm) | w.left()) >= 0) { // zm and the window are what they were: the null entry changed nothing
-                const uint32_t e2 = huff_second_level(tab, e0, peek, false);
-                const int total2  = e2 & 31;
-                if (iters_out) ++iters_out[1];
-                w.skip(total2);
-                const int s2 = (e2 >> 5) & 15;
-                zm += static_cast<int>(e2 >> 9);
-                const int v2 = extend_bits(bits_field(peek, total2, s2), s2);
-                sink.ac(s2, zm, v2);
-                if (s2 >= kEscapeFromCategory) sink.escape(v2);
-            } else if (s >= kEscapeFromCategory) {
-                sink.escape(v);
+        if ((it & (kWriteRarePeriod - 1)) == kWriteRarePeriod - 1) { // rare slot: the same iterations for every lane of a wave
+            // (zm and the window of a lane that waited are what they were: the null entry changed nothing)
+            const bool symbol = ready >= 0 && ((len0 - 1) | (kEscapeFromCategory - 1 - cat0)) < 0;
+            if (JG_WAVE_ANY(symbol || w.crossed() < 0)) {
+                if (iters_out) {
+                    ++iters_out[2];
+                    if (symbol || w.crossed() < 0) ++iters_out[3];
+                }
+                if (w.crossed() < 0) w.cross(); // the symbol in the window, if it was only this, goes with the next iteration
+                if (symbol) {
+                    const uint32_t e2 = len0 == 0 ? huff_second_level(tab, e0, peek, false) : e0;
+                    const int total2  = e2 & 31;
+                    if (iters_out) ++iters_out[1];
+                    w.skip(total2);
+                    const int s2 = (e2 >> 5) & 15;
+                    zm += static_cast<int>(e2 >> 9);
+                    const int v2 = extend_bits(bits_field(peek, total2, s2), s2);
+                    sink.ac(s2, zm, v2);
+                    if (s2 >= kEscapeFromCategory) sink.escape(v2);
+                }
             }
         }
         if (--flush_in == 0) { // the same iteration for every lane of the wave
