@@ -401,7 +401,7 @@ JG_HD inline int extend_bits(uint32_t bits, int s)
 ///     which changes nothing; the wave leaves when every lane has stopped.
 ///   * The AC step of every iteration has no per-lane branch at all: the window refill is three selects, the reload
 ///     of the prefetched word an exec-masked load, the entry is nulled by one select on the sign of an OR of the
-///     three reasons a lane may not step (outside a unit, window not yet refilled, entry without a length).
+///     reasons a lane may not step (outside a unit, window not yet refilled, a symbol for the rare slot).
 ///   * Everything rare -- second-level look-up / long code, a coefficient of category >= 10 with its escape entry, the
 ///     window leaving its row -- WAITS for a rare slot, every kWriteRarePeriod-th iteration, and only there the wave
 ///     asks whether any lane has such a thing. A lane meets one less than three times per 256-byte subsequence, so the
@@ -417,9 +417,10 @@ JG_HD inline int extend_bits(uint32_t bits, int s)
 /// `Window` is the lane's view of the bitstream (device: RowWindow over the tiled rows of the destuffed buffer,
 /// jg_kernels.hip; host twin: tests/emu): seek(p), top() -- the refill, once per iteration --, look() -- the 32 bits
 /// at the position, valid while left() >= 0 --, skip(n), left() -- negative when the window wants a refill --,
-/// crossed() -- negative where the position has just left its row --, cross() and done() behind the loop. The results do not depend on the
-/// slot period (a host emulation runs one lane at a time). `max_iters` bounds the loop whatever the stream holds (a
-/// valid one needs fewer than one iteration per bit).
+/// crossed() -- negative where the position has just left its row --, cross() and done() behind the loop. The results
+/// do not depend on the slot periods (a host emulation runs one lane at a time). `max_iters` bounds the loop whatever
+/// the stream holds (a valid one needs fewer than one iteration per bit; a symbol that waits for the rare slot,
+/// kWriteRarePeriod, and such symbols take eleven bits at least).
 template <class Window, class Sink>
 JG_HD inline void decode_units(
     const LaneState& st,
