@@ -709,8 +709,16 @@ def main():
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     if world != args.gpus:
-        if world == 1 and args.gpus > 1:
-            raise SystemExit("bench.py --gpus %d must be launched with torch.distributed.run" % args.gpus)
+        if "WORLD_SIZE" not in os.environ and args.gpus > 1:
+            # Started as the driver starts N = 1 (`python3 bench.py --gpus N ...`): this process becomes the launcher of its
+            # own ranks. Nothing here has imported torch or touched the GPU yet; the ranks are a CHILD process
+            # (torch.distributed.run), never an exec of this one, and its exit code is ours.
+            import subprocess
+
+            port = os.environ.get("MASTER_PORT") or str(29500 + os.getpid() % 2000)
+            cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(args.gpus),
+                   "--master-addr", "127.0.0.1", "--master-port", port, os.path.abspath(__file__)] + sys.argv[1:]
+            raise SystemExit(subprocess.run(cmd).returncode)
         args.gpus = world
 
     images = make_images(args, rank, world)

@@ -181,7 +181,9 @@ enum jpeggpu_status jpeggpu_ext_decode_batch(
 enum jpeggpu_status jpeggpu_ext_batch_destroy(jpeggpu_batch_t batch);
 /* Lock-step flow iterations inside the per-sequence sync kernel (>= 1: the first one is what gives every
  * subsequence its coefficient count and DC sums) before unfinished flows are handed to the low-footprint,
- * re-packing tail kernel (default 1; the drop-in decode keeps all flows in the sequence kernel). */
+ * re-packing tail kernel (default 1: measured, a second iteration inside the sequence kernel costs a batch more than
+ * the tail kernel's trip it saves; the drop-in decode keeps all flows in the sequence kernel, re-packed into its
+ * lowest lanes between iterations). */
 enum jpeggpu_status jpeggpu_ext_batch_set_sync_iterations(jpeggpu_batch_t batch, int iterations);
 /* For a caller that uses ONE stream: split every batch into `parts` (1..4, default 1) that run concurrently,
  * part 0 on the caller's stream and the others on internal streams forked from and joined back into it with

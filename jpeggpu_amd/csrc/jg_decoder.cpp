@@ -72,7 +72,7 @@ struct ScanPlan {
     size_t blob_tables = 0, blob_tables_sync = 0, blob_segments = 0, blob_chunks = 0, blob_parts = 0;
     // offsets inside d_tmp
     size_t destuffed = 0, seg_idx = 0, st_p = 0, st_n = 0, st_cz = 0, st_dc01 = 0, st_dc23 = 0;
-    size_t tails_n = 0, tails_dc01 = 0, tails_dc23 = 0, pending = 0, flow_list = 0;
+    size_t tails_n = 0, tails_dc01 = 0, tails_dc23 = 0, pending = 0, flow_list = 0, bnd_p = 0, bnd_cz = 0;
     size_t sym = 0, du_tab = 0;
     size_t mh_p = 0, mh_cz = 0, mh_link = 0, mh_pool = 0, mh_known = 0; // multi-hypothesis speculation (jg_defs.h), if mh > 1
     int mh = 0, max_seg_subseq = 0;
@@ -193,6 +193,10 @@ void Decoder::make_plan()
         sp.tails_dc01 = o;
         o += align_up(static_cast<size_t>(sp.num_seq) * 4, 256);
         sp.tails_dc23 = o;
+        o += align_up(static_cast<size_t>(sp.num_seq) * 4, 256);
+        sp.bnd_p = o;
+        o += align_up(static_cast<size_t>(sp.num_seq) * 4, 256);
+        sp.bnd_cz = o;
         o += align_up(static_cast<size_t>(sp.num_seq) * 4, 256);
         // Multi-hypothesis speculation (jg_defs.h) for an image decoded on its own: several data units per MCU,
         // restart segments the chain walk can hold in LDS.
@@ -409,6 +413,8 @@ jpeggpu_status build_jobs(
         job.st_dc01    = reinterpret_cast<uint32_t*>(base + pl.st_dc01);
         job.st_dc23    = reinterpret_cast<uint32_t*>(base + pl.st_dc23);
         job.pending    = base + pl.pending;
+        job.bnd_p      = reinterpret_cast<int*>(base + pl.bnd_p);
+        job.bnd_cz     = reinterpret_cast<int*>(base + pl.bnd_cz);
         job.flow_list  = reinterpret_cast<int*>(base + pl.flow_list);
         job.tail_parts = reinterpret_cast<const int*>(blob + pl.blob_parts);
         job.num_tail_parts = static_cast<int>(sc.tail_parts.size()) - 1;
@@ -825,7 +831,11 @@ struct jpeggpu_batch {
     hipEvent_t copied[kRing]    = {};
     bool in_use[kRing]          = {};
     int next                    = 0;
-    int sync_iters              = 1; // throughput: speculate + verify in the sequence kernel, the rest in the tail kernel
+    // Flow iterations inside the sequence kernel of a batch. One: speculate + verify there, the rest in the tail kernel. More
+    // were measured with the survivors re-packed into one wave per workgroup (round 4): 2 / 3 / 8 iterations take the tail
+    // kernel from 364 to 204 / 70 / 14 us per 64 images and the sequence kernel from 680 to 937 / 1109 / 1138 -- a
+    // workgroup keeps its 22 KB of tables in LDS while one of its four waves works, and LDS is what bounds the kernel.
+    int sync_iters              = 1;
     // A caller with ONE stream leaves the GPU idle while the latency-bound tail kernel runs (a fifth of a
     // batch's time). With overlap > 1 the jobs are split into that many parts, part 0 on the caller's
     // stream and the others on internal streams forked from and joined back into it with events.

@@ -22,11 +22,14 @@ constexpr int kMaxDuPerMcu  = 10; // T.81 B.2.3
 constexpr int kSeqLanes    = 256; // lanes per workgroup of the Huffman kernels (reference decode_huffman.cu:777)
 constexpr int kSeqOverlap  = 16;  // lanes of the sync kernel that re-decode the tail of the previous sequence
 constexpr int kSeqSubseq   = kSeqLanes - kSeqOverlap; // subsequences owned by one workgroup ("sequence")
-// Target subsequences per workgroup of huff_sync_tail (cut at segment starts). The kernel is latency-bound and its
-// workgroups mostly wait, holding LDS (the sync table pack) that the kernels of other streams need: parts of ~2048
-// (one 1024-lane workgroup each) instead of ~512 (256 lanes) make the kernel itself 35 % slower and a batch 2.7 %
-// faster (four streams in flight); one image alone does not notice.
-constexpr int kTailPartSubseq = 2048;
+// Target subsequences per workgroup of huff_sync_tail (cut at segment starts). The kernel is a chain of dependent
+// whole-subsequence decodes (two to four trips of its lock-step loop) for the ~8 % of the subsequences whose flow the
+// sequence kernel left unfinished, so what it costs is latency, and a part's trip takes as long as the slowest lane of
+// its fullest wave. Measured per 64 images of 12 MP, serialized / four streams overlapping (round 4, in-run): parts of
+// 2048 (one 1024-lane workgroup, ~170 flows in three waves) 370 us / 27.4 k images/s; 768 (256 lanes, ~64 flows) 258 us /
+// 27.7 k; 512 250 us / 27.0 k; 384 390 us / 26.4 k; 1024 590 us / 23.7 k. Round 2 chose 2048 against 512 for the
+// overlapping case alone.
+constexpr int kTailPartSubseq = 768;
 constexpr int kDestuffWin   = 4096; // stuffed bytes handled by one destuff workgroup (256 lanes x 16 B)
 
 /// Zig-zag index -> raster index inside a data unit (T.81 figure A.6; reference src/defs.hpp:94-102).
@@ -375,6 +378,8 @@ struct ScanJob {
     int num_seq;
     ScanParams sp;
     IdctParams ip;
+    int* bnd_p;                  // [num_seq] exit state of the subsequence in front of sequence b as b's workgroup assumed it
+    int* bnd_cz;                 //   (-1: nothing to say): a boundary where it equals the stored state needs no flow
 };
 
 } // namespace jg

@@ -306,11 +306,12 @@ __global__ __launch_bounds__(PL) void front_plan(FS src)
     }
 
     // segments: data bytes -> subsequences
-    bool too_big = false;
+    bool too_big = false, empty = false;
     for (uint32_t k = tid; k < E; k += PL) {
         const uint32_t g0 = k == 0 ? 0u : mkg[k - 1];
         const uint32_t d  = mkg[k] - g0;
         too_big |= d > (1u << 27); // bit positions are 32-bit
+        empty |= d == 0;           // a restart interval holds at least one MCU: no bytes at all is not a JPEG (as the host walk)
         cnt[k] = (d + SB - 1) / SB;
         // chunks: the 4 KiB windows the segment's bytes touch (at least one, which carries the padding)
         const uint32_t b0 = k == 0 ? P.scan_begin : mkp[k - 1] + 2;
@@ -318,13 +319,14 @@ __global__ __launch_bounds__(PL) void front_plan(FS src)
         const uint32_t last = b1 > b0 ? b1 - 1 : b0;
         nch[k] = last / kDestuffWin - b0 / kDestuffWin + 1;
     }
-    if (__syncthreads_or(too_big)) {
+    const bool any_empty = __syncthreads_or(empty);
+    if (__syncthreads_or(too_big) || any_empty) {
         if (tid == 0) {
             JG_GLOBAL ScanJob* job = as_global(P.job);
             job->num_chunks = job->num_seq = job->num_tail_parts = 0;
             job->sp.num_subseq = job->sp.num_segments = 0;
             job->ip.num_du = 0;
-            stat[0] = 4;
+            stat[0] = any_empty ? 2 : 4; // JPEGGPU_INVALID_JPEG / JPEGGPU_NOT_SUPPORTED
             stat[1] = stat[2] = stat[3] = stat[4] = 0;
         }
         return;

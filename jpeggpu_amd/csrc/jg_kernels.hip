@@ -76,6 +76,8 @@ struct JobView {
     JG_GLOBAL uint32_t* st_dc01;
     JG_GLOBAL uint32_t* st_dc23;
     JG_GLOBAL uint8_t* pending;
+    JG_GLOBAL int* bnd_p;
+    JG_GLOBAL int* bnd_cz;
     JG_GLOBAL int* flow_list;
     JG_GLOBAL const int* tail_parts;
     int num_tail_parts;
@@ -100,7 +102,7 @@ struct JobView {
           tables(as_global(j.tables)), tables_sync(as_global(j.tables_sync)), qtables(as_global(j.qtables)), destuffed(as_global(j.destuffed)),
           seg_idx(as_global(j.seg_idx)), st_p(as_global(j.st_p)), st_n(as_global(j.st_n)), st_cz(as_global(j.st_cz)),
           st_dc01(as_global(j.st_dc01)), st_dc23(as_global(j.st_dc23)), pending(as_global(j.pending)),
-          flow_list(as_global(j.flow_list)), tail_parts(as_global(j.tail_parts)), num_tail_parts(j.num_tail_parts),
+          bnd_p(as_global(j.bnd_p)), bnd_cz(as_global(j.bnd_cz)), flow_list(as_global(j.flow_list)), tail_parts(as_global(j.tail_parts)), num_tail_parts(j.num_tail_parts),
           tails_n(as_global(j.tails_n)), tails_dc01(as_global(j.tails_dc01)), tails_dc23(as_global(j.tails_dc23)),
           mh_p(as_global(j.mh_p)), mh_cz(as_global(j.mh_cz)), mh_link(as_global(j.mh_link)), mh_pool(as_global(j.mh_pool)), mh_known(as_global(j.mh_known)),
           sym(as_global(j.sym)), du_tab(as_global(j.du_tab)), sym_region(j.sym_region), sym_entries(j.sym_entries),
@@ -112,6 +114,7 @@ struct JobView {
 struct JobByValue {
     // One image: ~14 dependent flow iterations decide the time, the speculative pass is one of them.
     static constexpr bool kSpeculateStateOnly = false;
+    static constexpr bool kRepackFlows = true; // huff_sync_intra: flows that outlive the first iteration are packed into the lowest lanes
     ScanJob job;
     __device__ __forceinline__ const ScanJob& get() const { return job; }
 };
@@ -120,6 +123,7 @@ struct JobsByValue {
     // blockIdx.y -- the scans are independent, and a 39 MP file of three scans spends a third of the time of three
     // launch sequences one after the other.
     static constexpr bool kSpeculateStateOnly = false;
+    static constexpr bool kRepackFlows = true;
     ScanJob jobs[kMaxScans];
     __device__ __forceinline__ const ScanJob& get() const { return jobs[blockIdx.y]; }
 };
@@ -127,6 +131,10 @@ struct JobArray {
     // Batches run one flow iteration, so the speculative pass is half of the sequence kernel's work:
     // it tracks the exit state only (-10 % kernel time); single-image latency is 4 % better without.
     static constexpr bool kSpeculateStateOnly = true;
+    // The sequence kernel of a batch is bound by how many workgroups a CU holds (LDS: the sync table pack): the 4 KB the
+    // re-packing needs cost one in five (538 -> 680 us per 64 images), and follow-up iterations inside that kernel cost
+    // more than the tail kernel's trips they replace (jg_decoder.cpp, sync_iters): batches run huff_sync_intra_batch.
+    static constexpr bool kRepackFlows = false;
     const ScanJob* jobs;
     __device__ __forceinline__ const ScanJob& get() const { return jobs[blockIdx.y]; }
 };
@@ -135,6 +143,7 @@ struct JobSingle {
     // One job that lives in device memory, whatever blockIdx.y is: the lone decode of a device-scanned image (the
     // second dimension of the multi-hypothesis kernels' grid is the hypothesis).
     static constexpr bool kSpeculateStateOnly = false;
+    static constexpr bool kRepackFlows = true;
     const ScanJob* job;
     __device__ __forceinline__ const ScanJob& get() const { return *job; }
 };
@@ -550,15 +559,38 @@ __device__ __forceinline__ void load_tables(uint8_t* s_tab, JG_GLOBAL const uint
 
 /// Carve of the dynamic LDS of the two sequence-wide Huffman kernels.
 struct SeqLds {
-    static constexpr uint32_t kState = 0;
-    static constexpr uint32_t kTabs  = (kState + 6 * (T + 1) * 4 + 64 + 15) / 16 * 16; // 5 state arrays / scan scratch
+    static constexpr uint32_t kState = 0;                          // 5 state arrays of T + 1 words
+    static constexpr uint32_t kFlows = kState + 5 * (T + 1) * 4;   // 4 arrays of T words: the flows re-packed between iterations
+    static constexpr uint32_t kPend  = kFlows + 4 * T * 4;         // T + 1 bytes of marks
+    static constexpr uint32_t kTabs  = (kPend + T + 1 + 15) / 16 * 16;
     static_assert(kTabs % 16 == 0, "the table pack is read with 16-byte loads");
 };
 /// Static LDS of a kernel precedes its dynamic LDS; the Huffman kernels declare at most this much.
 constexpr uint32_t kStaticLdsSlack = 256;
-static_assert(kStaticLdsSlack + SeqLds::kTabs + kMaxTablePackSync <= 65536, "absolute table addresses are packed into 16 bits (load_tables)");
+static_assert(kStaticLdsSlack + SeqLds::kTabs + kMaxTablePackSync <= 65536 && kStaticLdsSlack + 6 * (T + 1) * 4 + 80 + kMaxTablePackSync <= 65536, "absolute table addresses are packed into 16 bits (load_tables)");
 
 __device__ __forceinline__ uint32_t pk_add(uint32_t a, uint32_t b) { return pk_add_u16(a, b); }
+
+/// Inclusive block-wide position of the set flags among TL lanes; returns the block total.
+template <int TL>
+__device__ __forceinline__ int block_rank(bool flag, int* s_wave, int& rank)
+{
+    const unsigned long long m = __ballot(flag);
+    const int before           = __popcll(m & ((1ull << lane_id()) - 1ull));
+    const int w                = threadIdx.x >> 6;
+    __syncthreads(); // previous use of s_wave is over
+    if (lane_id() == 0) s_wave[w] = __popcll(m);
+    __syncthreads();
+    int off = 0, total = 0;
+#pragma unroll
+    for (int k = 0; k < TL / 64; ++k) {
+        const int c = s_wave[k];
+        off += k < w ? c : 0;
+        total += c;
+    }
+    rank = off + before;
+    return total;
+}
 
 // ------------------------------------------------------------------------------------------------
 // Huffman: speculative decode + intra-sequence synchronisation
@@ -568,23 +600,45 @@ __device__ __forceinline__ uint32_t pk_add(uint32_t a, uint32_t b) { return pk_a
 /// only), then decodes the following subsequences of the same segment -- now with n and the DC sums --
 /// until the state it reaches equals the one stored there. A subsequence that
 /// opens a segment is decoded from the segment's start state by its left neighbour. In iteration i
-/// entry j = t+1+i of the LDS state table is read and written by lane t only, so one workgroup barrier
-/// per iteration is enough. At least one iteration is needed (max_intra_iters >= 1).
+/// entry j = t+1+i of the LDS state table is read and written by the flow that started at lane t only, so one
+/// workgroup barrier per iteration is enough. At least one iteration is needed (max_intra_iters >= 1).
+///
+/// FLOWS ARE RE-PACKED. The first flow iteration is every lane's (it supplies n and the DC sums of every
+/// subsequence). After it a few lanes in a hundred still flow -- 8 % on the 12 MP synthetic images, 22 % on the
+/// reference's photo at 256-byte subsequences (tools/probe/flow_study.py), and nearly all of them only CONFIRM the
+/// next entry: 99.5 % / 94 % of the table is already the sequential decoder's. Left where they are they keep all four
+/// waves of the workgroup in the loop; handed to huff_sync_tail (round 3) they become a chain of whole-subsequence
+/// decodes on a chip with one wave per SIMD, 430 us per 64 images of pure latency. So the survivors are packed into
+/// the lowest lanes between iterations (state through LDS: the entry a flow continues from may be overwritten in the
+/// same iteration by the flow behind it): the follow-up iterations cost ONE wave per workgroup, a workgroup leaves as
+/// soon as it has no flow left, and what the tail kernel still gets is the rare flow that crosses into the next
+/// sequence. This is the kernel of LONE decodes (one image: every flow stays in its sequence's workgroup). For batches
+/// it was measured and lost -- the workgroup keeps its 22 KB of tables while one of its four waves works, and LDS is what
+/// bounds this kernel when the chip is full: huff_sync_intra_batch below.
 ///
 /// The first OV lanes re-decode the last OV subsequences of the PREVIOUS sequence (their results are
 /// not stored): their flows enter this sequence the way the previous workgroup's would, so the first
-/// subsequences of the sequence are normally already what the inter-sequence kernel will confirm.
+/// subsequences of the sequence are normally already what the inter-sequence kernel will confirm. The exit state of
+/// the previous sequence's last subsequence AS THIS WORKGROUP SAW IT goes to `bnd_p / bnd_cz`: where it equals what the
+/// previous workgroup stored the boundary needs no flow at all (huff_sync_tail).
 template <int W, class JS>
 __global__ __launch_bounds__(T) void huff_sync_intra(JS js)
 {
     extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
-    int* s_p         = reinterpret_cast<int*>(smem + SeqLds::kState);
-    int* s_n         = s_p + T;
-    int* s_cz        = s_n + T;
-    uint32_t* s_dc01 = reinterpret_cast<uint32_t*>(s_cz + T);
-    uint32_t* s_dc23 = s_dc01 + T;
-    int* s_pend      = reinterpret_cast<int*>(s_dc23 + T);
-    uint8_t* s_tab   = smem + SeqLds::kTabs;
+    __shared__ int s_wave[T / 64];
+    __shared__ int s_cut; // a flow was cut short right at the last entry of the overlap zone: bnd would not be what entry OV came from
+    typedef SeqLds Lds;
+    int* s_p         = reinterpret_cast<int*>(smem + Lds::kState);
+    int* s_n         = s_p + (T + 1);
+    int* s_cz        = s_n + (T + 1);
+    uint32_t* s_dc01 = reinterpret_cast<uint32_t*>(s_cz + (T + 1));
+    uint32_t* s_dc23 = s_dc01 + (T + 1);
+    int* s_fj        = reinterpret_cast<int*>(smem + Lds::kFlows); // re-packed flows: entry last written | lane limit << 16,
+    int* s_frel      = s_fj + T;                                      //   that entry's index in its segment,
+    int* s_fp        = s_frel + T;                                    //   the state reached there
+    int* s_fcz       = s_fp + T;
+    uint8_t* s_pend  = smem + Lds::kPend; // bit 0: a flow that wrote the entry is unfinished; bit 1: a state a flow may stop at
+    uint8_t* s_tab   = smem + Lds::kTabs;
 
     const JobView J(js.get());
     if (static_cast<int>(blockIdx.x) >= J.num_seq) return;
@@ -592,6 +646,7 @@ __global__ __launch_bounds__(T) void huff_sync_intra(JS js)
     sp.use_sync_pack();
     const int t         = threadIdx.x;
     s_pend[t]           = 0;
+    if (t == 0) s_cut = 0;
     const int first_sub = blockIdx.x * SEQ;                  // first subsequence this workgroup owns
     const int img_first = first_sub - OV;                    // subsequence of lane 0
     const int img_end   = min(T, sp.num_subseq - img_first); // lanes below this have a subsequence
@@ -619,8 +674,196 @@ __global__ __launch_bounds__(T) void huff_sync_intra(JS js)
         seg = ld_global(J.segments + J.seg_idx[sub]);
         rel = sub - seg.subseq_offset;
         if (mh) {
-            st.p         = J.st_p[sub];
-            const int cz = J.st_cz[sub];
+            // (the resolved table has its own buffers, hypothesis 0's: what another workgroup of THIS launch stores into
+            // st_p / st_cz is never read here)
+            st.p         = J.mh_p[sub];
+            const int cz = J.mh_cz[sub];
+            st.c         = cz & 0xFF;
+            st.z         = cz >> 8;
+            known        = J.mh_known[sub] != 0;
+            s_pend[t]    = known ? 2 : 0;
+        } else {
+            // speculative pass: the own subsequence from the guessed state (c, z) = (0, 0), exit state only
+            st.p = rel * kBits;
+            fetch.set_row(sub, rel);
+            bw.seek(st.p, fetch);
+            if (JS::kSpeculateStateOnly) {
+                SpecSink none;
+                decode_subsequence(st, bw, fetch, (rel + 1) * kBits, s_tab, sp, none);
+            } else {
+                NoSink sums; // exact for a subsequence that opens a segment, replaced by a flow everywhere else
+                decode_subsequence(st, bw, fetch, (rel + 1) * kBits, s_tab, sp, sums);
+                s_n[t]    = st.n;
+                s_dc01[t] = st.dc01;
+                s_dc23[t] = st.dc23;
+            }
+            s_pend[t] = 2;
+        }
+        s_p[t]  = st.p;
+        s_cz[t] = st.c | (st.z << 8);
+    }
+    __syncthreads();
+    JG_STAMP(2);
+
+    // Flow passes. Lane t first decodes subsequence j = t + 1 from the own exit state. With a state-only
+    // speculative pass (and with the multi-hypothesis table) it also does so if j opens a restart segment -- from the
+    // segment's start state, which is known, not guessed -- so that every subsequence gets its n and DC sums from a
+    // decode that started in a real state; otherwise the speculative pass of such a j was already exact.
+    const bool covers_starts = JS::kSpeculateStateOnly || mh;
+    bool flowing = covers_starts ? t + 1 < img_end && img_first + t + 1 >= 0 : active;
+    int lim      = 0; // flows stay below this lane index: end of the segment or of the image
+    if (flowing) {
+        const int sub_j = img_first + t + 1;
+        if (covers_starts && (!active || rel + 1 == seg.subseq_count)) { // j opens the next segment
+            seg   = ld_global(J.segments + J.seg_idx[sub_j]);
+            rel   = -1;
+            st    = LaneState{};
+            known = true;
+        }
+        lim = min(img_end, seg.subseq_offset + seg.subseq_count - img_first);
+        flowing = known;
+    }
+    NoSink sink;
+    // One step of a flow that has reached entry j - 1 with state `st` (`rel`: that entry's index in its segment):
+    // decode entry j, compare, store. Returns whether the flow goes on.
+    const auto flow_step = [&](int j) -> bool {
+        st.n    = 0;
+        st.dc01 = 0;
+        st.dc23 = 0;
+        // every decode works in the row of its subsequence (GlobalFetch): the window is set up again from p
+        ++rel;
+        fetch.set_row(img_first + j, rel);
+        bw.seek(st.p, fetch);
+        decode_subsequence(st, bw, fetch, (rel + 1) * kBits, s_tab, sp, sink);
+        const int cz     = st.c | (st.z << 8);
+        const bool synced = st.p == s_p[j] && cz == s_cz[j] && (s_pend[j] & 2); // still store n / dc
+        s_p[j]    = st.p;
+        s_n[j]    = st.n;
+        s_cz[j]   = cz;
+        s_dc01[j] = st.dc01;
+        s_dc23[j] = st.dc23;
+        s_pend[j] = 2; // from here on a state a flow may stop at
+        return !synced;
+    };
+    // One loop, one copy of the symbol loop in it. The first iteration is every lane's own flow; `j` is the entry the
+    // lane's flow wrote last.
+    int j    = t;
+    int iter = 0;
+    for (; iter < sp.max_intra_iters; ++iter) {
+        bool go = flowing && j + 1 < lim;
+        if (iter > 0) {
+            // survivors into the lowest lanes (block_rank's barriers also order this iteration's table accesses behind
+            // the previous one's)
+            int rank;
+            const int total = block_rank<T>(go, s_wave, rank);
+            if (total == 0) break;
+            if (go) {
+                s_fj[rank]   = j | lim << 16;
+                s_frel[rank] = rel;
+                s_fp[rank]   = st.p;
+                s_fcz[rank]  = st.c | (st.z << 8);
+            }
+            __syncthreads();
+            go = t < total;
+            if (go) {
+                const int pk = s_fj[t], cz = s_fcz[t];
+                j    = pk & 0xFFFF;
+                lim  = pk >> 16;
+                rel  = s_frel[t];
+                st.p = s_fp[t];
+                st.c = cz & 0xFF;
+                st.z = cz >> 8;
+            }
+        }
+        flowing = go;
+        if (go) flowing = flow_step(++j);
+        JG_STAMP(3 + iter);
+    }
+    // Flows cut short by the iteration cap continue in huff_sync_tail from the entry they reached
+    // last: mark that entry (flows still inside the overlap zone belong to the previous workgroup).
+    if (iter == sp.max_intra_iters && flowing && j + 1 < lim) {
+        if (j >= OV) s_pend[j] |= 1;
+        if (j == OV - 1) s_cut = 1;
+    }
+    __syncthreads();
+
+    if (active && t >= OV) {
+        J.pending[sub] = static_cast<uint8_t>(s_pend[t] & 1);
+        J.st_p[sub]    = s_p[t];
+        J.st_n[sub]    = s_n[t];
+        J.st_cz[sub]   = s_cz[t];
+        J.st_dc01[sub] = s_dc01[t];
+        J.st_dc23[sub] = s_dc23[t];
+    }
+    if (t == OV - 1) {
+        // what entry OV (the sequence's first subsequence) was decoded from, if anything in this workgroup says so
+        const bool have = active && !s_cut;
+        J.bnd_p[blockIdx.x]  = have ? s_p[t] : -1;
+        J.bnd_cz[blockIdx.x] = have ? s_cz[t] : -1;
+    }
+}
+
+/// The sequence kernel of a BATCH (JobArray): round 3's kernel as it stood -- every flow stays in its lane, the loop is
+/// capped (normally at its first iteration) and the rest goes to huff_sync_tail. The kernel above computes the same with
+/// max_intra_iters == 1 and takes the same time alone on the chip (536 against 538 us per 64 images), but a batch whose
+/// four streams overlap ran 5 % slower with it (26.5 k against 27.9 k images/s, measured six times in-run against this
+/// one; neither its LDS footprint -- padded to this kernel's and beyond --, nor its code size, nor the job's layout, nor
+/// the boundary records explain it: DESIGN.md section 7), so batches keep this one.
+struct SeqLdsBatch {
+    static constexpr uint32_t kState = 0;
+    static constexpr uint32_t kTabs  = (kState + 6 * (T + 1) * 4 + 64 + 15) / 16 * 16; // 5 state arrays / scan scratch
+    static_assert(kTabs % 16 == 0, "the table pack is read with 16-byte loads");
+};
+template <int W, class JS>
+__global__ __launch_bounds__(T) void huff_sync_intra_batch(JS js)
+{
+    extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
+    int* s_p         = reinterpret_cast<int*>(smem + SeqLdsBatch::kState);
+    int* s_n         = s_p + T;
+    int* s_cz        = s_n + T;
+    uint32_t* s_dc01 = reinterpret_cast<uint32_t*>(s_cz + T);
+    uint32_t* s_dc23 = s_dc01 + T;
+    int* s_pend      = reinterpret_cast<int*>(s_dc23 + T);
+    uint8_t* s_tab   = smem + SeqLdsBatch::kTabs;
+
+    const JobView J(js.get());
+    if (static_cast<int>(blockIdx.x) >= J.num_seq) return;
+    ScanParams sp = J.sp;
+    sp.use_sync_pack();
+    const int t         = threadIdx.x;
+    s_pend[t]           = 0;
+    const int first_sub = blockIdx.x * SEQ;                  // first subsequence this workgroup owns
+    const int img_first = first_sub - OV;                    // subsequence of lane 0
+    const int img_end   = min(T, sp.num_subseq - img_first); // lanes below this have a subsequence
+
+    JG_STAMP(0);
+    load_tables(s_tab, J.tables_sync, sp);
+    __syncthreads();
+    JG_STAMP(1);
+
+    constexpr int kBits = W * 32;
+    const int sub       = img_first + t;
+    const bool active   = sub >= 0 && t < img_end;
+    // Multi-hypothesis speculation (jg_defs.h): the table this kernel starts from was written by huff_mh_resolve -- for
+    // every subsequence the candidate state the chain of links passes through -- instead of being speculated here. The
+    // flows below then are the reference's, from that table; an entry the chain hopped over (not `known`) starts no
+    // flow and stops none: the flow from upstream fills it in.
+    // (a batch never runs the multi-hypothesis kernels, build_jobs: the branches below fold away -- and must: with the
+    // table read from mh_p / mh_cz in the dead branch, two more pointers of the job loaded at the kernel's start, a batch
+    // of four overlapping streams ran 5 % slower, measured in-run eight times over)
+    constexpr bool mh = false;
+    LaneState st{};
+    BitWindow<GlobalFetch<W>> bw{};
+    GlobalFetch<W> fetch{reinterpret_cast<JG_GLOBAL const uint32_t*>(J.destuffed), 0, 0};
+    Segment seg{0, 0};
+    int rel = 0;
+    bool known = true;
+    if (active) {
+        seg = ld_global(J.segments + J.seg_idx[sub]);
+        rel = sub - seg.subseq_offset;
+        if (mh) {
+            st.p         = J.mh_p[sub];
+            const int cz = J.mh_cz[sub];
             st.c         = cz & 0xFF;
             st.z         = cz >> 8;
             known        = J.mh_known[sub] != 0;
@@ -706,6 +949,11 @@ __global__ __launch_bounds__(T) void huff_sync_intra(JS js)
         J.st_cz[sub]   = s_cz[t];
         J.st_dc01[sub] = s_dc01[t];
         J.st_dc23[sub] = s_dc23[t];
+    }
+    // (this kernel says nothing about the boundary: huff_sync_tail then starts a flow at every one, as round 3 did)
+    if (t == OV - 1) {
+        J.bnd_p[blockIdx.x]  = -1;
+        J.bnd_cz[blockIdx.x] = -1;
     }
 }
 
@@ -812,6 +1060,7 @@ __host__ __device__ constexpr size_t mh_resolve_lds(int H, int n)
 
 /// The chain: one workgroup per restart segment loads the segment's links into LDS and follows them from the first
 /// subsequence's hypothesis 0; everybody then writes the table huff_sync_intra starts from: the candidate the chain
+/// (in the rows of hypothesis 0 of mh_p / mh_cz): the candidate the chain
 /// passes through where it does, the state a hopping flow left in the pool where the chain hopped over a subsequence
 /// (both `mh_known`), hypothesis 0 as a placeholder where it hopped and the pool was full, and the plain speculation
 /// from where the chain broke off (a candidate that met none within kMhSteps).
@@ -830,12 +1079,9 @@ __global__ __launch_bounds__(256) void huff_mh_resolve(JS js)
     if (static_cast<int>(blockIdx.x) >= sp.num_segments) return;
     const Segment seg = ld_global(J.segments + blockIdx.x);
     const int n = seg.subseq_count, base = seg.subseq_offset, S = sp.num_subseq, H = sp.mh;
+    if (n <= 0) return; // (both walks refuse a segment without data; block-uniform, before anything is carved for n nodes)
     if (n > kMhMaxSegSubseq) { // (only a device-scanned image can get here: the host walk knows its segments) plain speculation
-        for (int r = threadIdx.x; r < n; r += 256) {
-            J.st_p[base + r]     = J.mh_p[base + r];
-            J.st_cz[base + r]    = J.mh_cz[base + r];
-            J.mh_known[base + r] = 1;
-        }
+        for (int r = threadIdx.x; r < n; r += 256) J.mh_known[base + r] = 1; // hypothesis 0's rows are the table (below)
         return;
     }
     const int nodes  = H * n;                                               // node (h, r) = h * n + r
@@ -873,7 +1119,7 @@ __global__ __launch_bounds__(256) void huff_mh_resolve(JS js)
     if (t == 0) {
         int m = 0;
         uint32_t a = 0; // node (0, 0): hypothesis 0 of the segment's first subsequence is exact
-        while (a < kBreak) {
+        while (a < kBreak && m <= n / 16 + 1) { // (an anchor every 16 links of a chain of at most n: the bound is belt and braces)
             const uint32_t h = a / n;
             s_anc[m++]       = static_cast<uint16_t>(h << 12 | (a - h * n));
             a                = s_ja[a];
@@ -922,8 +1168,11 @@ __global__ __launch_bounds__(256) void huff_mh_resolve(JS js)
             cz    = J.mh_cz[base + r];
             known = false;
         }
-        J.st_p[base + r]     = p;
-        J.st_cz[base + r]    = cz;
+        // The table lives in the rows of hypothesis 0, which nothing reads any more (entry base + r only by this lane,
+        // above): huff_sync_intra starts from buffers no workgroup of ITS launch writes (st_p / st_cz, which round 3
+        // used, are stored by the owners of the subsequences while the neighbours' overlap lanes read them: ADVICE r3).
+        J.mh_p[base + r]     = p;
+        J.mh_cz[base + r]    = cz;
         J.mh_known[base + r] = known ? 1 : 0;
     }
 }
@@ -938,27 +1187,6 @@ __global__ __launch_bounds__(256) void huff_mh_resolve(JS js)
 /// with overlapping streams). A scan without restart markers is one part with thousands of flows: 1024
 /// lanes, or its ordered groups of flows would run one after the other.
 constexpr int kTailLanesSmall = 256, kTailLanesLarge = 1024, kTailLargeFrom = 1024;
-
-/// Inclusive block-wide position of the set flags among TL lanes; returns the block total.
-template <int TL>
-__device__ __forceinline__ int block_rank(bool flag, int* s_wave, int& rank)
-{
-    const unsigned long long m = __ballot(flag);
-    const int before           = __popcll(m & ((1ull << lane_id()) - 1ull));
-    const int w                = threadIdx.x >> 6;
-    __syncthreads(); // previous use of s_wave is over
-    if (lane_id() == 0) s_wave[w] = __popcll(m);
-    __syncthreads();
-    int off = 0, total = 0;
-#pragma unroll
-    for (int k = 0; k < TL / 64; ++k) {
-        const int c = s_wave[k];
-        off += k < w ? c : 0;
-        total += c;
-    }
-    rank = off + before;
-    return total;
-}
 
 /// Continues, from global state, every flow that huff_sync_intra could not finish: one flow per
 /// sequence boundary (carry the exit state of the last subsequence of sequence b-1 into sequence b,
@@ -995,18 +1223,28 @@ __global__ __launch_bounds__(TL) void huff_sync_tail(JS js)
     const int hi           = J.tail_parts[blockIdx.x + 1];
     const int tid          = threadIdx.x;
     JG_TAIL_STAMP(0, static_cast<uint32_t>(wall_clock64()));
-    load_tables(s_tab, J.tables_sync, sp);
 
-    // ordered list of flow origins in [lo, hi)
+    // Ordered list of flow origins in [lo, hi): the marks huff_sync_intra left, and the sequence boundaries at which the
+    // exit state the following sequence's workgroup assumed for its predecessor (bnd_p / bnd_cz) is not the one stored:
+    // where it is, the sequence's first entry was derived from the stored state already and a flow could only confirm it.
     int count = 0;
     for (int base = lo; base < hi; base += TL) {
         const int sub = base + tid;
-        const bool f  = sub < hi && sub + 1 < sp.num_subseq && (J.pending[sub] != 0 || (sub + 1) % SEQ == 0);
+        bool f        = sub < hi && sub + 1 < sp.num_subseq;
+        if (f) {
+            f = J.pending[sub] != 0;
+            if (!f && (sub + 1) % SEQ == 0 && J.seg_idx[sub] == J.seg_idx[sub + 1]) {
+                const int b = (sub + 1) / SEQ;
+                f           = J.bnd_p[b] != J.st_p[sub] || J.bnd_cz[b] != J.st_cz[sub];
+            }
+        }
         int rank;
         const int total = block_rank<TL>(f, s_wave, rank);
         if (f) J.flow_list[lo + count + rank] = sub;
         count += total;
     }
+    if (count == 0) return; // (uniform) most parts of a batch: nothing crosses a sequence boundary unconfirmed
+    load_tables(s_tab, J.tables_sync, sp);
     __syncthreads(); // list and tables visible to the whole workgroup
     JG_TAIL_STAMP(1, static_cast<uint32_t>(wall_clock64()));
     [[maybe_unused]] int trips = 0;
@@ -1850,8 +2088,14 @@ hipError_t launch_huff(Stage stage, const JS& js, const JobExtent& e, int grid_y
     if (e.max_tab_bytes > kMaxTablePack || e.max_tab_bytes_sync > kMaxTablePackSync) return hipErrorInvalidValue;
     switch (stage) {
     case kStageSyncIntra:
-        if ((err = allow_lds(huff_sync_intra<W, JS>, seq_lds)) != hipSuccess) return err;
-        huff_sync_intra<W, JS><<<dim3(e.max_seq, grid_y), T, seq_lds, stream>>>(js);
+        if constexpr (JS::kRepackFlows) {
+            if ((err = allow_lds(huff_sync_intra<W, JS>, seq_lds)) != hipSuccess) return err;
+            huff_sync_intra<W, JS><<<dim3(e.max_seq, grid_y), T, seq_lds, stream>>>(js);
+        } else {
+            const size_t lds = SeqLdsBatch::kTabs + e.max_tab_bytes_sync;
+            if ((err = allow_lds(huff_sync_intra_batch<W, JS>, lds)) != hipSuccess) return err;
+            huff_sync_intra_batch<W, JS><<<dim3(e.max_seq, grid_y), T, lds, stream>>>(js);
+        }
         break;
     case kStageSyncInter:
         if (e.max_tail_parts > 0)

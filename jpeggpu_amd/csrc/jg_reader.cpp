@@ -645,6 +645,13 @@ jpeggpu_status Reader::walk_scan(Scan& scan, const Logger& log)
         if (qo > chunk_begin || scan.chunks.size() == seg_first_chunk) emit(chunk_begin, qo);
         const size_t seg_bytes = chunk_dst - static_cast<size_t>(seg_dst_base);
         if (seg_bytes > (1u << 27)) return JPEGGPU_NOT_SUPPORTED; // bit positions are 32-bit
+        // A restart interval holds at least one MCU, so at least one byte: two markers back to back (which the
+        // reference's walk, src/reader.cpp:447-489, takes for a segment of no subsequences) are not a JPEG. Kernels that
+        // work segment by segment would otherwise meet a segment without a first subsequence.
+        if (seg_bytes == 0) {
+            log.log("\trestart segment %d holds no entropy-coded data\n", static_cast<int>(scan.segments.size()));
+            return JPEGGPU_INVALID_JPEG;
+        }
         Segment seg;
         seg.subseq_offset = scan.num_subseq;
         seg.subseq_count  = static_cast<int>((seg_bytes + subseq_bytes_ - 1) / subseq_bytes_);
@@ -685,8 +692,9 @@ jpeggpu_status Reader::walk_scan(Scan& scan, const Logger& log)
     // workgroups: cut the scan at segment starts into parts of about kTailPartSubseq subsequences.
     scan.tail_parts.clear();
     scan.tail_parts.push_back(0);
+    const int part = kTailPartSubseq;
     for (const Segment& seg : scan.segments) {
-        if (seg.subseq_offset - scan.tail_parts.back() >= kTailPartSubseq) scan.tail_parts.push_back(seg.subseq_offset);
+        if (seg.subseq_offset - scan.tail_parts.back() >= part) scan.tail_parts.push_back(seg.subseq_offset);
     }
     scan.tail_parts.push_back(scan.num_subseq);
     return JPEGGPU_SUCCESS;

@@ -330,6 +330,31 @@ static void layout_free(jo_layout* l)
     memset(l, 0, sizeof(*l));
 }
 
+/* byte rule, reference src/decode_destuff.cu:37-44 (is_byte_data, called with prev_is_stuffing = the byte in front is
+   FF, :64 and :91): a byte is data iff it is the 00 behind an FF (it then stands for FF) or neither it nor the byte in front
+   of it is FF */
+static int byte_rule(int prev, int b, uint8_t* write)
+{
+    if (prev == 0xFF && b == 0x00) {
+        *write = 0xFF;
+        return 1;
+    }
+    if (prev != 0xFF && b != 0xFF) {
+        *write = (uint8_t)b;
+        return 1;
+    }
+    return 0;
+}
+
+void jo_byte_rule(const uint8_t* prev, const uint8_t* byte, int n, uint8_t* is_data, uint8_t* written)
+{
+    for (int i = 0; i < n; ++i) {
+        uint8_t w   = 0;
+        is_data[i] = (uint8_t)byte_rule(prev[i], byte[i], &w);
+        written[i] = w;
+    }
+}
+
 static int build_layout(const uint8_t* data, const jo_scan* sc, int subseq_bytes, jo_layout* l)
 {
     const uint8_t* p   = data + sc->begin;
@@ -349,14 +374,16 @@ static int build_layout(const uint8_t* data, const jo_scan* sc, int subseq_bytes
         int at_end = p >= end, is_rst = 0;
         if (!at_end) {
             int b = *p;
-            /* byte rule, reference src/decode_destuff.cu:37-44 */
-            if (prev == 0xFF && b == 0x00) l->bytes[nb++] = 0xFF;
-            else if (prev != 0xFF && b != 0xFF) l->bytes[nb++] = (uint8_t)b;
+            uint8_t w;
+            if (byte_rule(prev, b, &w)) l->bytes[nb++] = w;
             else if (prev == 0xFF && b >= 0xD0 && b <= 0xD7) is_rst = 1;
             prev = is_rst ? 0 : b;
         }
         if (at_end || is_rst) {
             int bytes = (int)nb - seg_start_b, cnt = ceil_div(bytes, subseq_bytes);
+            /* a restart interval holds at least one MCU: a segment without a byte (two markers back to back, which
+               the reference's walk src/reader.cpp:447-489 would count as a segment of no subsequences) is refused */
+            if (bytes == 0) return JO_INVALID_JPEG;
             if (ns == cap_s) {
                 cap_s *= 2;
                 l->seg_offset = realloc(l->seg_offset, sizeof(int) * (size_t)cap_s);
@@ -415,6 +442,26 @@ static int receive_extend(jo_bits* br, int s)
     for (int i = 0; i < s; ++i) v = v << 1 | get_bit(br);
     if (s && v < (1 << (s - 1))) v = v - (1 << s) + 1; /* T.81 F.2.2.1 */
     return v;
+}
+
+/* One symbol per 32-bit window (most significant bit first, zeros behind it), the outputs of the reference's
+   decode_next_symbol<true> (src/decode_huffman.cu:202-286): bits taken, coefficient value, run of zeros in front of
+   it (AC: 15 for ZRL, 63 - z for an end of block). For the tests against the reference-built known answers
+   (tests/golden/huff_kats.npz). */
+int jo_symbol_steps(const uint8_t bits[16], const uint8_t* vals, int count, int is_dc, const uint32_t* win, const int* z, int n,
+                    int* length, int* symbol, int* run)
+{
+    jo_htab t;
+    if (build_htab(&t, bits, vals, count)) return JO_INVALID_JPEG;
+    for (int i = 0; i < n; ++i) {
+        uint8_t b[4] = {(uint8_t)(win[i] >> 24), (uint8_t)(win[i] >> 16), (uint8_t)(win[i] >> 8), (uint8_t)win[i]};
+        jo_bits br  = {b, 32, 0};
+        int sym = decode_sym(&br, &t), ssss = sym & 15, rrrr = is_dc ? 0 : sym >> 4;
+        symbol[i]   = receive_extend(&br, ssss);
+        length[i]   = br.pos;
+        run[i]      = is_dc ? 0 : ssss ? rrrr : rrrr == 15 ? 15 : 63 - z[i];
+    }
+    return JO_OK;
 }
 
 /* Optional record of the decoder state at subsequence boundaries (stage twin of the sync passes). */

@@ -48,6 +48,11 @@ void jo_idct_block(const int16_t coef[64], const uint16_t q[64], uint8_t out[64]
 /* the 8-point fixed-point transform (reference idct_vector, src/idct.cu:50-95) on n vectors of 8 */
 void jo_idct_vectors(const int32_t* in, int32_t* out, int n);
 
+/* one Huffman symbol per 32-bit window / the byte rule of the destuffing, for the reference-built known answers */
+int jo_symbol_steps(const uint8_t bits[16], const uint8_t* vals, int count, int is_dc, const uint32_t* win, const int* z, int n,
+                    int* length, int* symbol, int* run);
+void jo_byte_rule(const uint8_t* prev, const uint8_t* byte, int n, uint8_t* is_data, uint8_t* written);
+
 typedef struct {
     int num_subseq, num_segments, num_du;
     size_t scan_begin, scan_end;

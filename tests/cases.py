@@ -23,6 +23,19 @@ def dense_escape_case(groups=96, seed=5):
     return jpegsynth.encode_blocks(coef, 24, np.ones(64, np.uint8), optimize=True)
 
 
+def empty_segment_case():
+    """A 4:2:0 file with restart markers in which one restart marker was taken out and put back right behind the next
+    one: the number of segments still matches the geometry, but one segment holds no byte at all (the chain
+    walk of huff_mh_resolve had no first subsequence to start from). Both walks refuse it."""
+    good = jpegsynth.encode(240, 168, S420, restart_interval=7, seed=9)
+    sos = good.index(b"\xff\xda")
+    marks = [i for i in range(sos, len(good) - 1) if good[i] == 0xFF and 0xD0 <= good[i + 1] <= 0xD7]
+    assert len(marks) >= 4
+    a, b = marks[1], marks[2]
+    # segment 1 and 2 become one (their marker is gone), an empty one follows the next marker
+    return good[:a] + good[a + 2:b + 2] + good[a:a + 2] + good[b + 2:]
+
+
 def matrix():
     """name -> bytes. Small enough for the oracle to finish in well under a second each."""
     e = jpegsynth.encode

@@ -15,7 +15,7 @@ def lib():
     global _lib
     if _lib is None:
         srcs = [os.path.join(_HERE, "emu_pipeline.cpp"), os.path.join(ROOT, "jpeggpu_amd", "csrc", "jg_reader.cpp")]
-        deps = srcs + [os.path.join(ROOT, "jpeggpu_amd", "csrc", h) for h in ("jg_huff_core.h", "jg_defs.h", "jg_reader.hpp")]
+        deps = srcs + [os.path.join(ROOT, "jpeggpu_amd", "csrc", h) for h in ("jg_huff_core.h", "jg_defs.h", "jg_reader.hpp", "jg_bytes.h")]
         if not os.path.exists(_LIB) or any(os.path.getmtime(d) > os.path.getmtime(_LIB) for d in deps):
             subprocess.check_call(["g++", "-O2", "-std=c++17", "-shared", "-fPIC", "-I" + os.path.join(ROOT, "include"),
                                    "-I" + os.path.join(ROOT, "jpeggpu_amd", "csrc")] + srcs + ["-o", _LIB])

@@ -6,6 +6,7 @@
 // write pass with look-back. It has no LDS, no waves and no barriers -- each "iteration" loops over
 // the lanes in order, reading the previous iteration's table -- so it checks the algorithm and the
 // host-built tables, not the kernels' memory layout. The GPU tests check the kernels themselves.
+#include "jg_bytes.h"
 #include "jg_huff_core.h"
 #include "jg_reader.hpp"
 
@@ -137,7 +138,83 @@ void emu_destuff(const uint8_t* bytes, const Scan& sc, int subseq_bytes, std::ve
 
 } // namespace
 
+static std::vector<St> g_pre_tail;       // studies (tools/probe/flow_study.py): the state table between the sequence
+static std::vector<uint8_t> g_pre_pend;  // kernel and the tail pass, and its pending marks
+
 extern "C" {
+
+/// The state table as the tail pass found it in the last emu_decode_scan (p, c | z << 8, pending mark); returns its length.
+int emu_read_pre_tail(int* p, int* cz, uint8_t* pend, int cap)
+{
+    const int n = static_cast<int>(g_pre_tail.size());
+    for (int i = 0; i < n && i < cap; ++i) {
+        p[i]    = g_pre_tail[i].p;
+        cz[i]   = g_pre_tail[i].cz;
+        pend[i] = g_pre_pend[i];
+    }
+    return n;
+}
+
+/// The product's symbol step on 32-bit windows, for the reference-built known answers (tests/test_huff_kats.py): the
+/// table is built from a DHT payload by the parser's own build_huff_table (and widened for the sync pack), looked up the
+/// way the kernels do (jg_huff_core.h: lut16_entry, huff_second_level, huff_long_code, bits_field, extend_bits), and the
+/// result is expressed as the reference's decode_next_symbol reports it. `path`: 0 write pack, 1 sync pack (low halves
+/// of the 32-bit entries), 2 the long-code path for every window (whatever the first level says).
+int emu_symbol_steps(const uint8_t* bits, const uint8_t* vals, int count, int is_dc, int path, const uint32_t* win, const int* z, int n,
+                     int* length, int* symbol, int* run)
+{
+    uint8_t nc[16];
+    std::memcpy(nc, bits, 16);
+    std::vector<uint8_t> t, wide;
+    build_huff_table(t, nc, vals, count, is_dc != 0);
+    widen_huff_table(t, is_dc != 0, wide);
+    const bool dc = is_dc != 0;
+    for (int i = 0; i < n; ++i) {
+        const uint32_t peek = win[i];
+        uint32_t e;
+        if (path == 0) {
+            e = dc ? lut16_entry<kLutBitsDc>(t.data(), peek) : lut16_entry<kLutBitsAc>(t.data(), peek);
+            if ((e & 31u) == 0) e = huff_second_level(t.data(), e, peek, dc);
+        } else if (path == 1) {
+            const uint32_t idx = peek >> (dc ? 32 - kLutBitsDc : 32 - kLutBitsAc);
+            e                  = ld_u16(wide.data() + kSyncEntryBytes * idx);
+            if ((e & 31u) == 0) e = huff_second_level<kSyncEntryBytes>(wide.data(), e, peek, dc);
+        } else {
+            e = huff_long_code(t.data() + (dc ? (2 << kLutBitsDc) : (2 << kLutBitsAc)), peek, dc);
+        }
+        const int total = e & 31, s = (e >> 5) & 15, adv = static_cast<int>(e >> 9);
+        length[i] = total;
+        symbol[i] = s ? extend_bits(bits_field(peek, total, s), s) : 0;
+        run[i]    = dc ? 0 : s ? adv - 1 : adv == 64 ? 63 - z[i] : adv - 1; // an end of block advances to index 64 (jg_defs.h)
+    }
+    return 0;
+}
+
+/// The product's byte rule (jg_bytes.h, as destuff_kernel applies it to four bytes at a time) on (previous byte, byte)
+/// pairs, with the pair placed inside one word (`across` 0) or across two words (1: the carry between words).
+void emu_byte_rule(const uint8_t* prev, const uint8_t* byte, int n, int across, uint8_t* is_data, uint8_t* written)
+{
+    for (int i = 0; i < n; ++i) {
+        // bytes in front of and behind the pair are plain data (0x11) so that only the pair decides
+        uint32_t w0 = across ? 0x11111111u : 0x11111111u, w1 = 0x11111111u;
+        int at; // byte index of `byte` in w1
+        if (across) {
+            w0 = (w0 & 0x00FFFFFFu) | static_cast<uint32_t>(prev[i]) << 24;
+            w1 = (w1 & 0xFFFFFF00u) | byte[i];
+            at = 0;
+        } else {
+            w1 = (w1 & 0xFF0000FFu) | static_cast<uint32_t>(prev[i]) << 8 | static_cast<uint32_t>(byte[i]) << 16;
+            at = 2;
+        }
+        const uint32_t F0 = bytes_ff(w0), F1 = bytes_ff(w1), Z1 = bytes_zero(w1);
+        const uint32_t PF      = of_previous_byte(F1, F0);
+        const uint32_t stuffed = PF & Z1;
+        const uint32_t data    = stuffed | (~(PF | F1) & kHi80);
+        w1 |= spread80(stuffed);
+        is_data[i] = (collapse80(data) >> at) & 1u;
+        written[i] = is_data[i] ? static_cast<uint8_t>(w1 >> (8 * at)) : 0;
+    }
+}
 
 int g_active_hist[512];
 int g_multi_hypothesis = 0; // emu_set_multi_hypothesis: the lone-decode path with the multi-hypothesis table (jg_defs.h)
@@ -356,12 +433,19 @@ int emu_decode_scan(
         }
     }
 
+    g_pre_tail.assign(st.begin(), st.end());
+    g_pre_pend = pend;
     // ---- tail pass (huff_sync_tail): sequence boundaries + pending flows, per part, groups of 256 ----
     for (size_t part = 0; part + 1 < sc.tail_parts.size(); ++part) {
         const int lo = sc.tail_parts[part], hi = sc.tail_parts[part + 1];
         std::vector<int> list;
-        for (int sub = lo; sub < hi; ++sub)
-            if (sub + 1 < S && (pend[sub] || (sub + 1) % T == 0)) list.push_back(sub);
+        for (int sub = lo; sub < hi; ++sub) {
+            if (sub + 1 >= S) continue;
+            // a sequence boundary needs a flow only where the state the next sequence's first entry was decoded from (here:
+            // the speculative table; the device's workgroups record theirs, bnd_p / bnd_cz) is not the stored one
+            const bool boundary = (sub + 1) % T == 0 && segi[sub] == segi[sub + 1] && (spec[sub].p != st[sub].p || spec[sub].cz != st[sub].cz);
+            if (pend[sub] || boundary) list.push_back(sub);
+        }
         for (size_t g = 0; g < list.size(); g += 256) {
             const int nb = static_cast<int>(std::min<size_t>(256, list.size() - g));
             std::vector<Lane> ln(nb);

@@ -443,8 +443,10 @@ def test_device_scan_agrees_with_host_walk_on_refusals(torch_cuda, monkeypatch):
     ffzero = good[:rst] + b"\xff\xff\x00" + good[rst:]          # fill byte followed by a stuffed FF
     cut = good[: len(good) * 2 // 3]
     behind_eoi = good + b"\xff\xff\x00" + bytes(100)             # the same sequence behind the image: not the scan's business
+    empty_seg = cases.empty_segment_case()                       # two restart markers back to back, segment COUNT as the geometry wants
     for name, data, want in (("good", good, Status.SUCCESS), ("ffzero", ffzero, Status.INVALID_JPEG),
-                             ("cut", cut, Status.INVALID_JPEG), ("behind_eoi", behind_eoi, Status.SUCCESS)):
+                             ("cut", cut, Status.INVALID_JPEG), ("behind_eoi", behind_eoi, Status.SUCCESS),
+                             ("empty_segment", empty_seg, Status.INVALID_JPEG)):
         host = jpeggpu_amd.Decoder()
         try:
             host.parse_header(data)
@@ -673,9 +675,12 @@ def test_bench_multi_rank_control_flow_over_gloo(torch_cuda):
     with socket.socket() as s:
         s.bind(("127.0.0.1", 0))
         port = s.getsockname()[1]
-    env = dict(os.environ, JPEGGPU_BENCH_BACKEND="gloo", HSA_ENABLE_IPC_MODE_LEGACY="0")
-    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
-           "--master-port", str(port), os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "2", "--warmup", "1",
+    # started exactly as the driver starts N = 1 -- plain `python bench.py --gpus 2 ...`, no WORLD_SIZE in the environment:
+    # bench.py launches its own ranks as a child process (torch.distributed.run) and exits with its code
+    env = dict(os.environ, JPEGGPU_BENCH_BACKEND="gloo", HSA_ENABLE_IPC_MODE_LEGACY="0", MASTER_PORT=str(port))
+    for k in ("WORLD_SIZE", "RANK", "LOCAL_RANK"):
+        env.pop(k, None)
+    cmd = [sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "2", "--warmup", "1",
            "--batch", "8", "--rounds", "1", "--unique", "2", "--latency-iters", "0", "--other-configs", "0", "--no-cpu", "--e2e-rounds", "0",
            "--roofline-launches", "2", "--gather-rounds", "2", "--segment-shard-rounds", "2"]
     r = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=600)

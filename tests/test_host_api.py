@@ -151,11 +151,15 @@ def test_negative_inputs_same_status_as_oracle(L):
     m = good.find(b"\xff\xda")
     v = bytearray(good); v[m + 6] = 0x33; variants["undefined_table_id"] = v
     v = bytearray(good); v[m + 5] = 9; variants["unknown_component"] = v
+    from tests import cases
+
+    variants["empty_restart_segment"] = cases.empty_segment_case()
     for name, data in variants.items():
         got, want = both(data)
         assert got == want, (name, got, want)
     assert both(variants["progressive"])[0] == Status.NOT_SUPPORTED
     assert both(variants["truncated"])[0] == Status.INVALID_JPEG
+    assert both(variants["empty_restart_segment"])[0] == Status.INVALID_JPEG
 
 
 def test_bytearray_input_is_borrowed_not_copied(L):

@@ -131,3 +131,27 @@ def test_two_rank_segment_bands_over_gloo():
         p.join(120)
         assert p.exitcode == 0
     assert result.get() is True
+
+
+def test_bench_starts_its_own_ranks_when_launched_plainly():
+    """`python bench.py --gpus 2 ...` with no WORLD_SIZE in the environment -- the shape of the driver's N = 1 command --
+    must become the launcher of its own two ranks (a child torch.distributed.run, no exec). There is no GPU here, so
+    each rank gets as far as bench.py's "needs a HIP device" assertion; what is checked is that argument handling did
+    not refuse the command, that two ranks really started, and that the launcher passes their exit code on."""
+    import subprocess
+    import sys
+
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    env = dict(os.environ, MASTER_PORT=str(port), JPEGGPU_BENCH_BACKEND="gloo")
+    for k in ("WORLD_SIZE", "RANK", "LOCAL_RANK"):
+        env.pop(k, None)
+    if torch.cuda.is_available():
+        pytest.skip("covered with a device by tests/test_gpu_api.py::test_bench_multi_rank_control_flow_over_gloo")
+    r = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--workload", "photo", "--no-cpu",
+                        "--steps", "1", "--warmup", "0"], env=env, capture_output=True, text=True, timeout=300)
+    assert "must be launched with" not in r.stderr
+    assert r.returncode != 0  # the ranks' failure is the launcher's
+    assert r.stderr.count("bench.py needs a HIP device") >= 2, r.stderr[-2000:]
