@@ -138,6 +138,7 @@ void emu_destuff(const uint8_t* bytes, const Scan& sc, int subseq_bytes, std::ve
 
 } // namespace
 
+static std::vector<int> g_write_iters, g_write_syms; // write pass, by subsequence: iterations of the lane's loop, symbols it decoded
 static std::vector<St> g_pre_tail;       // studies (tools/probe/flow_study.py): the state table between the sequence
 static std::vector<uint8_t> g_pre_pend;  // kernel and the tail pass, and its pending marks
 
@@ -214,6 +215,17 @@ void emu_byte_rule(const uint8_t* prev, const uint8_t* byte, int n, int across, 
         is_data[i] = (collapse80(data) >> at) & 1u;
         written[i] = is_data[i] ? static_cast<uint8_t>(w1 >> (8 * at)) : 0;
     }
+}
+
+/// Iterations and symbols of every lane of the write pass of the last emu_decode_scan (tools/probe/write_study.py).
+int emu_read_write_iters(int* iters, int* syms, int cap)
+{
+    const int n = static_cast<int>(g_write_iters.size());
+    for (int i = 0; i < n && i < cap; ++i) {
+        iters[i] = g_write_iters[i];
+        syms[i]  = g_write_syms[i];
+    }
+    return n;
 }
 
 int g_active_hist[512];
@@ -509,6 +521,8 @@ int emu_decode_scan(
         tails[b] = acc;
     }
 
+    g_write_iters.assign(S, 0);
+    g_write_syms.assign(S, 0);
     // ---- write pass (huff_write): symbol stream + data-unit table, then gather like the IDCT does ----
     const uint32_t region = sym_region_entries(subseq_bytes);
     std::vector<uint16_t> sym(static_cast<size_t>(S) * region, 0xDEADu);
@@ -562,7 +576,10 @@ int emu_decode_scan(
                 ls.z = st[sub - 1].cz >> 8;
             }
             HostWindow win{HostFetch{dst.data() + static_cast<size_t>(seg.subseq_offset) * subseq_bytes, seg.subseq_count * W}};
-            decode_units(ls, win, tabs, sp, sink, 2 * (bits + 64 * 32));
+            int it[4] = {0, 0, 0, 0};
+            decode_units(ls, win, tabs, sp, sink, 2 * (bits + 64 * 32), it);
+            g_write_iters[sub] = it[0];
+            g_write_syms[sub]  = it[1];
             sink.unit_boundary(); // nothing is left open when the lane stops (it stops in a DC slot), but say so
         }
     }
