@@ -847,7 +847,9 @@ def main():
             photo_bytes = f.read()
         for name, blob in (("config1_photo_12MP_420_dri252", photo_bytes),
                            ("config4_39MP_444_three_scans", jpegsynth.config(4)),
-                           ("config5_12MP_4_components_8_tables_no_dri", jpegsynth.config(5))):
+                           ("config5_12MP_4_components_8_tables_no_dri", jpegsynth.config(5)),
+                           ("cfg2_geometry_without_restart_markers_12MP_420", jpegsynth.encode(
+                               4032, 3024, ((2, 2), (1, 1), (1, 1)), True, 0, quality=88, noise=9, seed=0))):
             r = latency_probe(args, torch, jp, blob, device, streams[0], device_scan=False)
             others[name] = {"file_bytes": len(blob), "p50_ms": r["p50"], "p50_host_parse_ms": r["p50_host_parse"],
                             "max_ms": r["max"], "iters": r["iters"], "subsequence_bytes": r["subsequence_bytes"],

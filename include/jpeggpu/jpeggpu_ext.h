@@ -81,9 +81,12 @@ struct jpeggpu_ext_scan_layout {
     size_t off_device_status;
     /* Candidates per subsequence of the multi-hypothesis speculation that a lone decode (jpeggpu_decoder_decode) of this
      * scan runs in front of its synchronisation -- one per data unit of the MCU --, 0 where it does not apply (one data
-     * unit per MCU, no restart segments, a decoder for batches) or JPEGGPU_MULTI_HYPOTHESIS=0 switched it
-     * off at startup. */
+     * unit per MCU, a decoder for batches, a device-scanned image without restart markers, a scan of more than 256 blocks)
+     * or JPEGGPU_MULTI_HYPOTHESIS=0 switched it off at startup. */
     int hypotheses;
+    /* Blocks of the block-wise chain walk: 0 where every restart segment has at most 1024 subsequences (one workgroup
+     * walks a segment), else the scan's segments cut into blocks of 1024 (a scan without restart markers is one segment). */
+    int hypothesis_blocks;
 };
 
 struct jpeggpu_ext_layout {

@@ -49,7 +49,7 @@ class ExtScanLayout(C.Structure):
         ("off_state_cz", C.c_size_t), ("off_state_dc01", C.c_size_t), ("off_state_dc23", C.c_size_t),
         ("off_symbols", C.c_size_t), ("off_du_table", C.c_size_t), ("symbol_region_entries", C.c_int),
         ("device_scan", C.c_int), ("off_device_status", C.c_size_t),
-        ("hypotheses", C.c_int),
+        ("hypotheses", C.c_int), ("hypothesis_blocks", C.c_int),
     ]
 
 

@@ -75,6 +75,8 @@ struct ScanPlan {
     size_t tails_n = 0, tails_dc01 = 0, tails_dc23 = 0, pending = 0, flow_list = 0, bnd_p = 0, bnd_cz = 0;
     size_t sym = 0, du_tab = 0;
     size_t mh_p = 0, mh_cz = 0, mh_link = 0, mh_pool = 0, mh_known = 0; // multi-hypothesis speculation (jg_defs.h), if mh > 1
+    size_t blob_mh_blocks = 0, mh_blk_exit = 0, mh_blk_entry = 0;        // its block-wise chain walk, if mh_blocks is not empty
+    std::vector<jg::MhBlock> mh_blocks;
     int mh = 0, max_seg_subseq = 0;
     int num_seq = 0;
     // device-side front end (jg_front.hip): tables built on the device, scratch, the job and the status word
@@ -155,6 +157,55 @@ void Decoder::make_plan()
         b += align_up(sc.chunks.size() * sizeof(DestuffChunk), 256);
         sp.blob_parts     = b;
         b += align_up(sc.tail_parts.size() * sizeof(int), 256);
+        // Multi-hypothesis speculation (jg_defs.h) for an image decoded on its own: several data units per MCU. Segments
+        // the chain walk can hold in LDS are walked whole; longer ones (a scan without restart markers is one segment) in
+        // blocks whose descriptors travel with the blob.
+        sp.mh = 0;
+        sp.mh_blocks.clear();
+        // What the speculation buys depends on how long a decoder that is off by some data units stays undetected: as long
+        // as the units it confuses share their code tables. `run` = the longest run of consecutive data units of the MCU
+        // with the same tables: 4 for 4:2:0 (Y Y Y Y), 2 for 4:2:2 (Y Y | Cb Cr) and 4:4:4 (Cb Cr). Sync stage of one 12 MP
+        // image, speculation on / off (us, round 4): 4:2:0 with restart markers 137 / 294, without (block-wise walk)
+        // 186 / 278; 4:2:2 117 / 138 and 161 / 133; 4:4:4 95 / 62 and 133 / 75; BASELINE configs[4] (4 components, runs of
+        // 2, no restart markers) 204 / 140. So: runs of three and more always; runs of two only in the cheaper whole-segment
+        // form and only with four units or more per MCU.
+        int run = 1;
+        {
+            int du_tabs[2 * kMaxDuPerMcu], m = 0;
+            for (int rep = 0; rep < 2; ++rep)
+                for (int a = 0; a < sc.num_comp; ++a)
+                    for (int k = 0; k < sc.comp[a].h * sc.comp[a].v && m < 2 * kMaxDuPerMcu; ++k) du_tabs[m++] = sc.comp[a].dc_id * 4 + sc.comp[a].ac_id;
+            for (int i = 1, cur = 1; i < m; ++i) {
+                cur = du_tabs[i] == du_tabs[i - 1] ? cur + 1 : 1;
+                run = std::max(run, std::min(cur, sc.du_per_mcu));
+            }
+        }
+        if (!batched && sc.du_per_mcu >= 2 && sc.du_per_mcu <= kMhMaxHyp && mh_enabled && run >= 2) {
+            int longest = sc.device_walk ? kMhMaxSegSubseq : 0; // the device finds the segments: it falls back where one is longer
+            for (const Segment& g : sc.segments) longest = std::max(longest, g.subseq_count);
+            if (sc.device_walk && s.restart_interval == 0) longest = kMhMaxSegSubseq + 1; // one segment of unknown length, tables on the device: no
+            if (longest <= kMhMaxSegSubseq && run < 3 && sc.du_per_mcu < 4) longest = -1; // (runs of two: four units and more)
+            if (longest > kMhMaxSegSubseq && run < 3) longest = -1;                       // (block-wise: runs of three and more)
+            if (longest < 0) {
+            } else if (longest <= kMhMaxSegSubseq) {
+                sp.mh             = sc.du_per_mcu;
+                sp.max_seg_subseq = longest;
+            } else if (!sc.device_walk) {
+                for (const Segment& g : sc.segments) {
+                    for (int r = 0; r < g.subseq_count; r += kMhMaxSegSubseq)
+                        sp.mh_blocks.push_back(MhBlock{g.subseq_offset + r, std::min(kMhMaxSegSubseq, g.subseq_count - r),
+                                                       g.subseq_offset + g.subseq_count, r == 0 ? 1 : 0});
+                }
+                if (sp.mh_blocks.size() <= static_cast<size_t>(kMhMaxBlocks)) {
+                    sp.mh             = sc.du_per_mcu;
+                    sp.max_seg_subseq = kMhMaxSegSubseq;
+                    sp.blob_mh_blocks = b;
+                    b += align_up(sp.mh_blocks.size() * sizeof(MhBlock), 256);
+                } else {
+                    sp.mh_blocks.clear();
+                }
+            }
+        }
     }
     p.blob_size = b;
 
@@ -198,26 +249,23 @@ void Decoder::make_plan()
         o += align_up(static_cast<size_t>(sp.num_seq) * 4, 256);
         sp.bnd_cz = o;
         o += align_up(static_cast<size_t>(sp.num_seq) * 4, 256);
-        // Multi-hypothesis speculation (jg_defs.h) for an image decoded on its own: several data units per MCU,
-        // restart segments the chain walk can hold in LDS.
-        sp.mh = 0;
-        if (!batched && sc.du_per_mcu >= 2 && sc.du_per_mcu <= kMhMaxHyp && s.restart_interval != 0 && mh_enabled) {
-            int longest = sc.device_walk ? kMhMaxSegSubseq : 0; // the device finds the segments: it falls back where one is longer
-            for (const Segment& g : sc.segments) longest = std::max(longest, g.subseq_count);
-            if (longest <= kMhMaxSegSubseq) {
-                sp.mh             = sc.du_per_mcu;
-                sp.max_seg_subseq = longest;
-                const size_t N    = S * static_cast<size_t>(sp.mh);
-                sp.mh_p           = o;
-                o += align_up(N * 4, 256);
-                sp.mh_cz = o;
-                o += align_up(N * 4, 256);
-                sp.mh_link = o;
-                o += align_up(N * 4, 256);
-                sp.mh_pool = o;
-                o += align_up((1 + static_cast<size_t>(mh_pool_entries(static_cast<uint32_t>(S)))) * sizeof(uint2_t), 256);
-                sp.mh_known = o;
-                o += align_up(S, 256);
+        if (sp.mh > 1) { // multi-hypothesis speculation (decided with the blob, above)
+            const size_t N = S * static_cast<size_t>(sp.mh);
+            sp.mh_p        = o;
+            o += align_up(N * 4, 256);
+            sp.mh_cz = o;
+            o += align_up(N * 4, 256);
+            sp.mh_link = o;
+            o += align_up(N * 4, 256);
+            sp.mh_pool = o;
+            o += align_up((1 + static_cast<size_t>(mh_pool_entries(static_cast<uint32_t>(S)))) * sizeof(uint2_t), 256);
+            sp.mh_known = o;
+            o += align_up(S, 256);
+            if (!sp.mh_blocks.empty()) {
+                sp.mh_blk_exit = o;
+                o += align_up(sp.mh_blocks.size() * 64 * sizeof(uint16_t), 256);
+                sp.mh_blk_entry = o;
+                o += align_up(sp.mh_blocks.size() * sizeof(uint16_t), 256);
             }
         }
         if (sc.device_walk) {
@@ -294,6 +342,8 @@ bool Decoder::fill_blob()
             std::memcpy(blob.ptr + sp.blob_chunks, sc.chunks.data(), sc.chunks.size() * sizeof(DestuffChunk));
         if (!sc.tail_parts.empty())
             std::memcpy(blob.ptr + sp.blob_parts, sc.tail_parts.data(), sc.tail_parts.size() * sizeof(int));
+        if (!sp.mh_blocks.empty())
+            std::memcpy(blob.ptr + sp.blob_mh_blocks, sp.mh_blocks.data(), sp.mh_blocks.size() * sizeof(MhBlock));
     }
     return true;
 }
@@ -369,6 +419,10 @@ jpeggpu_status build_jobs(
         job.mh_link         = reinterpret_cast<uint32_t*>(base + pl.mh_link);
         job.mh_pool         = reinterpret_cast<uint2_t*>(base + pl.mh_pool);
         job.mh_known        = base + pl.mh_known;
+        job.num_mh_blocks   = lone ? static_cast<int>(pl.mh_blocks.size()) : 0;
+        job.mh_blocks       = job.num_mh_blocks ? reinterpret_cast<const MhBlock*>(blob + pl.blob_mh_blocks) : nullptr;
+        job.mh_blk_exit     = reinterpret_cast<uint16_t*>(base + pl.mh_blk_exit);
+        job.mh_blk_entry    = reinterpret_cast<uint16_t*>(base + pl.mh_blk_entry);
         IdctParams& ip = job.ip;
         ip.num_du      = sc.num_du;
         ip.du_per_mcu  = sc.du_per_mcu;
@@ -797,6 +851,7 @@ enum jpeggpu_status jpeggpu_ext_get_layout(jpeggpu_decoder_t decoder, struct jpe
         o.symbol_region_entries = static_cast<int>(jg::sym_region_entries(d.subseq_bytes));
         o.device_scan           = sc.device_walk ? 1 : 0;
         o.hypotheses            = pl.mh;
+        o.hypothesis_blocks     = static_cast<int>(pl.mh_blocks.size());
         if (sc.device_walk) {
             o.num_segments      = sc.expect_segments;
             o.num_chunks        = sc.max_chunks;

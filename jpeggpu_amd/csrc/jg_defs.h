@@ -290,7 +290,21 @@ constexpr int kMhMaxHyp        = 8;    // 4-bit candidate index; more data units
 #define JG_MH_STEPS 8
 #endif
 constexpr int kMhSteps         = JG_MH_STEPS; // subsequences a candidate's flow runs before it gives up
-constexpr int kMhMaxSegSubseq  = 1024; // the chain walk of a segment happens in LDS
+constexpr int kMhMaxSegSubseq  = 1024; // the chain walk of a segment -- or of one BLOCK of a longer segment -- happens in LDS
+/// Segments longer than that (a scan without restart markers is ONE segment) are walked BLOCK-WISE: every block of up to
+/// kMhMaxSegSubseq subsequences first works out, for each of the 64 nodes (candidate h, row 0..7) the chain can enter it
+/// at, where the chain leaves it (huff_mh_block_maps: pointer jumping inside the block); one workgroup strings the
+/// blocks' maps together (huff_mh_block_chain: block b's entry node = block b - 1's exit for ITS entry node, from node
+/// (0, 0) at the segment's start); then every block walks its part of the chain from its entry node as a short segment
+/// would (huff_mh_resolve). Three launches instead of one, whatever the segment's length.
+constexpr int kMhMaxBlocks     = 256;  // blocks of one scan (their maps are chained in LDS): 16 MB of scan at 64-byte subsequences
+constexpr uint32_t kMhBlockBroken = 0xFFFEu; // entry of a block behind the point where the chain broke off
+struct MhBlock {
+    int first;    // first subsequence of the block
+    int count;    // subsequences in it
+    int seg_end;  // one past the last subsequence of its segment
+    int opens;    // 1: the block starts its segment (entry node (0, 0))
+};
 constexpr uint32_t kMhNoLink   = 0;
 constexpr uint32_t kMhNoPool   = 0xFFFFFFu; // 24-bit pool index
 JG_HD inline uint32_t mh_pool_entries(uint32_t num_subseq) { return 2u * num_subseq + 64u; } // states; one counter in front
@@ -370,6 +384,10 @@ struct ScanJob {
     uint32_t* mh_link;           //   their links,
     uint2_t* mh_pool;            //   [1 + mh_pool_entries]: entry 0.x counts the states handed out, states from entry 1 on
     uint8_t* mh_known;           //   [num_subseq]: the table entry is a state of the resolved chain
+    const MhBlock* mh_blocks;    //   block-wise chain walk (segments longer than kMhMaxSegSubseq): [num_mh_blocks], else null
+    uint16_t* mh_blk_exit;       //   [num_mh_blocks][64]: where the chain leaves a block it enters at node h << 3 | row
+    uint16_t* mh_blk_entry;      //   [num_mh_blocks]: the node it really enters at, or kMhBlockBroken
+    int num_mh_blocks;
     uint16_t* sym;               // symbol stream: one region of `sym_region` 16-bit entries per subsequence, interleaved (above)
     uint2_t* du_tab;             // per data unit (stream order): {physical index of the first entry, number of entries}
     uint32_t sym_region;         // entries per subsequence region

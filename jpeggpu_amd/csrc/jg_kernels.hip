@@ -89,6 +89,10 @@ struct JobView {
     JG_GLOBAL uint32_t* mh_link;
     JG_GLOBAL uint2_t* mh_pool;
     JG_GLOBAL uint8_t* mh_known;
+    JG_GLOBAL const MhBlock* mh_blocks;
+    JG_GLOBAL uint16_t* mh_blk_exit;
+    JG_GLOBAL uint16_t* mh_blk_entry;
+    int num_mh_blocks;
     JG_GLOBAL uint16_t* sym;
     JG_GLOBAL uint2_t* du_tab;
     uint32_t sym_region;
@@ -105,6 +109,7 @@ struct JobView {
           bnd_p(as_global(j.bnd_p)), bnd_cz(as_global(j.bnd_cz)), flow_list(as_global(j.flow_list)), tail_parts(as_global(j.tail_parts)), num_tail_parts(j.num_tail_parts),
           tails_n(as_global(j.tails_n)), tails_dc01(as_global(j.tails_dc01)), tails_dc23(as_global(j.tails_dc23)),
           mh_p(as_global(j.mh_p)), mh_cz(as_global(j.mh_cz)), mh_link(as_global(j.mh_link)), mh_pool(as_global(j.mh_pool)), mh_known(as_global(j.mh_known)),
+          mh_blocks(as_global(j.mh_blocks)), mh_blk_exit(as_global(j.mh_blk_exit)), mh_blk_entry(as_global(j.mh_blk_entry)), num_mh_blocks(j.num_mh_blocks),
           sym(as_global(j.sym)), du_tab(as_global(j.du_tab)), sym_region(j.sym_region), sym_entries(j.sym_entries),
           num_chunks(j.num_chunks), num_seq(j.num_seq), sp(j.sp), ip(j.ip)
     {
@@ -1058,8 +1063,85 @@ __host__ __device__ constexpr size_t mh_resolve_lds(int H, int n)
     return static_cast<size_t>(H) * n * 8 + static_cast<size_t>(n) * 5 + static_cast<size_t>(n / 16 + 4) * 2 + 64;
 }
 
-/// The chain: one workgroup per restart segment loads the segment's links into LDS and follows them from the first
-/// subsequence's hypothesis 0; everybody then writes the table huff_sync_intra starts from: the candidate the chain
+// values of the successor tables (16 bits): a node h * n + r of the range at hand, or one of
+constexpr uint32_t kMhEnd = 0xFFFFu, kMhBreak = 0xFFFEu; // the segment ends / the candidate met none within kMhSteps
+constexpr uint32_t kMhExit = 0x8000u;                      // | h << 3 | row: the link leaves the BLOCK, into that node of the next one
+static_assert(kMhMaxHyp * kMhMaxSegSubseq <= static_cast<int>(kMhExit) && kMhMaxHyp <= 8 && kMhSteps <= 8, "node ids, exit codes");
+
+/// Successor of node (q, r) of the range [first, first + n) of a segment that ends at seg_end, from its link.
+__device__ __forceinline__ uint32_t mh_successor(uint32_t l, int r, int n, int first, int seg_end)
+{
+    const int k = static_cast<int>(l & 15u), r2 = r + k;
+    if (k == 0) return kMhBreak;
+    if (first + r2 >= seg_end) return kMhEnd;
+    const uint32_t g = (l >> 4) & 15u;
+    return r2 < n ? g * static_cast<uint32_t>(n) + static_cast<uint32_t>(r2) : kMhExit | g << 3 | static_cast<uint32_t>(r2 - n);
+}
+
+/// Block-wise chain walk, step 1 (jg_defs.h): one workgroup per block; for each of the 64 nodes (h, row 0..7) the chain can
+/// enter the block at, where it leaves it -- an exit code into the next block, the segment's end, or a break. Every node's
+/// successor is squared ceil(log2 n) times (pointer jumping; exits, ends and breaks absorb).
+template <class JS>
+__global__ __launch_bounds__(256) void huff_mh_block_maps(JS js)
+{
+    extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
+    const JobView J(js.get());
+    if (static_cast<int>(blockIdx.x) >= J.num_mh_blocks) return;
+    const MhBlock blk = ld_global(J.mh_blocks + blockIdx.x);
+    const int n = blk.count, first = blk.first, S = J.sp.num_subseq, H = J.sp.mh, nodes = H * n;
+    uint16_t* s_a = reinterpret_cast<uint16_t*>(smem); // [nodes] (ping-pong)
+    uint16_t* s_b = s_a + nodes;
+    const int t   = threadIdx.x;
+    for (int i = t; i < nodes; i += 256) {
+        const int q = i / n, r = i - q * n;
+        s_a[i]      = static_cast<uint16_t>(mh_successor(J.mh_link[static_cast<size_t>(q) * S + first + r], r, n, first, blk.seg_end));
+    }
+    __syncthreads();
+    for (int span = 1; span < n; span <<= 1) {
+        for (int i = t; i < nodes; i += 256) {
+            const uint32_t a = s_a[i];
+            s_b[i]           = static_cast<uint16_t>(a >= kMhExit ? a : s_a[a]);
+        }
+        __syncthreads();
+        uint16_t* sw = s_a;
+        s_a          = s_b;
+        s_b          = sw;
+    }
+    if (t < 64) {
+        const int h = t >> 3, r = t & 7;
+        J.mh_blk_exit[static_cast<size_t>(blockIdx.x) * 64 + t] = static_cast<uint16_t>(h < H && r < n ? s_a[h * n + r] : kMhBreak);
+    }
+}
+
+/// Step 2: one workgroup strings the maps together. A segment's first block is entered at node (0, 0) -- hypothesis 0 of a
+/// segment's first subsequence is exact --, block b at what block b - 1 says for ITS entry node; behind a break every
+/// block of the segment is marked kMhBlockBroken (plain speculation there).
+template <class JS>
+__global__ __launch_bounds__(256) void huff_mh_block_chain(JS js)
+{
+    extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
+    const JobView J(js.get());
+    const int nb    = J.num_mh_blocks;
+    uint16_t* s_map = reinterpret_cast<uint16_t*>(smem); // [nb][64]
+    int* s_opens    = reinterpret_cast<int*>(s_map + static_cast<size_t>(nb) * 64);
+    for (int i = threadIdx.x; i < nb * 64; i += 256) s_map[i] = J.mh_blk_exit[i];
+    for (int i = threadIdx.x; i < nb; i += 256) s_opens[i] = ld_global(J.mh_blocks + i).opens;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        uint32_t entry = 0;
+        for (int b = 0; b < nb; ++b) {
+            if (s_opens[b]) entry = 0;
+            J.mh_blk_entry[b] = static_cast<uint16_t>(entry);
+            if (entry == kMhBlockBroken) continue;
+            const uint32_t x = s_map[b * 64 + entry];
+            entry            = x == kMhBreak ? kMhBlockBroken : x == kMhEnd ? 0u : x & 63u; // (behind an end a segment opens)
+        }
+    }
+}
+
+/// The chain: one workgroup per restart segment (kBlocks: per block of the block-wise walk, from the entry node the two
+/// kernels above found) loads the range's links into LDS and follows them from the entry node -- the first subsequence's
+/// hypothesis 0 for a whole segment --; everybody then writes the table huff_sync_intra starts from
 /// (in the rows of hypothesis 0 of mh_p / mh_cz): the candidate the chain
 /// passes through where it does, the state a hopping flow left in the pool where the chain hopped over a subsequence
 /// (both `mh_known`), hypothesis 0 as a placeholder where it hopped and the pool was full, and the plain speculation
@@ -1069,19 +1151,35 @@ __host__ __device__ constexpr size_t mh_resolve_lds(int H, int n)
 /// whole point is a shorter critical path. So the links are squared four times first (every node gets its 16th
 /// successor: pointer jumping, all lanes), one lane walks those -- n / 16 steps -- and leaves an ANCHOR every 16
 /// links, and the lanes then walk the 16 links behind each anchor in parallel.
-template <class JS>
+template <class JS, bool kBlocks>
 __global__ __launch_bounds__(256) void huff_mh_resolve(JS js)
 {
     extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
     __shared__ int s_broke, s_anchors; // first subsequence behind the point where the chain broke off (n: nowhere); anchors
     const JobView J(js.get());
     const ScanParams& sp = J.sp;
-    if (static_cast<int>(blockIdx.x) >= sp.num_segments) return;
-    const Segment seg = ld_global(J.segments + blockIdx.x);
-    const int n = seg.subseq_count, base = seg.subseq_offset, S = sp.num_subseq, H = sp.mh;
+    int n, base, seg_end, row0 = 0; // the range, its segment's end, the row the chain enters it at
+    uint32_t entry = 0;             // ... as a node
+    if (kBlocks) {
+        if (static_cast<int>(blockIdx.x) >= J.num_mh_blocks) return;
+        const MhBlock blk = ld_global(J.mh_blocks + blockIdx.x);
+        n       = blk.count;
+        base    = blk.first;
+        seg_end = blk.seg_end;
+        entry   = J.mh_blk_entry[blockIdx.x];
+    } else {
+        if (static_cast<int>(blockIdx.x) >= sp.num_segments) return;
+        const Segment seg = ld_global(J.segments + blockIdx.x);
+        n       = seg.subseq_count;
+        base    = seg.subseq_offset;
+        seg_end = base + n;
+    }
+    const int S = sp.num_subseq, H = sp.mh;
     if (n <= 0) return; // (both walks refuse a segment without data; block-uniform, before anything is carved for n nodes)
-    if (n > kMhMaxSegSubseq) { // (only a device-scanned image can get here: the host walk knows its segments) plain speculation
-        for (int r = threadIdx.x; r < n; r += 256) J.mh_known[base + r] = 1; // hypothesis 0's rows are the table (below)
+    if (n > kMhMaxSegSubseq || entry == kMhBlockBroken) {
+        // plain speculation: hypothesis 0's rows are the table (a segment too long for this kernel: only a device-scanned
+        // image can get here, the host walk knows its segments and asks for blocks; a block behind a break)
+        for (int r = threadIdx.x; r < n; r += 256) J.mh_known[base + r] = 1;
         return;
     }
     const int nodes  = H * n;                                               // node (h, r) = h * n + r
@@ -1091,14 +1189,17 @@ __global__ __launch_bounds__(256) void huff_mh_resolve(JS js)
     uint16_t* s_jb   = s_ja + nodes;
     uint16_t* s_anc  = s_jb + nodes;                                         // [n / 16 + 2]: h << 12 | r of every 16th node of the chain
     uint8_t* s_hyp   = reinterpret_cast<uint8_t*>(s_anc + (n / 16 + 4));     // [n]: candidate the chain passes through, 0xFF none
-    constexpr uint32_t kEnd = 0xFFFFu, kBreak = 0xFFFEu;
     const int t = threadIdx.x;
+    if (kBlocks) {
+        row0  = static_cast<int>(entry & 7u);
+        entry = (entry >> 3) * static_cast<uint32_t>(n) + static_cast<uint32_t>(row0);
+    }
     for (int i = t; i < nodes; i += 256) {
         const int q = i / n, r = i - q * n;
         const uint32_t l = J.mh_link[static_cast<size_t>(q) * S + base + r];
         s_link[i]        = l;
-        const int k = static_cast<int>(l & 15u), r2 = r + k;
-        s_ja[i] = static_cast<uint16_t>(k == 0 ? kBreak : r2 >= n ? kEnd : ((l >> 4) & 15u) * n + r2);
+        const uint32_t x = mh_successor(l, r, n, base, seg_end);
+        s_ja[i]          = static_cast<uint16_t>(x >= kMhExit && x < kMhBreak ? kMhEnd : x); // (for the walk an exit is an end)
     }
     for (int r = t; r < n; r += 256) {
         s_hyp[r] = 0xFF;
@@ -1109,7 +1210,7 @@ __global__ __launch_bounds__(256) void huff_mh_resolve(JS js)
     for (int round = 0; round < 4; ++round) { // successor -> 16th successor
         for (int i = t; i < nodes; i += 256) {
             const uint32_t a = s_ja[i];
-            s_jb[i]          = static_cast<uint16_t>(a >= kBreak ? a : s_ja[a]);
+            s_jb[i]          = static_cast<uint16_t>(a >= kMhBreak ? a : s_ja[a]);
         }
         __syncthreads();
         uint16_t* sw = s_ja;
@@ -1118,8 +1219,8 @@ __global__ __launch_bounds__(256) void huff_mh_resolve(JS js)
     }
     if (t == 0) {
         int m = 0;
-        uint32_t a = 0; // node (0, 0): hypothesis 0 of the segment's first subsequence is exact
-        while (a < kBreak && m <= n / 16 + 1) { // (an anchor every 16 links of a chain of at most n: the bound is belt and braces)
+        uint32_t a = entry; // node (0, 0) of a segment: hypothesis 0 of its first subsequence is exact
+        while (a < kMhBreak && m <= n / 16 + 1) { // (an anchor every 16 links of a chain of at most n: the bound is belt and braces)
             const uint32_t h = a / n;
             s_anc[m++]       = static_cast<uint16_t>(h << 12 | (a - h * n));
             a                = s_ja[a];
@@ -1138,7 +1239,22 @@ __global__ __launch_bounds__(256) void huff_mh_resolve(JS js)
                 break;
             }
             const uint32_t pool = l >> 8;
-            for (int q = 1; q < k && r + q < n; ++q) s_src[r + q] = pool == kMhNoPool ? 0u : 1u + pool + static_cast<uint32_t>(q - 1);
+            for (int q = 1; q < k && base + r + q < seg_end; ++q) {
+                const uint32_t src = pool == kMhNoPool ? 0u : 1u + pool + static_cast<uint32_t>(q - 1);
+                if (r + q < n) {
+                    s_src[r + q] = src;
+                } else {
+                    // (block-wise walk) a subsequence of the NEXT block the chain hops over: this workgroup writes its
+                    // table entry, the next block's leaves the rows in front of its entry row alone
+                    const int sub = base + r + q;
+                    if (src != 0) {
+                        const uint2_t e = ld_global(J.mh_pool + src);
+                        J.mh_p[sub]     = static_cast<int>(e.x);
+                        J.mh_cz[sub]    = static_cast<int>(e.y);
+                    }
+                    J.mh_known[sub] = src != 0 ? 1 : 0;
+                }
+            }
             r += k;
             if (r >= n) break;
             h = static_cast<int>((l >> 4) & 15u);
@@ -1151,7 +1267,7 @@ __global__ __launch_bounds__(256) void huff_mh_resolve(JS js)
     // downstream was derived from.
     for (int r = s_broke + t; r < n; r += 256) s_hyp[r] = 0;
     __syncthreads();
-    for (int r = t; r < n; r += 256) {
+    for (int r = row0 + t; r < n; r += 256) { // (rows in front of the entry row belong to the previous block's workgroup)
         const int h = s_hyp[r];
         int p, cz;
         bool known = true;
@@ -1227,9 +1343,15 @@ __global__ __launch_bounds__(TL) void huff_sync_tail(JS js)
     // Ordered list of flow origins in [lo, hi): the marks huff_sync_intra left, and the sequence boundaries at which the
     // exit state the following sequence's workgroup assumed for its predecessor (bnd_p / bnd_cz) is not the one stored:
     // where it is, the sequence's first entry was derived from the stored state already and a flow could only confirm it.
+    // (A decode that keeps every flow in its sequence's workgroup -- a lone decode: max_intra_iters is the lane count --
+    // leaves no marks: only the last subsequence of every sequence is looked at, one round of the loop instead of one per
+    // TL subsequences: 48 000 subsequences of a 12 MP scan without restart markers are ONE part, and building its list took
+    // 60 of the kernel's 70 us.)
+    const bool marks = sp.max_intra_iters < T;
+    const int step   = marks ? 1 : SEQ;
     int count = 0;
-    for (int base = lo; base < hi; base += TL) {
-        const int sub = base + tid;
+    for (int base = marks ? lo : (lo + SEQ) / SEQ * SEQ - 1; base < hi; base += TL * step) {
+        const int sub = base + tid * step;
         bool f        = sub < hi && sub + 1 < sp.num_subseq;
         if (f) {
             f = J.pending[sub] != 0;
@@ -2221,8 +2343,17 @@ hipError_t launch_mh_w(const JS& js, const ScanJob& job, int max_seg_subseq, hip
     huff_mh_spec<W, JS><<<grid, T, lds, stream>>>(js);
     huff_mh_flow<W, JS><<<grid, T, lds, stream>>>(js);
     const size_t rlds = mh_resolve_lds(job.sp.mh, max_seg_subseq);
-    if ((err = allow_lds(huff_mh_resolve<JS>, rlds)) != hipSuccess) return err;
-    huff_mh_resolve<JS><<<job.sp.num_segments, 256, rlds, stream>>>(js);
+    if (job.num_mh_blocks > 0) { // segments longer than the chain walk's LDS: block by block (jg_defs.h)
+        const size_t mlds = static_cast<size_t>(job.sp.mh) * kMhMaxSegSubseq * 4, clds = static_cast<size_t>(job.num_mh_blocks) * (128 + 4);
+        if ((err = allow_lds(huff_mh_block_maps<JS>, mlds)) != hipSuccess) return err;
+        if ((err = allow_lds(huff_mh_resolve<JS, true>, rlds)) != hipSuccess) return err;
+        huff_mh_block_maps<JS><<<job.num_mh_blocks, 256, mlds, stream>>>(js);
+        huff_mh_block_chain<JS><<<1, 256, clds, stream>>>(js);
+        huff_mh_resolve<JS, true><<<job.num_mh_blocks, 256, rlds, stream>>>(js);
+        return hipGetLastError();
+    }
+    if ((err = allow_lds(huff_mh_resolve<JS, false>, rlds)) != hipSuccess) return err;
+    huff_mh_resolve<JS, false><<<job.sp.num_segments, 256, rlds, stream>>>(js);
     return hipGetLastError();
 }
 

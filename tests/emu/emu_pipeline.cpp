@@ -324,10 +324,15 @@ int emu_decode_scan(
     std::vector<uint8_t> known(S, 1);
     bool mh = false;
     g_mh_known = g_mh_subseq = 0;
-    if (g_multi_hypothesis && max_intra_iters >= kSeqLanes && sc.du_per_mcu >= 2 && sc.du_per_mcu <= kMhMaxHyp && s.restart_interval != 0) {
-        int longest = 0;
-        for (const Segment& g : sc.segments) longest = std::max(longest, g.subseq_count);
-        mh = longest <= kMhMaxSegSubseq;
+    if (g_multi_hypothesis && max_intra_iters >= kSeqLanes && sc.du_per_mcu >= 2 && sc.du_per_mcu <= kMhMaxHyp) {
+        // (segments of more than kMhMaxSegSubseq subsequences are walked block-wise on the device -- up to kMhMaxBlocks
+        // blocks --, which is the same chain: here it is followed link by link whatever its length)
+        int longest = 0, blocks = 0;
+        for (const Segment& g : sc.segments) {
+            longest = std::max(longest, g.subseq_count);
+            blocks += (g.subseq_count + kMhMaxSegSubseq - 1) / kMhMaxSegSubseq;
+        }
+        mh = longest <= kMhMaxSegSubseq || blocks <= kMhMaxBlocks;
     }
     if (mh) {
         const int H = sc.du_per_mcu;

@@ -618,6 +618,46 @@ def test_baseline_configs_full_size(torch_cuda, cfg):
             assert np.array_equal(planes[c].cpu().numpy(), ref.planes[c]), (cfg, c, device_scan)
 
 
+def test_block_wise_multi_hypothesis_walk_without_restart_markers(torch_cuda, monkeypatch):
+    """Scans without restart markers -- most JPEGs in the wild -- are ONE segment: the multi-hypothesis chain is walked
+    block by block (huff_mh_block_maps / _chain / huff_mh_resolve per block, jg_defs.h). A 12 MP 4:2:0 file without DRI
+    (~45 blocks of 1024 subsequences at 64 bytes), BASELINE configs[4] (4 components, 8 tables) and a restart interval
+    long enough for segments of more than 1024 subsequences: the layout says the blocks are used, planes bit-exact vs the
+    oracle at three subsequence sizes, and the same with the speculation switched off."""
+    import jpeggpu_amd
+    from oracle import oracle
+    from tools import jpegsynth
+
+    S420 = ((2, 2), (1, 1), (1, 1))
+    inputs = {"12mp_nodri": jpegsynth.encode(4032, 3024, S420, True, 0, quality=88, noise=9, seed=77),
+              "411_nodri": jpegsynth.encode(2560, 1920, ((4, 1), (1, 1), (1, 1)), True, 0, quality=90, noise=10, seed=79),
+              "long_segments": jpegsynth.encode(2048, 1536, S420, True, 128 * 24, quality=92, noise=12, seed=78)}
+    for name, data in inputs.items():
+        ref = oracle.decode(data)
+        for sb in (0, 32, 128):
+            planes, _, _tmp, _base, lay = jpeggpu_amd.decode_to_planes(data, subseq_bytes=sb, return_tmp=True)
+            sc = lay.scans[0]
+            assert sc.hypotheses == sc.data_units_per_mcu == 6, (name, sb)
+            assert sc.hypothesis_blocks >= (sc.num_subsequences + 1023) // 1024 > 1, (name, sb, sc.hypothesis_blocks)
+            for c in range(ref.ncomp):
+                assert np.array_equal(planes[c].cpu().numpy(), ref.planes[c]), (name, sb, c)
+    # BASELINE configs[4] -- runs of two data units with the same tables, no restart markers -- synchronises faster without
+    # (measured, jg_decoder.cpp make_plan): the library does not apply the speculation there
+    planes, _, _tmp, _base, lay = jpeggpu_amd.decode_to_planes(jpegsynth.config(5, small=True), return_tmp=True)
+    assert lay.scans[0].hypotheses == 6 and lay.scans[0].hypothesis_blocks == 0  # (a short scan: one segment, walked whole)
+    dec = jpeggpu_amd.Decoder()
+    dec.parse_header(jpegsynth.config(5, seed=3))
+    assert dec.layout().scans[0].hypotheses == 0
+    dec.cleanup()
+    monkeypatch.setenv("JPEGGPU_MULTI_HYPOTHESIS", "0")
+    data = inputs["12mp_nodri"]
+    ref = oracle.decode(data)
+    planes, _, _tmp, _base, lay = jpeggpu_amd.decode_to_planes(data, return_tmp=True)
+    assert lay.scans[0].hypotheses == 0
+    for c in range(3):
+        assert np.array_equal(planes[c].cpu().numpy(), ref.planes[c]), c
+
+
 def test_config3_batch_of_64_twelve_megapixel_images(torch_cuda):
     """BASELINE.json configs[2] on one GPU: 64 x 12 MP 4:2:0 (8 distinct seeds) through jpeggpu_ext_decode_batch in one
     call, plane hashes against the oracle. (Across GPUs the same batch is sharded by image: bench.py's `gather`.)"""

@@ -242,8 +242,9 @@ def test_subsequence_size_is_chosen_per_image(L, photo_bytes, monkeypatch):
 
 def test_multi_hypothesis_applies_to_lone_decodes_of_interleaved_restart_scans(L, photo_bytes, monkeypatch):
     """jpeggpu_ext_scan_layout.hypotheses (jg_defs.h, multi-hypothesis speculation): one candidate per data unit of the
-    MCU for an image decoded on its own whose scan has restart segments (device-scanned or not); not for batches,
-    single-unit MCUs, scans without restart markers, or when the environment switches it off."""
+    MCU for an image decoded on its own (device-scanned or not; a scan without restart markers, or with segments of more
+    than 1024 subsequences, walks its chain block-wise: hypothesis_blocks); not for batches, single-unit MCUs,
+    device-scanned images without restart markers, or when the environment switches it off."""
     m = cases.matrix()
 
     def hyp(data, batched=False, device_scan=False):
@@ -253,12 +254,20 @@ def test_multi_hypothesis_applies_to_lone_decodes_of_interleaved_restart_scans(L
         dec.parse_header(data)
         lay = dec.layout()
         out = [lay.scans[s].hypotheses for s in range(lay.num_scans)]
+        blocks[:] = [lay.scans[s].hypothesis_blocks for s in range(lay.num_scans)]
+        subseq[:] = [lay.scans[s].num_subsequences for s in range(lay.num_scans)]
         dec.cleanup()
         return out
 
+    blocks, subseq = [], []
+
     assert hyp(photo_bytes) == [6] and hyp(m["dri_row"]) == [6] and hyp(m["cfg2_small"]) == [6]
     assert hyp(photo_bytes, batched=True) == [0] and hyp(photo_bytes, device_scan=True) == [6]
-    assert hyp(m["multi_seq_nodri"]) == [0] and hyp(m["gray"]) == [0] and hyp(m["cfg5_small"]) == [0]
+    assert blocks == [0]
+    assert hyp(m["gray"]) == [0]
+    assert hyp(m["cfg5_small"]) == [6] and blocks == [0]       # no restart markers, one short segment: walked whole
+    assert hyp(m["multi_seq_nodri"]) == [6] and subseq[0] > 2048 and blocks == [(subseq[0] + 1023) // 1024]  # one long segment
+    assert hyp(m["multi_seq_nodri"], device_scan=True) == [0]  # the device finds the segments: no block list
     assert hyp(m["ni_420_dri"]) == [0, 0, 0]          # one data unit per MCU in every scan
     assert hyp(m["dri_7"]) == [6]
     monkeypatch.setenv("JPEGGPU_MULTI_HYPOTHESIS", "0")

@@ -8,10 +8,19 @@ import jpeggpu_amd as jp
 from oracle import oracle
 from tools import jpegsynth
 root = os.path.join(os.path.dirname(os.path.abspath(__file__)), "..", "..")
-inputs = {"photo": open(os.path.join(root, "tests", "golden", "IMG_6510.JPG"), "rb").read(), "cfg2": jpegsynth.config(2, seed=0)}
+inputs = {"photo": open(os.path.join(root, "tests", "golden", "IMG_6510.JPG"), "rb").read(), "cfg2": jpegsynth.config(2, seed=0),
+          "cfg2_nodri": jpegsynth.encode(4032, 3024, ((2, 2), (1, 1), (1, 1)), True, 0, quality=88, noise=9, seed=0),
+          "cfg5": jpegsynth.config(5),
+          "444_dri": jpegsynth.encode(4032, 3024, ((1, 1), (1, 1), (1, 1)), True, 504, quality=88, noise=9, seed=0),
+          "422_dri": jpegsynth.encode(4032, 3024, ((2, 1), (1, 1), (1, 1)), True, 252, quality=88, noise=9, seed=0),
+          "444_nodri": jpegsynth.encode(4032, 3024, ((1, 1), (1, 1), (1, 1)), True, 0, quality=88, noise=9, seed=0),
+          "422_nodri": jpegsynth.encode(4032, 3024, ((2, 1), (1, 1), (1, 1)), True, 0, quality=88, noise=9, seed=0)}
+only = sys.argv[1:]
 for name, data in inputs.items():
+    if only and name not in only:
+        continue
     ref = oracle.decode(data)
-    for sb in (None, 32):
+    for sb in (None,) if os.environ.get("LONE_DEFAULT_ONLY") else (None, 32):
         dec = jp.Decoder(sb)
         pinned = torch.empty(len(data), dtype=torch.uint8).pin_memory(); pinned.numpy()[:] = memoryview(data)
         info = dec.parse_header(pinned.data_ptr(), pinned.numel()); n = dec.get_buffer_size()
@@ -30,5 +39,5 @@ for name, data in inputs.items():
             dec.decode(ptrs, pit, base, n, st.cuda_stream)
         st.synchronize()
         us = {k: round(v * 1e3, 1) for k, v in dec.stage_ms().items()}
-        print(name, "subseq", dec.layout().subsequence_bytes, "tmp MB %.1f" % (n / 1e6), "p50 %.3f ms" % statistics.median(lat), "exact" if ok else "WRONG", us, flush=True)
+        print(name, "subseq", dec.layout().subsequence_bytes, "hyp", dec.layout().scans[0].hypotheses, "blocks", dec.layout().scans[0].hypothesis_blocks, "tmp MB %.1f" % (n / 1e6), "p50 %.3f ms" % statistics.median(lat), "exact" if ok else "WRONG", us, flush=True)
         dec.cleanup()
