@@ -79,7 +79,7 @@ def parse_args():
                     help="1: the images of the timed batch use jpeggpu_ext_set_device_scan (marker scan inside the timed region)")
     ap.add_argument("--roofline-launches", type=int, default=6,
                     help="serialized launches (one stream, nothing else on the chip) the roofline figures are averaged over; 0 = skip")
-    ap.add_argument("--other-configs", type=int, default=10,
+    ap.add_argument("--other-configs", type=int, default=200,
                     help="iterations of the latency protocol on BASELINE.json configs[0] (the reference's photo), [3] and [4]; 0 = skip")
     ap.add_argument("--photo-steps", type=int, default=3,
                     help="N = 1: steps of the batched protocol of `value` on the reference's photo (other_configs...batch_images_per_s); 0 = skip")
@@ -426,7 +426,7 @@ def latency_probe(args, torch, jp, data, device, stream, device_scan):
     pinned = torch.empty(len(data), dtype=torch.uint8).pin_memory()
     pinned.numpy()[:] = memoryview(data)
     host_ptr, host_n = pinned.data_ptr(), pinned.numel()
-    lat, lat_parse, lat_enqueue = [], [], []
+    lat, lat_parse, lat_enqueue, lat_xfer = [], [], [], []
     warm = 3
     for it in range(args.latency_iters + warm):
         t1 = time.perf_counter()
@@ -434,13 +434,16 @@ def latency_probe(args, torch, jp, data, device, stream, device_scan):
         n = s0.dec.get_buffer_size()
         t2 = time.perf_counter()
         s0.dec.transfer(s0.base, n, stream.cuda_stream)
+        t2b = time.perf_counter()
         s0.dec.decode(s0.ptrs, s0.pitches, s0.base, n, stream.cuda_stream)
         t3 = time.perf_counter()
         stream.synchronize()
         if it >= warm:
             lat.append((time.perf_counter() - t1) * 1e3)
             lat_parse.append((t2 - t1) * 1e3)
+            lat_xfer.append((t2b - t2) * 1e3)
             lat_enqueue.append((t3 - t2) * 1e3)
+    worst = max(range(len(lat)), key=lambda i: lat[i])
     # device-only time of one decode, nothing else running
     s0.dec.set_profiling(True)
     for _ in range(10):
@@ -450,6 +453,10 @@ def latency_probe(args, torch, jp, data, device, stream, device_scan):
     out = {"protocol": "parse+size+transfer+decode+sync, 1 image, 1 stream, pinned input (reference benchmark_jpeggpu.hpp:69-108)",
            "subsequence_bytes": s0.layout.subsequence_bytes, "device_scan": bool(s0.layout.scans[0].device_scan),
            "p50": statistics.median(lat), "mean": statistics.fmean(lat), "max": max(lat),
+           "p99": sorted(lat)[min(len(lat) - 1, int(0.99 * len(lat)))],
+           # where the slowest iteration spent its time (host calls; the rest is waiting for the stream)
+           "slowest": {"iteration": worst, "total": lat[worst], "parse_header": lat_parse[worst], "transfer_call": lat_xfer[worst],
+                       "decode_call": lat_enqueue[worst] - lat_xfer[worst], "synchronize": lat[worst] - lat_parse[worst] - lat_enqueue[worst]},
            "p50_host_parse": statistics.median(lat_parse), "p50_host_enqueue": statistics.median(lat_enqueue),
            "iters": len(lat), "images_per_s_single_stream": 1e3 / statistics.fmean(lat), "stage_us_device": solo}
     s0.dec.cleanup()
@@ -516,6 +523,23 @@ def committed_profile(name):
         return {}
 
 
+def counter_ratios(c):
+    """What the committed SQ counters of a kernel say about its waves' time (profiles/pmc_counters.json: rocprofv3 --pmc
+    passes over the serialized run of ANOTHER process of the same tree): per cycle a wave is resident, the share in which
+    it has an instruction being issued or executed (SQ_ACTIVE_INST_ANY / SQ_WAVE_CYCLES), waits for anything
+    (SQ_WAIT_ANY), waits for an instruction's operands or result (SQ_WAIT_INST_ANY); and the instruction mix. The 4-cycle
+    model behind `valu_issue_util` prices vector instructions only; these ratios are counter / counter and need no model."""
+    wc = c.get("SQ_WAVE_CYCLES")
+    if not wc:
+        return None
+    out = {"active_inst_per_wave_cycle": c.get("SQ_ACTIVE_INST_ANY", 0.0) / wc, "wait_any_per_wave_cycle": c.get("SQ_WAIT_ANY", 0.0) / wc,
+           "wait_inst_per_wave_cycle": c.get("SQ_WAIT_INST_ANY", 0.0) / wc}
+    for k in ("SQ_INSTS_VALU", "SQ_INSTS_SALU", "SQ_INSTS_LDS", "SQ_INSTS_VMEM_RD", "SQ_INSTS_VMEM_WR", "SQ_WAVES", "SQ_BUSY_CYCLES"):
+        if k in c:
+            out[k] = c[k]
+    return out
+
+
 def roofline_report(args, slot, stage_us, images_per_launch, entries, value, world):
     """The `roofline` and `kernels` objects (module docstring)."""
     ab = algorithmic_bytes(slot, entries)
@@ -529,12 +553,15 @@ def roofline_report(args, slot, stage_us, images_per_launch, entries, value, wor
         name = KERNEL_NAMES[k]
         t = traffic.get(name.split("+")[0], {}).get("per_image_bytes")
         valu = counters.get(name.split("+")[0], {}).get("SQ_INSTS_VALU")
+        c = counters.get(name.split("+")[0], {})
         kernels[name] = {
             "avg_launch_us": us, "own_bytes_per_launch": ab[k] * images_per_launch,
             "own_GBs": ab[k] * images_per_launch / (us * 1e-6) / 1e9 if us > 0 else None,
             "own_frac_of_hbm_peak": ab[k] * images_per_launch / (us * 1e-6) / 1e9 / HBM_PEAK_GBS if us > 0 else None,
             "traffic_bytes_per_launch": t * images_per_launch if t else None,
-            "valu_issue_util": valu * VALU_CYCLES / (SIMDS * SHADER_HZ * us * 1e-6) if valu and us > 0 else None}
+            "valu_issue_util": valu * VALU_CYCLES / (SIMDS * SHADER_HZ * us * 1e-6) if valu and us > 0 else None,
+            # ratios of counters of the SAME unit (per wave-resident cycle), from the committed profile, not from this run
+            "issue_counters": counter_ratios(c)}
     in_pass = [k for k in stages if k in PASS_STAGES]
     t_pass_us = sum(stage_us[k] for k in in_pass)
     pass_traffic = [kernels[KERNEL_NAMES[k]]["traffic_bytes_per_launch"] for k in in_pass]
@@ -548,8 +575,13 @@ def roofline_report(args, slot, stage_us, images_per_launch, entries, value, wor
             "kernel": "destuff+Huffman pass: " + " + ".join(KERNEL_NAMES[k] for k in in_pass),
             "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
             "traffic": sum(pass_traffic) if all(pass_traffic) else None,
-            "traffic_source": "profiles/pmc_traffic.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes over the same serialized "
-                              "launches, per-shape calibration of profiles/*_fetch_calibration.json)",
+            "traffic_source": "profiles/pmc_traffic.json: rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes over serialized launches of "
+                              "the same shape in ANOTHER process of the same tree (counters cannot be read from inside this one), "
+                              "per-shape calibration of profiles/*_fetch_calibration.json; valu_issue_util and issue_counters come "
+                              "from profiles/pmc_counters.json the same way -- only the durations are measured in this run",
+            "issue_counters": counter_ratios({k: sum(counters.get(KERNEL_NAMES[s].split("+")[0], {}).get(k, 0.0) for s in in_pass)
+                                             for k in ("SQ_WAVE_CYCLES", "SQ_ACTIVE_INST_ANY", "SQ_WAIT_ANY", "SQ_WAIT_INST_ANY", "SQ_INSTS_VALU",
+                                                       "SQ_INSTS_SALU", "SQ_INSTS_LDS", "SQ_BUSY_CYCLES")}),
             "algorithmic_bytes_per_launch": bytes_per_launch, "algorithmic_bytes_per_image": ab["b_dh"],
             "avg_launch_us": t_pass_us, "images_per_launch": images_per_launch,
             "valu_issue_util": (sum(pass_valu) * VALU_CYCLES / (SIMDS * SHADER_HZ * t_pass_us * 1e-6)) if all(pass_valu) else None,
@@ -851,8 +883,8 @@ def main():
                            ("cfg2_geometry_without_restart_markers_12MP_420", jpegsynth.encode(
                                4032, 3024, ((2, 2), (1, 1), (1, 1)), True, 0, quality=88, noise=9, seed=0))):
             r = latency_probe(args, torch, jp, blob, device, streams[0], device_scan=False)
-            others[name] = {"file_bytes": len(blob), "p50_ms": r["p50"], "p50_host_parse_ms": r["p50_host_parse"],
-                            "max_ms": r["max"], "iters": r["iters"], "subsequence_bytes": r["subsequence_bytes"],
+            others[name] = {"file_bytes": len(blob), "p50_ms": r["p50"], "p99_ms": r["p99"], "p50_host_parse_ms": r["p50_host_parse"],
+                            "max_ms": r["max"], "slowest_ms": r["slowest"], "iters": r["iters"], "subsequence_bytes": r["subsequence_bytes"],
                             "stage_us_device": r["stage_us_device"]}
         args.latency_iters = saved
         if world == 1 and args.photo_steps > 0 and args.mode == "batch" and args.workload != "photo":

@@ -128,9 +128,10 @@ enum jpeggpu_status jpeggpu_ext_get_shard_rows(jpeggpu_decoder_t decoder, int co
  * device-scanned images runs as four launches for the whole batch (grid.y = image). */
 /* enable: 0 off (default); 1 on, the caller asks for the status as above; 2 on and CHECKED: jpeggpu_decoder_decode
  * itself waits for the stream and returns the device's status (it then blocks the host, unlike every other mode).
- * The environment variable JPEGGPU_DEVICE_SCAN selects the same modes at jpeggpu_decoder_startup (1: asynchronous,
- * 2: checked), for callers of the drop-in API alone: in mode 1 such a caller learns of a truncated scan from unwritten
- * planes only, mode 2 tells it at the price of a blocking decode. Items of jpeggpu_ext_decode_batch are never waited
+ * The environment variable JPEGGPU_DEVICE_SCAN switches the scan on at jpeggpu_decoder_startup for callers of the
+ * drop-in API alone: "1", "2" or "checked" select the CHECKED mode -- such a caller cannot ask for the device's verdict,
+ * so decode tells it, at the price of a blocking call --, "async" mode 1 (a truncated scan then shows as unwritten planes
+ * only). Items of jpeggpu_ext_decode_batch are never waited
  * for: their status is read with the call below. A decoder in segment-shard mode (jpeggpu_ext_set_segment_shard with
  * world > 1) always takes the host walk -- its share is cut out of the host walk's tables -- and parse_header logs
  * that the device scan was not used (jpeggpu_ext_layout.scans[0].device_scan says which walk an image got). */

@@ -573,7 +573,7 @@ jpeggpu_status do_decode(Decoder& d, jpeggpu_img* img, void* d_tmp, size_t tmp_s
             d.mark(stage, stream);
         }
         if (d.device_scan == 2) {
-            // Checked mode (JPEGGPU_DEVICE_SCAN=1 in the environment of a caller that knows only the drop-in API):
+            // Checked mode (JPEGGPU_DEVICE_SCAN=1 / 2 / checked in the environment of a caller that knows only the drop-in API):
             // what the host walk would have reported from parse_header is known on the device only now. Wait for
             // it and return it, as such a caller cannot ask for it; nothing was written to the planes if it is
             // not success.
@@ -629,14 +629,15 @@ enum jpeggpu_status jpeggpu_decoder_startup(jpeggpu_decoder_t* decoder)
         const int v = std::atoi(e);
         if (jg::subseq_bytes_supported(v)) (*decoder)->d.subseq_request = v;
     }
-    // A caller of the drop-in API alone can opt into the device-side marker scan: JPEGGPU_DEVICE_SCAN=1 keeps decode
-    // asynchronous like every other mode (a truncated scan then shows as untouched planes, the reference's own
-    // behaviour for corrupt entropy data); =2 is the CHECKED mode, in which decode waits for the stream and returns
-    // the device's verdict -- the only way such a caller can learn it, at the price of a blocking call (jpeggpu_ext.h).
+    // A caller of the drop-in API alone can opt into the device-side marker scan through the environment (jpeggpu_ext.h).
     if (const char* e = std::getenv("JPEGGPU_MULTI_HYPOTHESIS")) (*decoder)->d.mh_enabled = std::atoi(e) != 0;
     if (const char* e = std::getenv("JPEGGPU_DEVICE_SCAN")) {
+        // 1, 2 and "checked": the CHECKED mode (2 of jpeggpu_ext_set_device_scan) -- a caller that knows only the drop-in
+        // API cannot ask for the device's verdict, so decode waits for it and returns it; "async": mode 1, decode stays
+        // asynchronous and a refused scan shows as untouched planes. (Round 3 made "1" the asynchronous mode; a caller who
+        // had set it for round 2's checked mode lost the error reporting without notice: ADVICE r3.)
         const int v = std::atoi(e);
-        (*decoder)->d.device_scan = v == 1 || v == 2 ? v : 0;
+        (*decoder)->d.device_scan = std::strcmp(e, "async") == 0 ? 1 : (v == 1 || v == 2 || std::strcmp(e, "checked") == 0) ? 2 : 0;
     }
     return JPEGGPU_SUCCESS;
 }
@@ -901,6 +902,11 @@ struct jpeggpu_batch {
     std::vector<jg::ScanJob> jobs;
     std::vector<jg::FrontParams> fronts;
     std::vector<int> order, group_begin; // scratch of decode_batch: items by subsequence size, job ranges of the sizes
+    struct Part {                        // ... and the parts of the job array, one launch per stage each
+        int begin, end, way;
+        jg::JobExtent extent;
+    };
+    std::vector<Part> parts;
     // optional stage timing, same contract as the decoder's
     bool profiling = false;
     std::vector<std::vector<hipEvent_t>> sets; // ring of kNumStages + 1 events
@@ -952,7 +958,30 @@ enum jpeggpu_status jpeggpu_ext_batch_destroy(jpeggpu_batch_t batch)
     return JPEGGPU_SUCCESS;
 }
 
+static enum jpeggpu_status decode_batch_impl(
+    jpeggpu_batch_t batch,
+    const struct jpeggpu_ext_batch_item* items,
+    int num_items,
+    void* d_scratch,
+    size_t scratch_size,
+    jpeggpu_stream_t stream);
+
 enum jpeggpu_status jpeggpu_ext_decode_batch(
+    jpeggpu_batch_t batch,
+    const struct jpeggpu_ext_batch_item* items,
+    int num_items,
+    void* d_scratch,
+    size_t scratch_size,
+    jpeggpu_stream_t stream)
+{
+    try { // the scratch vectors of the batch grow with its first calls: no exception crosses the C ABI
+        return decode_batch_impl(batch, items, num_items, d_scratch, scratch_size, stream);
+    } catch (const std::bad_alloc&) {
+        return JPEGGPU_OUT_OF_HOST_MEMORY;
+    }
+}
+
+static enum jpeggpu_status decode_batch_impl(
     jpeggpu_batch_t batch,
     const struct jpeggpu_ext_batch_item* items,
     int num_items,
@@ -1040,11 +1069,9 @@ enum jpeggpu_status jpeggpu_ext_decode_batch(
         part_stream[w] = batch->aux[w - 1];
         if (hipStreamWaitEvent(part_stream[w], batch->copied[r], 0) != hipSuccess) return JPEGGPU_INTERNAL_ERROR; // fork
     }
-    struct Part {
-        int begin, end, way;
-        jg::JobExtent extent;
-    };
-    std::vector<Part> parts;
+    typedef jpeggpu_batch::Part Part;
+    std::vector<Part>& parts = batch->parts;
+    parts.clear();
     for (size_t g = 0; g + 1 < group_begin.size(); ++g) {
         const int a = group_begin[g], b = group_begin[g + 1];
         int gw = ways;

@@ -290,6 +290,10 @@ constexpr int kMhMaxHyp        = 8;    // 4-bit candidate index; more data units
 #define JG_MH_STEPS 8
 #endif
 constexpr int kMhSteps         = JG_MH_STEPS; // subsequences a candidate's flow runs before it gives up
+// the step count sits in a 4-bit link field and the pool hands out kMhSteps - 1 entries per flow; a run of entries the
+// chain hops over (kMhSteps - 1) must be shorter than the overlap zone of huff_sync_intra, or entries at the start of a
+// sequence would get their n / DC sums from no flow
+static_assert(kMhSteps >= 2 && kMhSteps <= 15 && kMhSteps - 1 < kSeqOverlap, "JG_MH_STEPS: link field, pool reservation, overlap zone");
 constexpr int kMhMaxSegSubseq  = 1024; // the chain walk of a segment -- or of one BLOCK of a longer segment -- happens in LDS
 /// Segments longer than that (a scan without restart markers is ONE segment) are walked BLOCK-WISE: every block of up to
 /// kMhMaxSegSubseq subsequences first works out, for each of the 64 nodes (candidate h, row 0..7) the chain can enter it

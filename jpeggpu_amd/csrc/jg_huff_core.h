@@ -419,8 +419,8 @@ JG_HD inline int extend_bits(uint32_t bits, int s)
 /// at the position, valid while left() >= 0 --, skip(n), left() -- negative when the window wants a refill --,
 /// crossed() -- negative where the position has just left its row --, cross() and done() behind the loop. The results
 /// do not depend on the slot periods (a host emulation runs one lane at a time). `max_iters` bounds the loop whatever
-/// the stream holds (a valid one needs fewer than one iteration per bit; a symbol that waits for the rare slot,
-/// kWriteRarePeriod, and such symbols take eleven bits at least).
+/// the stream holds; a valid one needs at most kWriteDcPeriod iterations per two bits (a data unit of a one-bit DC code
+/// and a one-bit end of block waits for its DC slot: jg_kernels.hip derives the bound from the periods).
 template <class Window, class Sink>
 JG_HD inline void decode_units(
     const LaneState& st,

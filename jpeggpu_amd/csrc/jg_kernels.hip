@@ -432,13 +432,23 @@ struct GlobalFetch {
 /// kernel's time (measured with the loads compiled out). The lane that refills now, though, needs the word it asked for
 /// at its PREVIOUS refill, a handful of iterations ago. So the loads are issued from inline assembly, where the compiler
 /// does not see them, and the wait is for all but the most recent one (vmcnt(1)). That is enough because
-///   * vector memory operations of a wave complete in the order they were issued,
+///   * vector memory operations of a wave complete in the order they were issued: `s_waitcnt vmcnt(N)` waits until all
+///     but the wave's N youngest vector-memory operations are done, and loads, stores and atomics of the global_* / buffer_*
+///     forms share that ONE counter in issue order (only flat_* operations may return out of order, and this kernel has
+///     none: every pointer of the job is qualified address_space(1), JobView) -- /opt/skills/guides/MI355X_MICROARCH.md,
+///     "s_waitcnt vmcnt(N)", and the gfx9-family ISA manuals' description of VM_CNT. The sink's stores, which the
+///     COMPILER issues between two refills, are operations on the same counter like any other: one issued behind a
+///     refill's load makes that load older, so vmcnt(1) waits for it as well (stricter than needed, never laxer); one
+///     issued in front of it is simply waited for. What vmcnt(1) never waits for is the wave's YOUNGEST operation, which
+///     is why the word a lane consumes must come from a load that is not the youngest:
 ///   * a lane does not refill in two consecutive iterations (`ok`: a lane that would sits one iteration out; it would
 ///     need 33 bits in two symbols), and
 ///   * a lane that refilled one iteration ago loads the same word into `nxt` AGAIN (`prev`): behind the load a lane
 ///     needs there is therefore always a younger one -- its own --, whatever the other lanes do.
 /// Everything that touches `nxt` lives in that assembly block, with read-write operands: the compiler never copies the
-/// register while a load into it is in flight. Operations the compiler does track (the sink's stores) only make its
+/// register while a load into it is in flight -- which it does not KNOW, so the build checks it (jpeggpu_amd/build.py,
+/// check_refill: no scratch and no spills in huff_write, and between the loop's first refill and done() no instruction
+/// outside these assembly blocks names the register; otherwise the library is rebuilt with -DJG_SAFE_REFILL: vmcnt(0)). Operations the compiler does track (the sink's stores) only make its
 /// own waits stricter. The refill is branch-free: an exec mask around three moves, two adds and the load.
 template <int W>
 struct RowWindow {
@@ -474,7 +484,7 @@ struct RowWindow {
         asm volatile(
             "s_mov_b64 %[save], exec\n\t"
             "s_and_b64 exec, %[save], %[need]\n\t"
-#if defined(JG_EXP_VMCNT0)
+#if defined(JG_SAFE_REFILL) // the build falls back to this when its check of the generated code fails (jpeggpu_amd/build.py)
             "s_waitcnt vmcnt(0)\n\t"
 #else
             "s_waitcnt vmcnt(1)\n\t"
@@ -1815,8 +1825,13 @@ __global__ __launch_bounds__(T) void huff_write(JS js)
     sink.started = 0u; // until the lane's first DC symbol
     RowWindow<W> words{GlobalFetch<W, true>{reinterpret_cast<JG_GLOBAL const uint32_t*>(J.destuffed), 0, 0}};
     words.g.set_row(sub, rel);
-    // a valid stream takes less than one iteration per bit of the subsequence and of the unit the lane runs on into
-    constexpr int kMaxIters = 2 * (W * 32 + 64 * 32);
+    // Iterations a valid stream can need for the bits of the subsequence and of the unit the lane runs on into (64 symbols of
+    // at most 32 bits): the densest stream is two-bit data units (a one-bit DC code of category 0 and a one-bit end of
+    // block), and such a unit takes one DC slot and the AC step behind it -- kWriteDcPeriod iterations per two bits; a
+    // symbol that waits for the rare slot has eleven bits or more and waits at most kWriteRarePeriod iterations.
+    constexpr int kItersPerBitX2 = kWriteDcPeriod > 2 ? kWriteDcPeriod : 2; // iterations per TWO bits, worst case
+    constexpr int kMaxIters      = kItersPerBitX2 * (W * 32 + 64 * 32) / 2 + 2 * kWriteRarePeriod;
+    static_assert(kWriteRarePeriod <= 11, "a symbol that waits for the rare slot must not wait longer than its bits allow for");
 #if defined(JG_PROBE)
     int iters[4] = {0, 0, 0, 0};
     decode_units(st, words, s_tab, sp, sink, kMaxIters, iters);

@@ -432,8 +432,8 @@ def test_device_side_marker_scan(torch_cuda):
 def test_device_scan_agrees_with_host_walk_on_refusals(torch_cuda, monkeypatch):
     """What the host walk refuses at parse time gets the same status from the device: an FF FF 00 inside
     the scan (neither fill byte + marker nor stuffing), a scan no marker ends. And the checked mode that
-    JPEGGPU_DEVICE_SCAN=2 selects for callers of the drop-in API alone: decode itself returns that status
-    (=1 keeps decode asynchronous: success at enqueue time whatever the stream holds)."""
+    JPEGGPU_DEVICE_SCAN=1 / 2 / checked selects for callers of the drop-in API alone: decode itself returns that status
+    (=async keeps decode asynchronous: success at enqueue time whatever the stream holds)."""
     import jpeggpu_amd
     from jpeggpu_amd import JpegGpuError, Status
 
@@ -459,7 +459,7 @@ def test_device_scan_agrees_with_host_walk_on_refusals(torch_cuda, monkeypatch):
         assert lay.scans[0].device_scan and status == want, (name, status)
         assert want == Status.SUCCESS or all((p == 0x5A).all() for p in planes)
         # checked mode through the environment variable, drop-in calls only
-        for env, expect in (("2", want), ("1", Status.SUCCESS)):
+        for env, expect in (("2", want), ("1", want), ("checked", want), ("async", Status.SUCCESS)):
             monkeypatch.setenv("JPEGGPU_DEVICE_SCAN", env)
             dec = jpeggpu_amd.Decoder()
             monkeypatch.delenv("JPEGGPU_DEVICE_SCAN")

@@ -379,3 +379,28 @@ def test_fails_loudly_without_a_device(L):
         dec.transfer(base, n, 0)
     assert ei.value.status == Status.INTERNAL_ERROR
     dec.cleanup()
+
+
+def test_build_checks_the_counted_wait_refill_of_the_write_pass(L):
+    """ADVICE r3 (medium): RowWindow::top() loads the next bitstream word from inline assembly and waits with
+    `s_waitcnt vmcnt(1)`; the compiler must never touch that register between the assembly blocks. jpeggpu_amd/build.py
+    checks the generated gfx950 code at every build (no scratch, no spills, the register named only inside the blocks) and
+    falls back to -DJG_SAFE_REFILL otherwise. The check passes on the tree as it is, and it does find a copy of the
+    register planted into the loop, a spill count and a missing block."""
+    import re
+
+    from jpeggpu_amd import build as jbuild
+
+    text = jbuild.device_assembly()
+    assert jbuild.check_refill_text(text) == []
+    # plant `v_mov_b32 v255, <nxt>` behind the first refill block of the first huff_write
+    start = next(i for i, ln in enumerate(text) if re.match(r"^_ZN2jg\S*huff_write\S*:", ln))
+    k = next(i for i in range(start, len(text)) if "global_load_dword" in text[i] and ";;#ASMSTART" in "".join(text[i - 12:i]))
+    reg = re.match(r"\s*global_load_dword (v\d+),", text[k]).group(1)
+    end = next(i for i in range(k, len(text)) if ";;#ASMEND" in text[i])
+    doctored = text[:end + 1] + ["\tv_mov_b32_e32 v255, %s" % reg] + text[end + 1:]
+    bad = jbuild.check_refill_text(doctored)
+    assert len(bad) == 1 and "touched outside the assembly blocks" in bad[0] and reg in bad[0]
+    spilled = [ln.replace(".vgpr_spill_count: 0", ".vgpr_spill_count: 3") if ".vgpr_spill_count" in ln else ln for ln in text]
+    assert any("vgpr_spill_count: 3" in p for p in jbuild.check_refill_text(spilled))
+    assert jbuild.check_refill_text([ln for ln in text if "global_load_dword" not in ln or "s[" not in ln]) != []
