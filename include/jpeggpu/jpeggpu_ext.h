@@ -114,8 +114,8 @@ enum jpeggpu_status jpeggpu_ext_get_layout(jpeggpu_decoder_t decoder, struct jpe
 enum jpeggpu_status jpeggpu_ext_set_segment_shard(jpeggpu_decoder_t decoder, int rank, int world);
 enum jpeggpu_status jpeggpu_ext_get_shard_rows(jpeggpu_decoder_t decoder, int component, int* first_row, int* num_rows);
 
-/* Device-side front end (enable != 0, before parse_header): for a file whose first scan holds every component,
- * parse_header stops at the scan header instead of walking the entropy-coded bytes for restart markers (the
+/* Device-side front end (enable != 0, before parse_header): parse_header stops at the header of the file's LAST scan
+ * (the only one of most files) instead of walking the entropy-coded bytes for restart markers (the
  * reference does that walk on the host inside its timed loop, src/reader.cpp:447-489; here it is 0.2 of the
  * 0.87 ms of a 12 MP image). transfer then copies everything up to the end of the file, and decode first runs four
  * small kernels that find the markers and build the segment table and the destuff work list in device memory. What
@@ -124,8 +124,9 @@ enum jpeggpu_status jpeggpu_ext_get_shard_rows(jpeggpu_decoder_t decoder, int co
  * only on the device: decode leaves the planes untouched, and jpeggpu_ext_get_device_status (which synchronises
  * `stream`) returns the status. If the file ends in an end-of-image marker, or in one followed by padding, the
  * copy stops there (a backwards search on the host); otherwise it runs to the end of the file.
- * Other files (several scans) take the host walk as before. A batch may mix both kinds: the front end of its
- * device-scanned images runs as four launches for the whole batch (grid.y = image). */
+ * In a file of several scans the LAST one is the device's: the scans in front of it are walked on the host (the next scan
+ * header lies behind their last byte), their restart markers, the device-walked scan's status. A batch may mix both
+ * kinds: the front end of its device-scanned images runs as four launches for the whole batch (grid.y = image). */
 /* enable: 0 off (default); 1 on, the caller asks for the status as above; 2 on and CHECKED: jpeggpu_decoder_decode
  * itself waits for the stream and returns the device's status (it then blocks the host, unlike every other mode).
  * The environment variable JPEGGPU_DEVICE_SCAN switches the scan on at jpeggpu_decoder_startup for callers of the

@@ -270,7 +270,7 @@ void Decoder::make_plan()
         }
         if (sc.device_walk) {
             const size_t E   = static_cast<size_t>(sc.expect_segments);
-            sp.num_windows   = static_cast<uint32_t>(align_up(p.bytes_len, kDestuffWin) / kDestuffWin);
+            sp.num_windows   = static_cast<uint32_t>(align_up(p.bytes_len, kDestuffWin) / kDestuffWin) - sc.front_win0;
             const size_t Wn  = sp.num_windows;
             const auto carve = [&](size_t& at, size_t bytes) {
                 at = o;
@@ -494,23 +494,34 @@ jpeggpu_status build_jobs(
             job.num_tail_parts = sc.max_tail_parts - 1;
             job.max_tail_part  = s.restart_interval ? kTailPartSubseq : (1 << 30); // lanes of the tail kernel
             sp.num_segments    = sc.expect_segments;
+            // the device's tables count from the window that holds this scan's first byte (earlier scans lie in front)
+            job.bytes          = base + plan.off_bytes + static_cast<size_t>(sc.front_win0) * kDestuffWin;
         }
         jobs.push_back(job);
     }
     return JPEGGPU_SUCCESS;
 }
 
-/// Parameters of the device-side front end for scan 0 of a parsed image; `d_job` is the device copy of its job.
-jg::FrontParams front_params(const Decoder& d, void* d_tmp, jg::ScanJob* d_job)
+/// Index of the scan of a parsed image that the device walks (its last one), or -1.
+int device_scan_index(const Decoder& d)
+{
+    const jg::Stream& s = d.reader.s;
+    return s.num_scans > 0 && s.scans[s.num_scans - 1].device_walk ? s.num_scans - 1 : -1;
+}
+
+/// Parameters of the device-side front end for the device-walked scan `k` of a parsed image; `d_job` is the device copy
+/// of its job.
+jg::FrontParams front_params(const Decoder& d, void* d_tmp, jg::ScanJob* d_job, int k)
 {
     using namespace jg;
-    const Scan& sc     = d.reader.s.scans[0];
-    const ScanPlan& pl = d.plan.scan[0];
+    const Scan& sc     = d.reader.s.scans[k];
+    const ScanPlan& pl = d.plan.scan[k];
     uint8_t* base      = static_cast<uint8_t*>(d_tmp);
+    const size_t skip  = static_cast<size_t>(sc.front_win0) * kDestuffWin; // whole windows of earlier scans' bytes
     FrontParams P{};
-    P.bytes           = base + d.plan.off_bytes;
-    P.bytes_len       = static_cast<uint32_t>(d.plan.bytes_len);
-    P.scan_begin      = static_cast<uint32_t>(sc.begin - d.reader.s.xfer_begin);
+    P.bytes           = base + d.plan.off_bytes + skip;
+    P.bytes_len       = static_cast<uint32_t>(d.plan.bytes_len - skip);
+    P.scan_begin      = static_cast<uint32_t>(sc.begin - d.reader.s.xfer_begin - skip);
     P.num_windows     = pl.num_windows;
     P.expect_segments = static_cast<uint32_t>(sc.expect_segments);
     P.subseq_bytes    = static_cast<uint32_t>(d.subseq_bytes);
@@ -539,9 +550,10 @@ jg::FrontParams front_params(const Decoder& d, void* d_tmp, jg::ScanJob* d_job)
 jpeggpu_status read_device_status(Decoder& d, const void* d_tmp, hipStream_t stream, jpeggpu_status* status)
 {
     *status = JPEGGPU_SUCCESS;
-    if (!d.reader.s.scans[0].device_walk) return JPEGGPU_SUCCESS; // the host walk has already judged the stream
+    const int k = device_scan_index(d);
+    if (k < 0) return JPEGGPU_SUCCESS; // the host walk has already judged the stream
     uint32_t word = 0;
-    const uint8_t* src = static_cast<const uint8_t*>(d_tmp) + d.plan.scan[0].d_status;
+    const uint8_t* src = static_cast<const uint8_t*>(d_tmp) + d.plan.scan[k].d_status;
     if (hipMemcpyAsync(&word, src, sizeof(word), hipMemcpyDeviceToHost, stream) != hipSuccess ||
         hipStreamSynchronize(stream) != hipSuccess)
         return JPEGGPU_INTERNAL_ERROR;
@@ -558,25 +570,32 @@ jpeggpu_status do_decode(Decoder& d, jpeggpu_img* img, void* d_tmp, size_t tmp_s
     if (st != JPEGGPU_SUCCESS) return st;
     d.next_event_set();
     d.mark(-1, stream);
-    if (d.reader.s.scans[0].device_walk) {
-        // Device-side front end: the job lives in device memory, front_plan fills in its counts, and the
-        // stages read it from there, with launch extents from the header's upper bounds.
-        ScanJob* d_job = reinterpret_cast<ScanJob*>(static_cast<uint8_t*>(d_tmp) + d.plan.scan[0].d_job);
-        const FrontParams P = front_params(d, d_tmp, d_job);
+    if (const int k = device_scan_index(d); k >= 0) {
+        // Device-side front end for the image's last scan: its job lives in device memory, front_plan fills in its counts,
+        // and the stages read it from there, with launch extents from the header's upper bounds. The scans in front of
+        // it (a file of several scans) were walked on the host: their jobs travel by value, one launch per stage for all
+        // of them beside the device-walked scan's.
+        ScanJob* d_job = reinterpret_cast<ScanJob*>(static_cast<uint8_t*>(d_tmp) + d.plan.scan[k].d_job);
+        const FrontParams P = front_params(d, d_tmp, d_job, k);
         // the job travels as a kernel argument of the first front-end kernel, which stores it to d_job
-        JG_CHECK_HIP(launch_front(P, d.jobs[0], stream));
+        JG_CHECK_HIP(launch_front(P, d.jobs[k], stream));
         JobExtent extent;
-        extend(extent, d.jobs[0]);
+        extend(extent, d.jobs[k]);
         for (int stage = 0; stage < kNumStages; ++stage) {
-            if (stage == kStageSyncIntra && d.jobs[0].sp.mh > 1) JG_CHECK_HIP(launch_mh(d.jobs[0], d_job, d.plan.scan[0].max_seg_subseq, stream));
+            if (stage == kStageSyncIntra) {
+                for (int i = 0; i < k; ++i)
+                    if (d.jobs[i].sp.mh > 1) JG_CHECK_HIP(launch_mh(d.jobs[i], nullptr, d.plan.scan[i].max_seg_subseq, stream));
+                if (d.jobs[k].sp.mh > 1) JG_CHECK_HIP(launch_mh(d.jobs[k], d_job, d.plan.scan[k].max_seg_subseq, stream));
+            }
+            if (k > 0) JG_CHECK_HIP(launch_stage_scans(static_cast<Stage>(stage), d.jobs.data(), k, stream));
             JG_CHECK_HIP(launch_stage_device_job(static_cast<Stage>(stage), d_job, extent, stream));
             d.mark(stage, stream);
         }
         if (d.device_scan == 2) {
             // Checked mode (JPEGGPU_DEVICE_SCAN=1 / 2 / checked in the environment of a caller that knows only the drop-in API):
             // what the host walk would have reported from parse_header is known on the device only now. Wait for
-            // it and return it, as such a caller cannot ask for it; nothing was written to the planes if it is
-            // not success.
+            // it and return it, as such a caller cannot ask for it; nothing of the device-walked scan was written to the
+            // planes if it is not success.
             jpeggpu_status dev = JPEGGPU_SUCCESS;
             const jpeggpu_status rc = read_device_status(d, d_tmp, stream, &dev);
             return rc != JPEGGPU_SUCCESS ? rc : dev;
@@ -1015,9 +1034,9 @@ static enum jpeggpu_status decode_batch_impl(
         const size_t first_job = batch->jobs.size();
         const jpeggpu_status st = build_jobs(it.decoder->d, it.img, it.d_tmp, it.tmp_size, batch->sync_iters, false, batch->jobs);
         if (st != JPEGGPU_SUCCESS) return st;
-        if (it.decoder->d.reader.s.scans[0].device_walk) {
+        if (const int dk = device_scan_index(it.decoder->d); dk >= 0) {
             // device-side front end (jpeggpu_ext_set_device_scan): the counts of this job are filled in on the device
-            batch->fronts.push_back(front_params(it.decoder->d, it.d_tmp, d_jobs_rw + first_job));
+            batch->fronts.push_back(front_params(it.decoder->d, it.d_tmp, d_jobs_rw + first_job + static_cast<size_t>(dk), dk));
             front_windows = std::max(front_windows, batch->fronts.back().num_windows);
         }
     }

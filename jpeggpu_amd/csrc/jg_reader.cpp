@@ -510,7 +510,9 @@ jpeggpu_status Reader::read_sos(const Logger& log)
     }
     if (s.num_scans == 0) s.xfer_begin = (scan.begin - 1) & ~static_cast<size_t>(15);
     ++s.num_scans;
-    if (device_scan_ && s.num_scans == 1 && ns == s.num_comp) {
+    bool last_scan = true; // this scan completes the frame's components (comp_in_scan_ already counts its own)
+    for (int c = 0; c < s.num_comp; ++c) last_scan = last_scan && comp_in_scan_[c];
+    if (device_scan_ && last_scan) {
         // Device-side front end: everything up to the end of the file is transferred, the device finds the
         // restart markers and the end of the scan. Upper bounds: a segment of d data bytes has
         // ceil(d / subsequence) subsequences, so at most (bytes / subsequence) + segments in total; a chunk
@@ -530,10 +532,14 @@ jpeggpu_status Reader::read_sos(const Logger& log)
         const size_t file_end = static_cast<size_t>(stop - base_);
         const size_t bytes    = file_end - scan.begin;
         const size_t segments = static_cast<size_t>(ceil_div(total_mcus, scan.mcus_per_segment));
-        const size_t windows  = (file_end - s.xfer_begin + kDestuffWin - 1) / kDestuffWin;
+        // the device looks at the windows from the one that holds this scan's first byte on (earlier scans' bytes lie in
+        // front of it: they were walked on the host)
+        const size_t win0     = (scan.begin - s.xfer_begin) / kDestuffWin;
+        const size_t windows  = (file_end - s.xfer_begin + kDestuffWin - 1) / kDestuffWin - win0;
         const size_t subseq   = bytes / static_cast<size_t>(subseq_bytes_) + segments + 1;
         if (segments <= (1u << 20) && subseq < (1u << 24) && bytes < (1u << 27)) {
             scan.device_walk     = true;
+            scan.front_win0      = static_cast<uint32_t>(win0);
             scan.expect_segments = static_cast<int>(segments);
             scan.num_subseq      = static_cast<int>(subseq);
             scan.max_chunks      = static_cast<int>(windows + segments + 1);

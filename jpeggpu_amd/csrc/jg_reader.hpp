@@ -74,6 +74,7 @@ struct Scan {
     // Device-side front end (jg_front.hip): the host does not walk the scan; num_subseq and the three
     // capacities are upper bounds from the header, segments / chunks / tail_parts stay empty.
     bool device_walk    = false;
+    uint32_t front_win0 = 0; // device_walk: first 4 KiB window of the transferred bytes the device looks at (the one that holds `begin`)
     int expect_segments = 0;
     int max_chunks      = 0;
     int max_tail_parts  = 0; // entries of the device's tail_parts array
@@ -119,8 +120,9 @@ inline int choose_subseq_bytes(bool batched, size_t scan_bytes_bound, size_t seg
 }
 
 struct Reader {
-    /// `device_scan`: a file whose first scan holds every component is not walked on the host (jg_front.hip
-    /// does it on the device); parsing stops at that scan's first entropy-coded byte.
+    /// `device_scan`: the LAST scan of a file -- the one that completes the frame's components; the only one of most
+    /// files -- is not walked on the host (jg_front.hip does it on the device); parsing stops at that scan's first
+    /// entropy-coded byte. Earlier scans are walked on the host: the next scan header lies behind their last byte.
     /// `subseq_bytes`: 32, 64, 128 or 256, or a request to choose per image (the reference leaves this as a TODO,
     /// src/decoder_defs.hpp:28-34): kSubseqAutoLone for an image decoded on its own (jpeggpu_decoder_decode),
     /// kSubseqAutoBatched for one that shares its launches with others (jpeggpu_ext_decode_batch). The choice is made

@@ -376,8 +376,9 @@ def _decode_device_scan(torch, jpeggpu_amd, data, subseq_bytes):
     for p in planes:
         assert (p[0] == 0x5A).all() and (p[-1] == 0x5A).all(), "plane overrun"
     words = None
-    if lay.scans[0].device_scan:
-        w = tmp[off + lay.scans[0].off_device_status: off + lay.scans[0].off_device_status + 32].cpu().numpy().view(np.uint32)
+    last = lay.scans[lay.num_scans - 1]  # the scan the device walks, if any
+    if last.device_scan:
+        w = tmp[off + last.off_device_status: off + last.off_device_status + 32].cpu().numpy().view(np.uint32)
         words = [int(x) for x in w[:5]]
     dec.cleanup()
     return status, [p[1:-1].cpu().numpy() for p in planes], lay, words
@@ -393,18 +394,19 @@ def test_device_side_marker_scan(torch_cuda):
 
     torch = torch_cuda
     m = cases.matrix()
-    took_device_path = 0
+    took_device_path = multi_scan = 0
     for name, data in m.items():
         ref = oracle.decode(data)
         for sb in (128, 32):
             status, planes, lay, words = _decode_device_scan(torch, jpeggpu_amd, data, sb)
-            if not lay.scans[0].device_scan:
-                assert ref.nscans > 1, name  # only files with several scans keep the host walk
-                assert status == Status.SUCCESS
-            else:
+            k = lay.num_scans - 1
+            # the last scan of every file is walked on the device, the scans in front of it (if any) on the host
+            assert lay.num_scans == ref.nscans and lay.scans[k].device_scan and not any(lay.scans[i].device_scan for i in range(k)), name
+            multi_scan += k > 0
+            if True:
                 host = jpeggpu_amd.Decoder(sb)
                 host.parse_header(data)
-                hl = host.layout().scans[0]
+                hl = host.layout().scans[k]
                 host.cleanup()
                 assert status == Status.SUCCESS, (name, sb, status)
                 took_device_path += 1
@@ -413,7 +415,7 @@ def test_device_side_marker_scan(torch_cuda):
             if status == Status.SUCCESS:
                 for c in range(ref.ncomp):
                     assert np.array_equal(planes[c], ref.planes[c]), (name, sb, c)
-    assert took_device_path > 40  # every single-scan case, however dense its restart markers
+    assert took_device_path > 40 and multi_scan >= 6  # every case, however dense its restart markers; three files of three scans
 
     # what the host walk refuses at parse time comes back from the device; the planes are not written
     good = m["multi_seq_dri"]
@@ -444,9 +446,13 @@ def test_device_scan_agrees_with_host_walk_on_refusals(torch_cuda, monkeypatch):
     cut = good[: len(good) * 2 // 3]
     behind_eoi = good + b"\xff\xff\x00" + bytes(100)             # the same sequence behind the image: not the scan's business
     empty_seg = cases.empty_segment_case()                       # two restart markers back to back, segment COUNT as the geometry wants
+    three = cases.matrix()["ni_420_dri"]                          # three scans: the last one is the device's, refused like a lone one
+    three_cut = three[: len(three) - 40]                          # ... its terminating marker is gone
+    three_bad = three[:-2] + b"\xff\xff\x00" + three[-2:]         # ... FF FF 00 in front of it
     for name, data, want in (("good", good, Status.SUCCESS), ("ffzero", ffzero, Status.INVALID_JPEG),
                              ("cut", cut, Status.INVALID_JPEG), ("behind_eoi", behind_eoi, Status.SUCCESS),
-                             ("empty_segment", empty_seg, Status.INVALID_JPEG)):
+                             ("empty_segment", empty_seg, Status.INVALID_JPEG), ("three_scans", three, Status.SUCCESS),
+                             ("three_scans_cut", three_cut, Status.INVALID_JPEG), ("three_scans_ffff00", three_bad, Status.INVALID_JPEG)):
         host = jpeggpu_amd.Decoder()
         try:
             host.parse_header(data)
@@ -456,15 +462,16 @@ def test_device_scan_agrees_with_host_walk_on_refusals(torch_cuda, monkeypatch):
         host.cleanup()
         assert host_status == want, (name, host_status)
         status, planes, lay, _ = _decode_device_scan(torch, jpeggpu_amd, data, 128)
-        assert lay.scans[0].device_scan and status == want, (name, status)
-        assert want == Status.SUCCESS or all((p == 0x5A).all() for p in planes)
+        assert lay.scans[lay.num_scans - 1].device_scan and status == want, (name, status)
+        # nothing of a refused scan is written (the host-walked scans in front of it, if any, are decoded as usual)
+        assert want == Status.SUCCESS or all((p == 0x5A).all() for p in planes[lay.num_scans - 1:])
         # checked mode through the environment variable, drop-in calls only
         for env, expect in (("2", want), ("1", want), ("checked", want), ("async", Status.SUCCESS)):
             monkeypatch.setenv("JPEGGPU_DEVICE_SCAN", env)
             dec = jpeggpu_amd.Decoder()
             monkeypatch.delenv("JPEGGPU_DEVICE_SCAN")
             info = dec.parse_header(data)
-            assert dec.layout().scans[0].device_scan
+            assert dec.layout().scans[dec.layout().num_scans - 1].device_scan
             n, tmp, base, pl = _alloc(torch, dec, info)
             dec.transfer(base, n, 0)
             try:
@@ -611,7 +618,7 @@ def test_baseline_configs_full_size(torch_cuda, cfg):
 
     data = jpegsynth.config(cfg, seed=5)
     ref = oracle.decode(data)
-    for device_scan in (False, True):  # cfg 4 has three scans and keeps the host walk either way
+    for device_scan in (False, True):  # (of cfg 4's three scans the last one is then walked on the device)
         planes, info = jpeggpu_amd.decode_to_planes(data, device_scan=device_scan)
         assert info.num_components == ref.ncomp
         for c in range(ref.ncomp):
