@@ -886,10 +886,13 @@ def main():
             others[name] = {"file_bytes": len(blob), "p50_ms": r["p50"], "p99_ms": r["p99"], "p50_host_parse_ms": r["p50_host_parse"],
                             "max_ms": r["max"], "slowest_ms": r["slowest"], "iters": r["iters"], "subsequence_bytes": r["subsequence_bytes"],
                             "stage_us_device": r["stage_us_device"]}
-            if name.startswith("config4"):  # three scans: with jpeggpu_ext_set_device_scan the last one is walked on the device
+            if name.startswith("config4"):
+                # three scans: jpeggpu_ext_set_device_scan hands the LAST scan of such a file to the device only if it is the
+                # bulk of the bytes; here it is a fifth, so the host walks all three (with the last one on the device, measured
+                # in round 4: host parse 0.105 -> 0.099 ms, p50 0.58 -> 0.76 ms)
                 r = latency_probe(args, torch, jp, blob, device, streams[0], device_scan=True)
-                others[name]["device_scan_of_the_last_scan"] = {"p50_ms": r["p50"], "p99_ms": r["p99"], "p50_host_parse_ms": r["p50_host_parse"],
-                                                                "max_ms": r["max"], "stage_us_device": r["stage_us_device"]}
+                others[name]["with_device_scan_enabled"] = {"p50_ms": r["p50"], "p50_host_parse_ms": r["p50_host_parse"],
+                                                            "last_scan_walked_on_device": r["device_scan"]}
         args.latency_iters = saved
         if world == 1 and args.photo_steps > 0 and args.mode == "batch" and args.workload != "photo":
             pset = BatchSet(args, torch, jp, [photo_bytes], device, streams, args.batch)

@@ -124,8 +124,8 @@ enum jpeggpu_status jpeggpu_ext_get_shard_rows(jpeggpu_decoder_t decoder, int co
  * only on the device: decode leaves the planes untouched, and jpeggpu_ext_get_device_status (which synchronises
  * `stream`) returns the status. If the file ends in an end-of-image marker, or in one followed by padding, the
  * copy stops there (a backwards search on the host); otherwise it runs to the end of the file.
- * In a file of several scans the LAST one is the device's: the scans in front of it are walked on the host (the next scan
- * header lies behind their last byte), their restart markers, the device-walked scan's status. A batch may mix both
+ * In a file of several scans the LAST one is the device's if it holds at least as many bytes as the scans in front of it
+ * (those are walked on the host: the next scan header lies behind their last byte); otherwise the host walks them all. A batch may mix both
  * kinds: the front end of its device-scanned images runs as four launches for the whole batch (grid.y = image). */
 /* enable: 0 off (default); 1 on, the caller asks for the status as above; 2 on and CHECKED: jpeggpu_decoder_decode
  * itself waits for the stream and returns the device's status (it then blocks the host, unlike every other mode).

@@ -122,7 +122,8 @@ inline int choose_subseq_bytes(bool batched, size_t scan_bytes_bound, size_t seg
 struct Reader {
     /// `device_scan`: the LAST scan of a file -- the one that completes the frame's components; the only one of most
     /// files -- is not walked on the host (jg_front.hip does it on the device); parsing stops at that scan's first
-    /// entropy-coded byte. Earlier scans are walked on the host: the next scan header lies behind their last byte.
+    /// entropy-coded byte. Earlier scans are walked on the host: the next scan header lies behind their last byte; and
+    /// the last of several is handed to the device only if it holds at least as many bytes as those in front of it.
     /// `subseq_bytes`: 32, 64, 128 or 256, or a request to choose per image (the reference leaves this as a TODO,
     /// src/decoder_defs.hpp:28-34): kSubseqAutoLone for an image decoded on its own (jpeggpu_decoder_decode),
     /// kSubseqAutoBatched for one that shares its launches with others (jpeggpu_ext_decode_batch). The choice is made

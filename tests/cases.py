@@ -36,6 +36,12 @@ def empty_segment_case():
     return good[:a] + good[a + 2:b + 2] + good[a:a + 2] + good[b + 2:]
 
 
+def big_last_scan_case(restart_interval=0, seed=41):
+    """Two non-interleaved scans of which the LAST one holds most of the bytes (component 1 has four times the samples of
+    component 0): the shape of file whose last scan the device-side marker scan takes over (jpeggpu_ext_set_device_scan)."""
+    return jpegsynth.encode(232, 176, ((1, 1), (2, 2)), interleaved=False, restart_interval=restart_interval, quality=90, noise=12, seed=seed)
+
+
 def matrix():
     """name -> bytes. Small enough for the oracle to finish in well under a second each."""
     e = jpegsynth.encode
@@ -62,6 +68,8 @@ def matrix():
         "ni_444": e(232, 176, S444, interleaved=False, seed=16),
         "ni_420": e(232, 176, S420, interleaved=False, seed=17),
         "ni_420_dri": e(233, 171, S420, interleaved=False, restart_interval=9, seed=18),
+        "ni_big_last": big_last_scan_case(),
+        "ni_big_last_dri": big_last_scan_case(restart_interval=5, seed=42),
         # components and tables
         "two_comp": e(160, 120, ((2, 1), (1, 1)), seed=19),
         "four_comp_opt": e(264, 200, ((2, 1), (1, 1), (1, 1), (2, 1)), optimize=True, seed=20),

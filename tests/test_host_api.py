@@ -277,13 +277,13 @@ def test_multi_hypothesis_applies_to_lone_decodes_of_interleaved_restart_scans(L
 def test_device_scan_knob_and_environment(L, monkeypatch):
     """jpeggpu_ext_set_device_scan / JPEGGPU_DEVICE_SCAN: the LAST scan of a file (the only one of most) is parsed up to
     its scan header only (capacities instead of counts, a bigger buffer) -- the scans in front of it keep the host walk,
-    which has to find the next scan header behind them anyway; the environment variable switches it on for decoders
-    created afterwards."""
+    which has to find the next scan header behind them anyway, and the last of several is the device's only if it holds
+    at least as many bytes as they do; the environment variable switches it on for decoders created afterwards."""
     m = cases.matrix()
 
     def layouts(dec):
         out = []
-        for name in ("multi_seq_dri", "ni_420_dri"):
+        for name in ("multi_seq_dri", "ni_420_dri", "ni_big_last_dri"):
             dec.parse_header(m[name])
             lay = dec.layout()
             out.append((lay.scans[0], dec.get_buffer_size(), [lay.scans[k].device_scan for k in range(lay.num_scans)]))
@@ -296,12 +296,13 @@ def test_device_scan_knob_and_environment(L, monkeypatch):
     b = layouts(plain)
     # (the buffer sizes are not comparable: the host-walked lone decode also carries the multi-hypothesis tables)
     assert b[0][0].device_scan and b[0][0].num_subsequences >= a[0][0].num_subsequences and b[0][1] != a[0][1]
-    assert a[1][2] == [0, 0, 0] and b[1][2] == [0, 0, 1] and b[1][1] != a[1][1]  # three scans: the last one on the device
+    assert a[1][2] == [0, 0, 0] and b[1][2] == [0, 0, 0] and b[1][1] == a[1][1]  # three scans, the last one a sixth of the bytes: host walk
+    assert a[2][2] == [0, 0] and b[2][2] == [0, 1] and b[2][1] != a[2][1]        # two scans, the last one the bulk: on the device
     plain.cleanup()
     monkeypatch.setenv("JPEGGPU_DEVICE_SCAN", "1")
     env = jpeggpu_amd.Decoder()
     c = layouts(env)
-    assert c[0][0].device_scan and c[0][1] == b[0][1] and c[1][2] == [0, 0, 1]
+    assert c[0][0].device_scan and c[0][1] == b[0][1] and c[1][2] == [0, 0, 0] and c[2][2] == [0, 1]
     env.cleanup()
 
 
