@@ -26,10 +26,14 @@ constexpr int kSeqSubseq   = kSeqLanes - kSeqOverlap; // subsequences owned by o
 // whole-subsequence decodes (two to four trips of its lock-step loop) for the ~8 % of the subsequences whose flow the
 // sequence kernel left unfinished, so what it costs is latency, and a part's trip takes as long as the slowest lane of
 // its fullest wave. Measured per 64 images of 12 MP, serialized / four streams overlapping (round 4, in-run): parts of
-// 2048 (one 1024-lane workgroup, ~170 flows in three waves) 370 us / 27.4 k images/s; 768 (256 lanes, ~64 flows) 258 us /
-// 27.7 k; 512 250 us / 27.0 k; 384 390 us / 26.4 k; 1024 590 us / 23.7 k. Round 2 chose 2048 against 512 for the
-// overlapping case alone.
-constexpr int kTailPartSubseq = 768;
+// 2048 in 1024-lane workgroups (round 3) 370 us / 27.4 k images/s; in 256-lane workgroups, a part's flows in its lowest
+// lanes: 1024 590 us / 23.7 k (the 1024-lane kernel, two workgroups to a CU), 768 258 / 27.7 k, 512 250 / 27.0 k,
+// 384 390 / 26.4 k; with the flows spread over the four waves: 512 237, 640 212, 768 232, 900 223, 960 219, 1260 230,
+// 1920 241 us, images/s 27.8 ... 28.7 k, rising slowly with the size.
+#ifndef JG_TAIL_PART
+#define JG_TAIL_PART 960
+#endif
+constexpr int kTailPartSubseq = JG_TAIL_PART;
 constexpr int kDestuffWin   = 4096; // stuffed bytes handled by one destuff workgroup (256 lanes x 16 B)
 
 /// Zig-zag index -> raster index inside a data unit (T.81 figure A.6; reference src/defs.hpp:94-102).

@@ -1307,12 +1307,18 @@ __global__ __launch_bounds__(256) void huff_mh_resolve(JS js)
 // Huffman: inter-sequence synchronisation
 // ------------------------------------------------------------------------------------------------
 
-/// Lanes of the tail kernel. A part cut from a scan with restart markers holds ~500 subsequences and a
-/// few dozen flows: 256 lanes, so that the idle waves of the ~500 us this latency-bound kernel lives do not
-/// hold the wave slots other streams' kernels need (16-wave workgroups held 3/4 of them: -8 % throughput
-/// with overlapping streams). A scan without restart markers is one part with thousands of flows: 1024
+/// Lanes of the tail kernel. A part cut from a scan with restart markers holds ~1000 subsequences (jg_defs.h) and
+/// 60-80 flows, spread over the four waves of a 256-lane workgroup: idle waves of the ~200 us this latency-bound
+/// kernel lives must not hold the wave slots other streams' kernels need (16-wave workgroups held 3/4 of them: -8 %
+/// throughput with overlapping streams). A scan without restart markers is one part with thousands of flows: 1024
 /// lanes, or its ordered groups of flows would run one after the other.
-constexpr int kTailLanesSmall = 256, kTailLanesLarge = 1024, kTailLargeFrom = 1024;
+#ifndef JG_TAIL_LANES_SMALL
+#define JG_TAIL_LANES_SMALL 256
+#endif
+#ifndef JG_TAIL_LARGE_FROM
+#define JG_TAIL_LARGE_FROM 4096 // (1024-lane workgroups fit two to a CU: parts of ~1060 subsequences in them took 590 us per 64 images)
+#endif
+constexpr int kTailLanesSmall = JG_TAIL_LANES_SMALL, kTailLanesLarge = 1024, kTailLargeFrom = JG_TAIL_LARGE_FROM;
 
 /// Continues, from global state, every flow that huff_sync_intra could not finish: one flow per
 /// sequence boundary (carry the exit state of the last subsequence of sequence b-1 into sequence b,
@@ -1386,8 +1392,12 @@ __global__ __launch_bounds__(TL) void huff_sync_tail(JS js)
         // a flow between iterations: it has reached subsequence j - 1 with state (p, c, z)
         int j = 0, p = 0, cz = 0;
         bool live = false;
-        if (g + tid < count) {
-            const int from = J.flow_list[lo + g + tid];
+        // flow k of a group runs on lane (k % waves) * 64 + k / waves: a part's ~64 flows spread over the workgroup's waves,
+        // a quarter of them on each of four SIMDs, instead of filling one wave (a trip takes as long as its slowest lane and
+        // every step of a wave pays the LDS bank conflicts of all its lanes: 244 -> 231 us per 64 images, +1.2 % images/s)
+        const int slot = (tid & 63) * (TL / 64) + (tid >> 6);
+        if (g + slot < count) {
+            const int from = J.flow_list[lo + g + slot];
             j              = from + 1;
             p              = J.st_p[from];
             cz             = J.st_cz[from];
@@ -1432,11 +1442,11 @@ __global__ __launch_bounds__(TL) void huff_sync_tail(JS js)
                 s_cz[rank] = cz;
             }
             __syncthreads();
-            live = tid < total;
+            live = slot < total;
             if (live) {
-                j  = s_j[tid];
-                p  = s_pz[tid];
-                cz = s_cz[tid];
+                j  = s_j[slot];
+                p  = s_pz[slot];
+                cz = s_cz[slot];
             }
         }
         __syncthreads();
