@@ -210,6 +210,12 @@ enum jpeggpu_status jpeggpu_ext_upsample_planes(
     int height,
     jpeggpu_stream_t stream);
 
+/* One small decode (a built-in 96 x 80 4:2:0 JPEG with restart markers, through the public calls above, device memory
+ * from hipMalloc) whose planes are compared with stored hashes: JPEGGPU_SUCCESS if the running system -- library build,
+ * driver, device -- decodes bit-exactly, JPEGGPU_INTERNAL_ERROR if not (or without a device). Synchronises `stream`.
+ * Meant for an application's start-up checks; the library never calls it on its own. */
+enum jpeggpu_status jpeggpu_ext_self_test(jpeggpu_stream_t stream);
+
 /* jpeggpu_decoder_parse_header for many images on `num_threads` host threads (the calling thread is one
  * of them). A 12 MP scan costs ~0.2 ms of one core to walk (reference src/reader.cpp:447-489 does the
  * same walk inside its timed loop), so a serving loop at 18 k images/s needs about four cores of it.

@@ -13,5 +13,6 @@ from .api import (  # noqa: F401
     decode_to_planes,
     lib,
     parse_headers,
+    self_test,
     status_string,
 )

@@ -126,6 +126,7 @@ def lib():
         C.POINTER(ImgInfo), C.POINTER(Img), C.POINTER(Img), C.c_int, C.c_int, C.c_void_p]
     L.jpeggpu_ext_set_segment_shard.argtypes = [dec, C.c_int, C.c_int]
     L.jpeggpu_ext_get_shard_rows.argtypes = [dec, C.c_int, C.POINTER(C.c_int), C.POINTER(C.c_int)]
+    L.jpeggpu_ext_self_test.argtypes = [C.c_void_p]
     L.jpeggpu_ext_set_device_scan.argtypes = [dec, C.c_int]
     L.jpeggpu_ext_get_device_status.argtypes = [dec, C.c_void_p, C.c_void_p, C.POINTER(C.c_int)]
     L.jpeggpu_ext_parse_headers.argtypes = [C.POINTER(ParseItem), C.c_int, C.c_int, C.POINTER(C.c_int)]
@@ -307,6 +308,12 @@ class Batch:
             self.destroy()
         except Exception:
             pass
+
+
+def self_test(stream: int = 0) -> None:
+    """jpeggpu_ext_self_test: one small built-in decode checked against stored plane hashes; raises JpegGpuError if the
+    running system does not decode bit-exactly."""
+    _check(lib().jpeggpu_ext_self_test(stream), "jpeggpu_ext_self_test")
 
 
 def decode_to_planes(data: bytes, device="cuda:0", subseq_bytes=None, return_tmp=False, device_scan=False):

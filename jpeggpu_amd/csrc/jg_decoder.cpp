@@ -11,6 +11,7 @@
 #include "jg_front.hpp"
 #include "jg_kernels.hpp"
 #include "jg_reader.hpp"
+#include "jg_selftest_data.h"
 
 #include <jpeggpu/jpeggpu.h>
 #include <jpeggpu/jpeggpu_ext.h>
@@ -1211,6 +1212,60 @@ enum jpeggpu_status jpeggpu_ext_planes_to_rgbi(
         src->image, src->pitch, info->sizes_x, info->sizes_y, info->subsampling.x, info->subsampling.y,
         sx_max, sy_max, nc, dst, dst_pitch, width, height, stream);
     return err == hipSuccess ? JPEGGPU_SUCCESS : JPEGGPU_INTERNAL_ERROR;
+}
+
+enum jpeggpu_status jpeggpu_ext_self_test(jpeggpu_stream_t stream)
+{
+    // One small decode through the public calls, planes hashed against constants. The write pass refills its bit window
+    // with a counted wait the compiler knows nothing about (jg_kernels.hip, RowWindow; the build checks the generated code,
+    // jpeggpu_amd/build.py): this is the same question asked of the running system -- driver, firmware, device.
+    jpeggpu_decoder_t dec = nullptr;
+    if (jpeggpu_decoder_startup(&dec) != JPEGGPU_SUCCESS) return JPEGGPU_OUT_OF_HOST_MEMORY;
+    jpeggpu_status result = JPEGGPU_INTERNAL_ERROR;
+    void* d_tmp           = nullptr;
+    uint8_t* d_planes     = nullptr;
+    std::vector<uint8_t> host;
+    do {
+        jpeggpu_img_info info;
+        if (jpeggpu_decoder_parse_header(dec, &info, jg::kSelfTestJpeg, sizeof(jg::kSelfTestJpeg)) != JPEGGPU_SUCCESS) break;
+        size_t tmp_size = 0, total = 0, off[3];
+        if (jpeggpu_decoder_get_buffer_size(dec, &tmp_size) != JPEGGPU_SUCCESS || info.num_components != 3) break;
+        for (int c = 0; c < 3; ++c) {
+            if (info.sizes_x[c] != jg::kSelfTestW[c] || info.sizes_y[c] != jg::kSelfTestH[c]) break;
+            off[c] = total;
+            total += static_cast<size_t>(jg::kSelfTestW[c]) * jg::kSelfTestH[c];
+        }
+        if (total != 96u * 80u + 2u * 48u * 40u) break;
+        if (hipMalloc(&d_tmp, tmp_size) != hipSuccess || hipMalloc(reinterpret_cast<void**>(&d_planes), total) != hipSuccess) break;
+        jpeggpu_img img{};
+        for (int c = 0; c < 3; ++c) {
+            img.image[c] = d_planes + off[c];
+            img.pitch[c] = jg::kSelfTestW[c];
+        }
+        if (jpeggpu_decoder_transfer(dec, d_tmp, tmp_size, stream) != JPEGGPU_SUCCESS) break;
+        if (jpeggpu_decoder_decode(dec, &img, d_tmp, tmp_size, stream) != JPEGGPU_SUCCESS) break;
+        try {
+            host.resize(total);
+        } catch (const std::bad_alloc&) {
+            result = JPEGGPU_OUT_OF_HOST_MEMORY;
+            break;
+        }
+        if (hipMemcpyAsync(host.data(), d_planes, total, hipMemcpyDeviceToHost, stream) != hipSuccess ||
+            hipStreamSynchronize(stream) != hipSuccess)
+            break;
+        bool same = true;
+        for (int c = 0; c < 3; ++c) {
+            uint64_t h = 0xcbf29ce484222325ull; // FNV-1a
+            for (size_t i = 0, n = static_cast<size_t>(jg::kSelfTestW[c]) * jg::kSelfTestH[c]; i < n; ++i) h = (h ^ host[off[c] + i]) * 0x100000001b3ull;
+            same = same && h == jg::kSelfTestHash[c];
+        }
+        result = same ? JPEGGPU_SUCCESS : JPEGGPU_INTERNAL_ERROR;
+    } while (false);
+    (void)hipGetLastError();
+    if (d_tmp) (void)hipFree(d_tmp);
+    if (d_planes) (void)hipFree(d_planes);
+    (void)jpeggpu_decoder_cleanup(dec);
+    return result;
 }
 
 enum jpeggpu_status jpeggpu_ext_parse_headers(

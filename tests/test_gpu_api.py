@@ -1,4 +1,5 @@
 """GPU-side API contract, the additive upsample kernel, and the full-size BASELINE configurations."""
+import os
 import threading
 
 import numpy as np
@@ -627,6 +628,36 @@ def test_baseline_configs_full_size(torch_cuda, cfg):
         assert info.num_components == ref.ncomp
         for c in range(ref.ncomp):
             assert np.array_equal(planes[c].cpu().numpy(), ref.planes[c]), (cfg, c, device_scan)
+
+
+def test_self_test_passes_and_its_constants_are_the_oracles(torch_cuda):
+    """jpeggpu_ext_self_test: the built-in image decodes to the stored plane hashes on this system; and those constants
+    (jpeggpu_amd/csrc/jg_selftest_data.h, data made once) are what the oracle says about that image: the array is read
+    back out of the header and decoded by the oracle here."""
+    import re
+
+    import jpeggpu_amd
+    from oracle import oracle
+    from tests.conftest import ROOT
+
+    jpeggpu_amd.self_test()
+    text = open(os.path.join(ROOT, "jpeggpu_amd", "csrc", "jg_selftest_data.h")).read()
+    body = text[text.index("kSelfTestJpeg[] = {"):]
+    data = bytes(int(x, 16) for x in re.findall(r"0x([0-9a-f]{2})\b", body[:body.index("};")]))
+    want = [int(x, 16) for x in re.findall(r"0x([0-9a-f]{16})ull", text)]
+    ref = oracle.decode(data)
+    assert len(data) == 5325 and ref.ncomp == 3 and len(want) == 3
+
+    def fnv(b):
+        h = 0xcbf29ce484222325
+        for x in b:
+            h = ((h ^ x) * 0x100000001b3) & 0xFFFFFFFFFFFFFFFF
+        return h
+
+    assert [fnv(p.tobytes()) for p in ref.planes] == want
+    planes, _ = jpeggpu_amd.decode_to_planes(data)
+    for c in range(3):
+        assert np.array_equal(planes[c].cpu().numpy(), ref.planes[c])
 
 
 def test_block_wise_multi_hypothesis_walk_without_restart_markers(torch_cuda, monkeypatch):
