@@ -415,6 +415,7 @@ jpeggpu_status build_jobs(
         sp.tab_bytes_sync   = static_cast<uint32_t>(sc.table_pack_sync.size());
         sp.cursor_off_sync  = sc.cursor_off_sync;
         sp.mh               = lone ? pl.mh : 0; // the multi-hypothesis kernels run in front of a lone decode's sequence kernel only
+        sp.seq_subseq       = lone ? kSeqSubseq : kSeqSubseqBatch; // a batch's sequences are longer: one overlap lane (jg_defs.h)
         job.mh_p            = reinterpret_cast<int*>(base + pl.mh_p);
         job.mh_cz           = reinterpret_cast<int*>(base + pl.mh_cz);
         job.mh_link         = reinterpret_cast<uint32_t*>(base + pl.mh_link);
@@ -484,7 +485,7 @@ jpeggpu_status build_jobs(
         job.sym_region  = sym_region_entries(d.subseq_bytes);
         job.sym_entries = sym_buffer_entries(static_cast<uint32_t>(sc.num_subseq), job.sym_region);
         job.num_chunks = static_cast<int>(sc.chunks.size());
-        job.num_seq    = pl.num_seq;
+        job.num_seq    = static_cast<int>((static_cast<size_t>(sc.num_subseq) + sp.seq_subseq - 1) / sp.seq_subseq); // <= pl.num_seq, what the arrays are sized for
         if (sc.device_walk) {
             // tables built by jg_front.hip in device memory; the counts below are capacities (launch extents),
             // the device writes the real ones into its copy of the job
@@ -838,7 +839,7 @@ enum jpeggpu_status jpeggpu_ext_get_layout(jpeggpu_decoder_t decoder, struct jpe
     const jg::Stream& s = d.reader.s;
     std::memset(out, 0, sizeof(*out));
     out->subsequence_bytes = d.subseq_bytes;
-    out->subsequences_per_sequence = jg::kSeqSubseq;
+    out->subsequences_per_sequence = d.batched ? jg::kSeqSubseqBatch : jg::kSeqSubseq; // of the call type the decoder was set up for
     out->num_scans         = s.num_scans;
     out->transferred_bytes = d.plan.bytes_len;
     out->blob_bytes        = d.plan.blob_size;
@@ -856,7 +857,7 @@ enum jpeggpu_status jpeggpu_ext_get_layout(jpeggpu_decoder_t decoder, struct jpe
         o.off_state_dc23 = pl.st_dc23;
         o.num_subsequences   = sc.num_subseq;
         o.num_segments       = static_cast<int>(sc.segments.size());
-        o.num_sequences      = pl.num_seq;
+        o.num_sequences      = static_cast<int>((static_cast<size_t>(sc.num_subseq) + out->subsequences_per_sequence - 1) / out->subsequences_per_sequence);
         o.num_data_units     = sc.num_du;
         o.data_units_per_mcu = sc.du_per_mcu;
         o.num_chunks         = static_cast<int>(sc.chunks.size());

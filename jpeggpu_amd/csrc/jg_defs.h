@@ -21,7 +21,13 @@ constexpr int kMaxScans     = 4;  // baseline: every component appears in exactl
 constexpr int kMaxDuPerMcu  = 10; // T.81 B.2.3
 constexpr int kSeqLanes    = 256; // lanes per workgroup of the Huffman kernels (reference decode_huffman.cu:777)
 constexpr int kSeqOverlap  = 16;  // lanes of the sync kernel that re-decode the tail of the previous sequence
-constexpr int kSeqSubseq   = kSeqLanes - kSeqOverlap; // subsequences owned by one workgroup ("sequence")
+constexpr int kSeqSubseq   = kSeqLanes - kSeqOverlap; // subsequences owned by one workgroup ("sequence") of a LONE decode
+// A batch runs ONE flow iteration in the sequence kernel, and the only overlap lane whose work that iteration uses is the
+// last one (its flow gives the sequence's first subsequence its n and DC sums): its sequences are 255 subsequences
+// long, one lane re-decodes the previous sequence's last subsequence (ScanParams::seq_subseq says which a job has). The
+// 15 lanes saved are 6 % of the sequence kernel's and of the write pass's workgroups (round 4).
+constexpr int kSeqOverlapBatch = 1;
+constexpr int kSeqSubseqBatch  = kSeqLanes - kSeqOverlapBatch;
 // Target subsequences per workgroup of huff_sync_tail (cut at segment starts). The kernel is a chain of dependent
 // whole-subsequence decodes (two to four trips of its lock-step loop) for the ~8 % of the subsequences whose flow the
 // sequence kernel left unfinished, so what it costs is latency, and a part's trip takes as long as the slowest lane of
@@ -260,6 +266,7 @@ struct ScanParams {
     uint32_t cursor_off;  // byte offset of the cursor ring in that pack
     uint32_t tab_bytes_sync, cursor_off_sync; // the same for the sync pack (state-only passes)
     int mh;               // hypotheses per subsequence of the multi-hypothesis speculation (below); 0: off
+    int seq_subseq;       // subsequences a workgroup of the Huffman kernels owns: kSeqSubseq (lone decode) or kSeqSubseqBatch
     /// The state-only kernels call this on their copy of the parameters before loading the tables.
     JG_HD inline void use_sync_pack()
     {

@@ -388,7 +388,8 @@ __global__ __launch_bounds__(PL) void front_plan(FS src)
         JG_GLOBAL ScanJob* job = as_global(P.job);
         const bool fits        = S <= P.max_subseq && C <= P.max_chunks;
         job->num_chunks        = fits ? static_cast<int>(C) : 0;
-        job->num_seq           = fits ? static_cast<int>((S + kSeqSubseq - 1) / kSeqSubseq) : 0;
+        const uint32_t seq     = static_cast<uint32_t>(job->sp.seq_subseq); // per job: a lone decode's sequences or a batch's (jg_defs.h)
+        job->num_seq           = fits ? static_cast<int>((S + seq - 1) / seq) : 0;
         job->num_tail_parts    = fits ? static_cast<int>(nparts) : 0;
         job->sp.num_subseq     = fits ? static_cast<int>(S) : 0;
         job->sp.num_segments   = static_cast<int>(E);

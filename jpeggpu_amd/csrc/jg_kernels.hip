@@ -30,8 +30,10 @@ namespace jg {
 namespace {
 
 constexpr int T   = kSeqLanes;   // lanes per workgroup in the Huffman kernels
-constexpr int SEQ = kSeqSubseq;  // subsequences a workgroup owns
-constexpr int OV  = kSeqOverlap; // lanes that re-decode the tail of the previous sequence
+// Subsequences a workgroup owns (SEQ) and lanes that re-decode the tail of the previous sequence (OV = T - SEQ): per job,
+// ScanParams::seq_subseq -- 240 + 16 for a lone decode, 255 + 1 in batches (jg_defs.h). Every kernel reads it into a local
+// `SEQ` (uniform: a scalar register).
+constexpr int kMaxSeq = kSeqLanes - 1;
 
 /// Pointers read out of a job that lives in memory are generic to the compiler, and generic (flat) loads
 /// and stores count against lgkmcnt as well as vmcnt: every wait for an LDS table read would also wait for
@@ -662,6 +664,7 @@ __global__ __launch_bounds__(T) void huff_sync_intra(JS js)
     const int t         = threadIdx.x;
     s_pend[t]           = 0;
     if (t == 0) s_cut = 0;
+    const int SEQ = sp.seq_subseq, OV = T - SEQ;             // 240 + 16 for a lone decode, 255 + 1 in batches (jg_defs.h)
     const int first_sub = blockIdx.x * SEQ;                  // first subsequence this workgroup owns
     const int img_first = first_sub - OV;                    // subsequence of lane 0
     const int img_end   = min(T, sp.num_subseq - img_first); // lanes below this have a subsequence
@@ -847,6 +850,7 @@ __global__ __launch_bounds__(T) void huff_sync_intra_batch(JS js)
     sp.use_sync_pack();
     const int t         = threadIdx.x;
     s_pend[t]           = 0;
+    const int SEQ = sp.seq_subseq, OV = T - SEQ;             // 240 + 16 for a lone decode, 255 + 1 in batches (jg_defs.h)
     const int first_sub = blockIdx.x * SEQ;                  // first subsequence this workgroup owns
     const int img_first = first_sub - OV;                    // subsequence of lane 0
     const int img_end   = min(T, sp.num_subseq - img_first); // lanes below this have a subsequence
@@ -1364,6 +1368,7 @@ __global__ __launch_bounds__(TL) void huff_sync_tail(JS js)
     // TL subsequences: 48 000 subsequences of a 12 MP scan without restart markers are ONE part, and building its list took
     // 60 of the kernel's 70 us.)
     const bool marks = sp.max_intra_iters < T;
+    const int SEQ    = sp.seq_subseq;
     const int step   = marks ? 1 : SEQ;
     int count = 0;
     for (int base = marks ? lo : (lo + SEQ) / SEQ * SEQ - 1; base < hi; base += TL * step) {
@@ -1483,6 +1488,7 @@ __global__ __launch_bounds__(T) void huff_seq_tails(JS js)
     const JobView J(js.get());
     if (static_cast<int>(blockIdx.x) >= J.num_seq) return;
     const int t         = threadIdx.x;
+    const int SEQ       = J.sp.seq_subseq;
     const int first_sub = blockIdx.x * SEQ;
     const int nsub      = min(SEQ, J.sp.num_subseq - first_sub);
     const int last_seg  = J.seg_idx[first_sub + nsub - 1];
@@ -1716,7 +1722,7 @@ __device__ __forceinline__ uint32_t pk_sub(uint32_t a, uint32_t b) { return pk_a
 struct WriteLds {
     static constexpr uint32_t kScan = 0;                                   // T + 1 + 4 + 3 words
     static constexpr uint32_t kRing = ((T + 8) * 4 + 15) / 16 * 16;
-    static constexpr uint32_t kTabs = (kRing + kRingStride * SEQ + 15) / 16 * 16; // lanes SEQ..T-1 emit nothing
+    static constexpr uint32_t kTabs = (kRing + kRingStride * kMaxSeq + 15) / 16 * 16; // lanes SEQ..T-1 emit nothing (SEQ <= 255)
     static_assert(kTabs % 16 == 0, "the table pack is read with 16-byte loads");
     static_assert(kStaticLdsSlack + kTabs + kMaxTablePack <= 65536, "absolute table addresses are packed into 16 bits (load_tables)");
 };
@@ -1743,6 +1749,7 @@ __global__ __launch_bounds__(T) void huff_write(JS js)
     if (static_cast<int>(blockIdx.x) >= J.num_seq) return;
     ScanParams sp = J.sp;
     const int t         = threadIdx.x;
+    const int SEQ       = sp.seq_subseq;
     const int first_sub = blockIdx.x * SEQ;
     const int nsub      = min(SEQ, sp.num_subseq - first_sub);
 

@@ -288,7 +288,7 @@ int emu_decode_scan(
     sp_sync.use_sync_pack();
 
     const int S    = sc.num_subseq;
-    const int T    = kSeqSubseq;
+    const int T    = max_intra_iters >= kSeqLanes ? kSeqSubseq : kSeqSubseqBatch; // a lone decode's sequences, or a batch's (jg_defs.h)
     const int bits = subseq_bytes * 8;
     const int W    = subseq_bytes / 4;
     std::vector<St> st(S);
