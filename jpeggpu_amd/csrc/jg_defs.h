@@ -80,7 +80,10 @@ constexpr int kDestuffWin   = 4096; // stuffed bytes handled by one destuff work
 /// A lane keeps the entry of the data unit it is in; at the end of a data unit it loads the next one.
 /// This replaces per-symbol table selection arithmetic by one LDS read per symbol.
 constexpr int kLutBitsDc   = 9;
-constexpr int kLutBitsAc   = 11;
+#ifndef JG_LUT_BITS_AC
+#define JG_LUT_BITS_AC 11
+#endif
+constexpr int kLutBitsAc   = JG_LUT_BITS_AC;
 constexpr int kSubBits     = 5;
 constexpr int kSubTableSize = 2 << kSubBits; // bytes
 constexpr int kMaxSubTables = 16;
