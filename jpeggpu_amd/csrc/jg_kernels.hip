@@ -1937,25 +1937,35 @@ __device__ __forceinline__ void unpack8(const uint4& raw, int (&v)[8])
 constexpr int kIdctIters    = 8;                            // groups of 32 data units per workgroup
 constexpr int kIdctDuPerWg  = kIdctDuPerBlock * kIdctIters; // 256
 
+/// Two 16-bit products at once (v_pk_mul_lo_u16): the low halves of coefficient * quantiser.
+__device__ __forceinline__ uint32_t mul_lo_u16x2(uint32_t a, uint32_t b)
+{
+    typedef unsigned short u16x2 __attribute__((ext_vector_type(2)));
+    return __builtin_bit_cast(uint32_t, static_cast<u16x2>(__builtin_bit_cast(u16x2, a) * __builtin_bit_cast(u16x2, b)));
+}
+
 /// One data unit per 8 lanes, kIdctIters groups of 32 units per workgroup. The unit's entries are
-/// gathered from the symbol stream (consecutive 4-byte reads), de-zigzagged and dequantised on the
-/// way into LDS; everything else is zero. Steps and int16 truncation points are those of the
-/// reference `idct_kernel` (src/idct.cu:146-223): (int16)(coef * q) -> column pass -> row pass ->
-/// +128 -> clamp. The MCU geometry (reference decode_transpose.cu:65-131) is applied when the 8x8
-/// pixels are stored.
+/// gathered from the symbol stream (aligned 4-byte reads of two entries) and de-zigzagged on the
+/// way into LDS; everything else is zero. The lane of the column pass dequantises its column when it
+/// reads it. Steps and int16 truncation points are those of the reference `idct_kernel`
+/// (src/idct.cu:146-223): (int16)(coef * q) -> column pass -> row pass -> +128 -> clamp. The MCU
+/// geometry (reference decode_transpose.cu:65-131) is applied when the 8x8 pixels are stored.
 ///
 /// Two things bound a naive version: LDS instruction issue and the chain of dependent loads
 /// (table entry -> symbol entries) paid once per tiny workgroup. So the block is staged TRANSPOSED
 /// ([column][row]: zeroing is one 16-byte write, the column pass one 16-byte read), all table
-/// entries of the workgroup are loaded up front, and the first two symbol entries of each lane are
-/// fetched one iteration ahead.
+/// entries of the workgroup are loaded up front, and the first entries of each lane are fetched one
+/// iteration ahead.
 template <class JS>
 __global__ __launch_bounds__(256) void idct_kernel(JS js)
 {
     __shared__ __attribute__((aligned(16))) int16_t s_blk[kIdctDuPerBlock][kIdctDuStride]; // [unit][col * 8 + row]
-    // [quantisation table][zig-zag index]: byte offset of the coefficient's transposed slot in a staged block (low
-    // byte) and the quantiser (high half, up to 16 bits): both sit where an SDWA operand can pick them up
-    __shared__ uint32_t s_zq[4 * 64];
+    // [quantisation table][column][row]: the 16 bytes a lane of the column pass multiplies its column with
+    // ((int16)(coef * q), reference idct.cu:178-180: the low 16 bits of the product, whatever the signs)
+    __shared__ __attribute__((aligned(16))) uint16_t s_qcol[4 * 64];
+    // zig-zag index -> byte offset of the coefficient's transposed slot in a staged block. 64 bytes are 16 banks:
+    // lanes that ask for different entries never collide (same word: broadcast).
+    __shared__ __attribute__((aligned(16))) uint8_t s_slot[64];
     __shared__ uint2 s_px[2][kIdctDuPerBlock][9]; // finished pixel rows, [buffer][unit][row] (+1: bank spread)
     // Where the pixels of each of the workgroup's data units go, worked out ONCE per unit by lane = unit (reference
     // decode_transpose.cu:65-131 walks the same geometry): address of the unit's top-left pixel, pitch, how many of
@@ -1964,8 +1974,9 @@ __global__ __launch_bounds__(256) void idct_kernel(JS js)
     struct UnitGeo {
         uint32_t addr_lo, addr_hi;
         int pitch;
-        uint32_t vis; // visible columns | visible rows << 4 | quantisation table << 8
+        uint32_t vis; // visible columns | visible rows << 4 | quantisation table << 8 | kGeoWhole
     };
+    constexpr uint32_t kGeoWhole = 1u << 12; // all 8 columns visible and every row 8-byte aligned: one store per row
     __shared__ __attribute__((aligned(16))) UnitGeo s_geo[kIdctDuPerWg];
 
     const JobView J(js.get());
@@ -1978,11 +1989,12 @@ __global__ __launch_bounds__(256) void idct_kernel(JS js)
     const int r  = t & 7;  // column (pass 1) or row (pass 2) handled by this lane
     const int dl = t >> 3; // data unit inside the group
 
-    {
-        // natural index = row * 8 + col -> transposed slot col * 8 + row; unsigned q (Appendix B-3)
+    s_qcol[t] = J.qtables[(t & ~63) + (t & 7) * 8 + ((t >> 3) & 7)]; // [table][col][row] <- natural row * 8 + col
+    if (t < 64) {
+        // natural index = row * 8 + col -> transposed slot col * 8 + row
         constexpr uint8_t nat[64] = JG_ORDER_NATURAL;
-        const int n               = nat[t & 63];
-        s_zq[t] = static_cast<uint32_t>(((n & 7) * 8 + (n >> 3)) * 2) | static_cast<uint32_t>(J.qtables[(t & ~63) + n]) << 16;
+        const int n               = nat[t];
+        s_slot[t]                 = static_cast<uint8_t>(((n & 7) * 8 + (n >> 3)) * 2);
     }
     {
         const int du = du0 + t;
@@ -1998,14 +2010,15 @@ __global__ __launch_bounds__(256) void idct_kernel(JS js)
             const int y0  = (my * ip.comp_v[sc] + ip.du_dy[k]) * 8;
             const int vx  = min(max(ip.size_x[sc] - x0, 0), 8), vy = min(max(ip.size_y[sc] - y0, 0), 8);
             const uint64_t a = reinterpret_cast<uint64_t>(ip.plane[sc]) + static_cast<uint64_t>(y0) * static_cast<uint32_t>(ip.pitch[sc]) + static_cast<uint32_t>(x0);
+            const bool whole = vx == 8 && ((a | static_cast<uint32_t>(ip.pitch[sc])) & 7u) == 0;
             g = UnitGeo{static_cast<uint32_t>(a), static_cast<uint32_t>(a >> 32), ip.pitch[sc],
-                        static_cast<uint32_t>(vx) | static_cast<uint32_t>(vy) << 4 | static_cast<uint32_t>(ip.qidx[sc]) << 8};
+                        static_cast<uint32_t>(vx) | static_cast<uint32_t>(vy) << 4 | static_cast<uint32_t>(ip.qidx[sc]) << 8 | (whole ? kGeoWhole : 0u)};
         }
         s_geo[t] = g;
     }
     int16_t* blk = s_blk[dl];
     uint8_t* const blk_bytes = reinterpret_cast<uint8_t*>(blk);
-    __syncthreads(); // s_zq, s_geo are loaded
+    __syncthreads(); // s_qcol, s_slot, s_geo are loaded
 
     // table entries of all iterations (independent loads, one latency); a table entry that was never
     // written (corrupt stream) must not lead out of the buffer
@@ -2019,97 +2032,93 @@ __global__ __launch_bounds__(256) void idct_kernel(JS js)
         tcnt[it] = e.y & 0xFFu; // entries (at most 127) | kUnitHasEscape
         toff[it] = static_cast<uint32_t>(e.x < limit ? e.x : limit);
     }
-#ifndef JG_IDCT_PREFETCH
-#define JG_IDCT_PREFETCH 4
+#ifndef JG_IDCT_PAIRS
+#define JG_IDCT_PAIRS 2
 #endif
-    constexpr int kAhead = JG_IDCT_PREFETCH; // entries per lane fetched one iteration ahead (8 lanes: kAhead * 8 per unit)
-    uint32_t nx[kAhead];
-    // Entries r, r + 8, r + 16, ...: sixteen entries further is the same slot of the next sector. The loads stay
-    // predicated on the unit's entry count: fetching the sectors behind a unit's last entry without asking (no
-    // compare, no branch) was measured 5 % slower -- this kernel waits for memory, not for instruction issue
-    // (15 % fewer vector instructions from the geometry table bought 3 %).
-    // (scalar base + 32-bit byte offset: one address computation per entry, no 64-bit arithmetic)
+    // Entry PAIRS per lane fetched one iteration ahead: the lane reads the aligned 32-bit words r, r + 8, ... of the
+    // sector row its unit starts in, counted from the word that holds the unit's first entry. Eight words further is
+    // the same word of the next sector (one 32-byte sector = 16 entries = 8 words): +2048 bytes, an immediate. With an
+    // odd first entry the low half of lane 0's first word belongs to the unit in front. (Up to round 4 the lanes read
+    // single entries: twice the loads and twice the address arithmetic in a kernel that is bound by instruction issue.)
+    constexpr int kPairs = JG_IDCT_PAIRS;
+    static_assert(kPairs * kSymSectorStride * 2 <= 4096 + 2048, "immediate offsets of the loads");
+    uint32_t nx[kPairs];
     const auto entry_at = [&](uint32_t index) -> uint32_t {
         return *reinterpret_cast<JG_GLOBAL const uint16_t*>(reinterpret_cast<JG_GLOBAL const uint8_t*>(J.sym) + index * 2u);
     };
-    // entries r, r + 8, r + 16, r + 24 of a unit: 8 further is the same sector or, from the upper half of one, the
-    // lower half of the next
-    // Entry w of the sector row that holds `first` (w = first % 16 + j for the unit's entry j) lies at entry index
-    // (first & ~15) + (w / 16) * 1024 + w % 16 = (first & ~15) + w + (w & ~15) * 63: in BYTES one AND and one
-    // multiply-add per entry, the step of 8 entries between a lane's fetches inside the AND's operand.
-    const auto prefetch = [&](uint32_t first, uint32_t cnt, uint32_t (&out)[kAhead]) {
-        const uint32_t w2   = ((first & (kSymSectorEntries - 1u)) + static_cast<uint32_t>(r)) * 2u; // byte offset of entry r in the row
-        const uint32_t row2 = (first & ~(kSymSectorEntries - 1u)) * 2u + w2;
+    // Entry j of the unit sits in half (j + odd) & 1 of word (j + odd) / 2 counted as above; a lane's word k holds
+    // the entries jb + 16 k and jb + 16 k + 1, jb = 2 r - odd.
+    const auto prefetch = [&](uint32_t first, uint32_t cnt, uint32_t (&out)[kPairs]) {
+        const uint32_t w4   = ((first & (kSymSectorEntries - 1u)) >> 1) * 4u + static_cast<uint32_t>(r) * 4u; // byte offset of the word in the row
+        const uint32_t base = (first * 2u & ~(2u * kSymSectorEntries - 1u)) + (w4 & 28u) + (w4 & 32u) * (kSymSectorStride * 2u / 32u);
+        const int jb        = 2 * r - static_cast<int>(first & 1u);
         JG_GLOBAL const uint8_t* stream = reinterpret_cast<JG_GLOBAL const uint8_t*>(J.sym);
 #pragma unroll
-        for (int k = 0; k < kAhead; ++k) {
-            const uint32_t sector2 = (w2 + 16u * k) & ~(2u * kSymSectorEntries - 1u);
-            out[k] = static_cast<uint32_t>(r + 8 * k) < cnt
-                         ? *reinterpret_cast<JG_GLOBAL const uint16_t*>(stream + (row2 + sector2 * (kSymSectorStride / kSymSectorEntries - 1u)) + 16u * k)
-                         : 0u;
-        }
+        for (int k = 0; k < kPairs; ++k)
+            out[k] = jb + 16 * k < static_cast<int>(cnt) ? *reinterpret_cast<JG_GLOBAL const uint32_t*>(stream + base + k * (kSymSectorStride * 2u)) : 0u;
     };
     prefetch(toff[0], tcnt[0] & 0x7Fu, nx);
 
 #pragma unroll
     for (int it = 0; it < kIdctIters; ++it) {
-        uint32_t ex[kAhead];
+        uint32_t ex[kPairs];
 #pragma unroll
-        for (int k = 0; k < kAhead; ++k) ex[k] = nx[k];
+        for (int k = 0; k < kPairs; ++k) ex[k] = nx[k];
         if (it + 1 < kIdctIters) prefetch(toff[it + 1], tcnt[it + 1] & 0x7Fu, nx); // in flight while this one computes
         // The 8 lanes of a data unit sit in one wave and LDS executes a wave's instructions in order,
         // so the phases below need no workgroup barrier among themselves; only the pixel re-mapping
         // at the end crosses waves (one barrier per iteration, buffers alternate).
         *reinterpret_cast<uint4*>(blk + r * 8) = make_uint4(0, 0, 0, 0);
 
-        const uint32_t* zq = s_zq + ((s_geo[it * kIdctDuPerBlock + dl].vis >> 8) & 3u) * 64;
-        // dequantise and place one coefficient: zig-zag index, value (its low 16 bits count, reference idct.cu:178-180)
-        const auto put = [&](uint32_t zz, uint32_t value) {
-            const uint32_t e = zq[zz];
-            *reinterpret_cast<int16_t*>(blk_bytes + (e & 0xFFu)) = static_cast<int16_t>(value * (e >> 16));
-        };
+        const uint32_t qtab = (s_geo[it * kIdctDuPerBlock + dl].vis >> 8) & 3u;
+        // place one coefficient, not yet dequantised: zig-zag index, value (its low 16 bits count)
+        const auto put = [&](uint32_t zz, uint32_t value) { *reinterpret_cast<int16_t*>(blk_bytes + s_slot[zz]) = static_cast<int16_t>(value); };
         const uint32_t cnt = tcnt[it] & 0x7Fu;
+        const uint32_t odd = toff[it] & 1u;
         // Entry j of the unit (jg_defs.h): j == 0 is the DC value; an AC entry holds value << 6 | index; an entry
         // with index 0 behind one is the ESCAPE that carries the value's high bits. The unit's record says whether it
         // holds one (no photograph does): the wave asks once.
         if (__builtin_expect(__ballot((tcnt[it] & kUnitHasEscape) != 0) == 0, 1)) {
+            const int jb = 2 * r - static_cast<int>(odd);
+            // the look-ups first, all of them (an index of a word that was not loaded is 0): one LDS latency, not one per entry
+            uint32_t slot[kPairs][2];
 #pragma unroll
-            for (int k = 0; k < kAhead; ++k) {
-                if (static_cast<uint32_t>(r + 8 * k) < cnt) {
-                    const uint32_t e = ex[k];
-                    if (k == 0 && r == 0) put(0, e);
-                    else put(sym_entry_index(e), static_cast<uint32_t>(sym_entry_value(e)));
+            for (int k = 0; k < kPairs; ++k) {
+                slot[k][0] = s_slot[ex[k] & 63u];
+                slot[k][1] = s_slot[(ex[k] >> 16) & 63u];
+            }
+            if (r == 0) blk[0] = static_cast<int16_t>(ex[0] >> (odd * 16u)); // DC: lane 0, the half the unit starts in
+#pragma unroll
+            for (int k = 0; k < kPairs; ++k) {
+#pragma unroll
+                for (int h = 0; h < 2; ++h) {
+                    // 1 <= j < cnt
+                    if (static_cast<uint32_t>(jb + 16 * k + h - 1) < cnt - 1u)
+                        *reinterpret_cast<int16_t*>(blk_bytes + slot[k][h]) = static_cast<int16_t>(static_cast<int32_t>(ex[k] << (16 - 16 * h)) >> 22);
                 }
+            }
+            for (uint32_t i = 16u * kPairs - odd + static_cast<uint32_t>(r); i < cnt; i += 8) { // dense units only: entries behind the fetched words
+                const uint32_t e = entry_at(sym_advance(toff[it], i));
+                put(sym_entry_index(e), static_cast<uint32_t>(sym_entry_value(e)));
             }
         } else {
-            // the entry behind a lane's own: the right neighbour's of the same round, or, for the last lane of the
-            // unit, the first lane's of the next round (row_shl:1 / row_shr:7 stay inside a row of 16 lanes)
-#pragma unroll
-            for (int k = 0; k < kAhead; ++k) {
-                const uint32_t right = static_cast<uint32_t>(__builtin_amdgcn_update_dpp(0, static_cast<int>(ex[k]), 0x101, 0xF, 0xF, false));
-                uint32_t wrap        = 1u; // behind the last prefetched entry: looked up below
-                if (k + 1 < kAhead) wrap = static_cast<uint32_t>(__builtin_amdgcn_update_dpp(0, static_cast<int>(ex[k + 1]), 0x117, 0xF, 0xF, false));
-                uint32_t next = r == 7 ? wrap : right;
-                const uint32_t j = r + 8 * k;
-                if (k + 1 == kAhead && r == 7 && j + 1 < cnt) next = entry_at(sym_advance(toff[it], j + 1));
-                if (j + 1 >= cnt) next = 1u; // nothing behind the unit's last entry
-                if (j < cnt) {
-                    const uint32_t e = ex[k];
-                    if (j == 0) put(0, e);
-                    else if (sym_entry_index(e) != 0)
-                        put(sym_entry_index(e), static_cast<uint32_t>(sym_entry_index(next) == 0 ? sym_entry_value(e, next) : sym_entry_value(e)));
-                }
+            for (uint32_t i = r; i < cnt; i += 8) {
+                const uint32_t e    = entry_at(sym_advance(toff[it], i));
+                const uint32_t next = i + 1 < cnt ? entry_at(sym_advance(toff[it], i + 1)) : 1u;
+                if (i == 0) put(0, e);
+                else if (sym_entry_index(e) != 0)
+                    put(sym_entry_index(e), static_cast<uint32_t>(sym_entry_index(next) == 0 ? sym_entry_value(e, next) : sym_entry_value(e)));
+                asm volatile("" ::"v"(next)); // no load of this rare path is left in flight: the common path behind it would wait for it with everything else
             }
-        }
-        for (uint32_t i = r + 8 * kAhead; i < cnt; i += 8) { // dense units only
-            const uint32_t e    = entry_at(sym_advance(toff[it], i));
-            const uint32_t next = i + 1 < cnt ? entry_at(sym_advance(toff[it], i + 1)) : 1u;
-            if (sym_entry_index(e) != 0)
-                put(sym_entry_index(e), static_cast<uint32_t>(sym_entry_index(next) == 0 ? sym_entry_value(e, next) : sym_entry_value(e)));
         }
         __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
         int v[8];
-        unpack8(*reinterpret_cast<const uint4*>(blk + r * 8), v); // column r
+        {
+            uint4 col      = *reinterpret_cast<const uint4*>(blk + r * 8); // column r
+            const uint4 qc = *reinterpret_cast<const uint4*>(s_qcol + qtab * 64u + r * 8);
+            col.x = mul_lo_u16x2(col.x, qc.x), col.y = mul_lo_u16x2(col.y, qc.y), col.z = mul_lo_u16x2(col.z, qc.z), col.w = mul_lo_u16x2(col.w, qc.w);
+            unpack8(col, v);
+        }
         __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront"); // every column is read before rows overwrite the block
         idct8(v);
 #pragma unroll
@@ -2127,6 +2136,14 @@ __global__ __launch_bounds__(256) void idct_kernel(JS js)
         // consecutive lanes write the neighbouring 8-byte segments of one image row.
         s_px[it & 1][dl][r] = o;
         __syncthreads();
+        // The next iteration's entries have had this iteration's time to arrive; asking for them HERE, in front of the
+        // pixel stores, keeps those stores out of the wait (one counter counts loads and stores, and behind the
+        // stores' branches the compiler can only wait for everything: every iteration then stood until its
+        // predecessor's pixels had reached L2).
+        if (it + 1 < kIdctIters) {
+#pragma unroll
+            for (int k = 0; k < kPairs; ++k) asm volatile("" : "+v"(nx[k]));
+        }
         {
             const int r2      = t >> 5;
             const int j       = t & 31;
@@ -2136,7 +2153,7 @@ __global__ __launch_bounds__(256) void idct_kernel(JS js)
                 const uint2 w = s_px[it & 1][j][r2];
                 JG_GLOBAL uint8_t* row = reinterpret_cast<JG_GLOBAL uint8_t*>(
                     ((static_cast<uint64_t>(g.addr_hi) << 32) | g.addr_lo) + static_cast<uint64_t>(static_cast<uint32_t>(r2)) * static_cast<uint64_t>(static_cast<uint32_t>(g.pitch))); // one v_mad_u64_u32
-                if (vx == 8 && (reinterpret_cast<uintptr_t>(row) & 7) == 0) {
+                if (g.vis & kGeoWhole) {
                     st_global(reinterpret_cast<JG_GLOBAL uint2*>(row), w);
                 } else {
 #pragma unroll
