@@ -1884,8 +1884,12 @@ __device__ __forceinline__ void idct8(int (&v)[8])
 
     const int e0 = (v[0] + v[4]) * cos_1_4;
     const int e1 = (v[0] - v[4]) * cos_1_4;
-    const int e2 = v[2] * sin_1_8 - v[6] * cos_1_8;
-    const int e3 = v[6] * sin_1_8 + v[2] * cos_1_8;
+    // (a rotation as three products: x s - y c = (x + y) s - y (s + c), y s + x c = (x + y) s + x (c - s); the same
+    // numbers in wrapping 32-bit arithmetic, and an addition issues faster than a multiplication)
+    int z26 = (v[2] + v[6]) * sin_1_8;
+    asm("" : "+v"(z26)); // one product with two users: left to itself the compiler multiplies it out again inside each of them
+    const int e2  = z26 - v[6] * (sin_1_8 + cos_1_8);
+    const int e3  = z26 + v[2] * (cos_1_8 - sin_1_8);
     const int a0 = e0 + e3, a1 = e1 + e2, a2 = e1 - e2, a3 = e0 - e3;
 
     const int m0 = unfixo((v[3] + v[5]) * cos_1_4);
@@ -1893,10 +1897,14 @@ __device__ __forceinline__ void idct8(int (&v)[8])
     // x4 written as a multiplication: `<<` on a negative int is undefined before C++20 and hipcc uses that
     const int q1 = v[1] * 4, q7 = v[7] * 4;
     const int o0 = q1 + m0, o1 = q7 + m1, o2 = q1 - m0, o3 = q7 - m1;
-    const int b0 = o0 * ocos_1_16 + o1 * osin_1_16;
-    const int b1 = o0 * osin_1_16 - o1 * ocos_1_16;
-    const int b2 = o2 * ocos_5_16 + o3 * osin_5_16;
-    const int b3 = o2 * osin_5_16 - o3 * ocos_5_16;
+    int z01 = (o0 + o1) * osin_1_16;
+    asm("" : "+v"(z01));
+    const int b0  = z01 + o0 * (ocos_1_16 - osin_1_16); // o0 c + o1 s
+    const int b1  = z01 - o1 * (ocos_1_16 + osin_1_16); // o0 s - o1 c
+    int z23 = (o2 + o3) * osin_5_16;
+    asm("" : "+v"(z23));
+    const int b2  = z23 + o2 * (ocos_5_16 - osin_5_16); // o2 c + o3 s
+    const int b3  = z23 - o3 * (ocos_5_16 + osin_5_16); // o2 s - o3 c
 
     // results rounded but NOT shifted: the int16 the reference stores (`unfixh`) is the high half
     v[0] = a0 + b0 + kRound;
@@ -1914,14 +1922,16 @@ __device__ __forceinline__ uint32_t magic_quot(uint32_t n, uint32_t mul, uint32_
     return mul ? __umulhi(n, mul) >> shift : n;
 }
 
-/// Two finished samples from two row-pass results whose high halves already hold (int16)(t + 128): clamped to
-/// 0..255 (reference src/idct.cu:218-220), as two bytes in the low half of the result.
-__device__ __forceinline__ uint32_t finish_pixels(int w0, int w1)
+/// Four finished samples from four row-pass results whose high halves already hold (int16)(t + 128): clamped to
+/// 0..255 (reference src/idct.cu:218-220), one byte each.
+__device__ __forceinline__ uint32_t finish_pixels(int w0, int w1, int w2, int w3)
 {
-    const uint32_t pair = __builtin_amdgcn_perm(static_cast<uint32_t>(w1), static_cast<uint32_t>(w0), 0x07060302u);
-    uint32_t r;
-    asm("v_sat_pk_u8_i16 %0, %1" : "=v"(r) : "v"(pair));
-    return r & 0xFFFFu;
+    const uint32_t lo = __builtin_amdgcn_perm(static_cast<uint32_t>(w1), static_cast<uint32_t>(w0), 0x07060302u);
+    const uint32_t hi = __builtin_amdgcn_perm(static_cast<uint32_t>(w3), static_cast<uint32_t>(w2), 0x07060302u);
+    uint32_t a, b;
+    asm("v_sat_pk_u8_i16 %0, %1" : "=v"(a) : "v"(lo)); // two bytes in the low half
+    asm("v_sat_pk_u8_i16 %0, %1" : "=v"(b) : "v"(hi));
+    return __builtin_amdgcn_perm(b, a, 0x05040100u);
 }
 
 constexpr int kIdctDuPerBlock = 32; // 8 lanes per data unit, 256 lanes
@@ -1954,8 +1964,8 @@ __device__ __forceinline__ uint32_t mul_lo_u16x2(uint32_t a, uint32_t b)
 /// Two things bound a naive version: LDS instruction issue and the chain of dependent loads
 /// (table entry -> symbol entries) paid once per tiny workgroup. So the block is staged TRANSPOSED
 /// ([column][row]: zeroing is one 16-byte write, the column pass one 16-byte read), all table
-/// entries of the workgroup are loaded up front, and the first entries of each lane are fetched one
-/// iteration ahead.
+/// entries of the workgroup are loaded up front, and the first entries of each lane are fetched two
+/// iterations ahead.
 template <class JS>
 __global__ __launch_bounds__(256) void idct_kernel(JS js)
 {
@@ -1974,9 +1984,11 @@ __global__ __launch_bounds__(256) void idct_kernel(JS js)
     struct UnitGeo {
         uint32_t addr_lo, addr_hi;
         int pitch;
-        uint32_t vis; // visible columns | visible rows << 4 | quantisation table << 8 | kGeoWhole
+        // rows to store (0..8; 0 if no column is visible) | byte offset of the quantisation table in s_qcol (bits
+        // 7-8) | visible columns << 12 | kGeoWhole: every field where one instruction picks it up
+        uint32_t vis;
     };
-    constexpr uint32_t kGeoWhole = 1u << 12; // all 8 columns visible and every row 8-byte aligned: one store per row
+    constexpr uint32_t kGeoWhole = 1u << 31; // all 8 columns visible and every row 8-byte aligned: one store per row
     __shared__ __attribute__((aligned(16))) UnitGeo s_geo[kIdctDuPerWg];
 
     const JobView J(js.get());
@@ -2012,7 +2024,7 @@ __global__ __launch_bounds__(256) void idct_kernel(JS js)
             const uint64_t a = reinterpret_cast<uint64_t>(ip.plane[sc]) + static_cast<uint64_t>(y0) * static_cast<uint32_t>(ip.pitch[sc]) + static_cast<uint32_t>(x0);
             const bool whole = vx == 8 && ((a | static_cast<uint32_t>(ip.pitch[sc])) & 7u) == 0;
             g = UnitGeo{static_cast<uint32_t>(a), static_cast<uint32_t>(a >> 32), ip.pitch[sc],
-                        static_cast<uint32_t>(vx) | static_cast<uint32_t>(vy) << 4 | static_cast<uint32_t>(ip.qidx[sc]) << 8 | (whole ? kGeoWhole : 0u)};
+                        static_cast<uint32_t>(vx > 0 ? vy : 0) | static_cast<uint32_t>(ip.qidx[sc] & 3) << 7 | static_cast<uint32_t>(vx) << 12 | (whole ? kGeoWhole : 0u)};
         }
         s_geo[t] = g;
     }
@@ -2032,54 +2044,77 @@ __global__ __launch_bounds__(256) void idct_kernel(JS js)
         tcnt[it] = e.y & 0xFFu; // entries (at most 127) | kUnitHasEscape
         toff[it] = static_cast<uint32_t>(e.x < limit ? e.x : limit);
     }
+    // Nothing but the fetched words to place in any of this wave's units (no unit above 31 entries, none with an
+    // escape: the record's flag sits above the count)? Asked once per wave, not once per iteration.
+    uint32_t most = 0;
+#pragma unroll
+    for (int it = 0; it < kIdctIters; ++it) most = max(most, tcnt[it]);
+    const bool plain = __ballot(most > 31u) == 0;
+    typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
+    u32x4 zero4 = {0u, 0u, 0u, 0u};
+    asm volatile("" : "+v"(zero4)); // four registers that stay zero: the compiler would set them up again in every iteration
+    const uint2* const px_mine = &s_px[0][t & 31][t >> 5];
+    const uint8_t* const qcol_mine = reinterpret_cast<const uint8_t*>(s_qcol) + r * 16;
 #ifndef JG_IDCT_PAIRS
 #define JG_IDCT_PAIRS 2
 #endif
-    // Entry PAIRS per lane fetched one iteration ahead: the lane reads the aligned 32-bit words r, r + 8, ... of the
-    // sector row its unit starts in, counted from the word that holds the unit's first entry. Eight words further is
-    // the same word of the next sector (one 32-byte sector = 16 entries = 8 words): +2048 bytes, an immediate. With an
-    // odd first entry the low half of lane 0's first word belongs to the unit in front. (Up to round 4 the lanes read
-    // single entries: twice the loads and twice the address arithmetic in a kernel that is bound by instruction issue.)
+#ifndef JG_IDCT_DEPTH
+#define JG_IDCT_DEPTH 2
+#endif
+#ifndef JG_IDCT_UNCOND
+#define JG_IDCT_UNCOND 1
+#endif
+    // Entry PAIRS per lane, fetched kDepth iterations ahead: the lane reads the aligned 32-bit words r, r + 8, ... of
+    // the sector row its unit starts in, counted from the word that holds the unit's first entry. Eight words further
+    // is the same word of the next sector (one 32-byte sector = 16 entries = 8 words): +2048 bytes. With an odd first
+    // entry the low half of lane 0's first word belongs to the unit in front. The words are read whether the unit
+    // reaches them or not (toff is clamped so that they lie inside the buffer; what is not the unit's is not placed):
+    // without branches around the loads the compiler can count them, and the wait for one iteration's words leaves
+    // the next one's in flight. (Up to round 4 the lanes read single entries under a compare and a branch each: twice
+    // the loads, twice the address arithmetic, and one wait for everything.)
     constexpr int kPairs = JG_IDCT_PAIRS;
     static_assert(kPairs * kSymSectorStride * 2 <= 4096 + 2048, "immediate offsets of the loads");
-    uint32_t nx[kPairs];
+    constexpr int kDepth = JG_IDCT_DEPTH; // iterations the fetches run ahead
+    uint32_t pre[kIdctIters + kDepth][kPairs];
     const auto entry_at = [&](uint32_t index) -> uint32_t {
         return *reinterpret_cast<JG_GLOBAL const uint16_t*>(reinterpret_cast<JG_GLOBAL const uint8_t*>(J.sym) + index * 2u);
     };
     // Entry j of the unit sits in half (j + odd) & 1 of word (j + odd) / 2 counted as above; a lane's word k holds
     // the entries jb + 16 k and jb + 16 k + 1, jb = 2 r - odd.
     const auto prefetch = [&](uint32_t first, uint32_t cnt, uint32_t (&out)[kPairs]) {
-        const uint32_t w4   = ((first & (kSymSectorEntries - 1u)) >> 1) * 4u + static_cast<uint32_t>(r) * 4u; // byte offset of the word in the row
-        const uint32_t base = (first * 2u & ~(2u * kSymSectorEntries - 1u)) + (w4 & 28u) + (w4 & 32u) * (kSymSectorStride * 2u / 32u);
+        // the word that holds the unit's first entry, r words on; past the end of the 8-word sector: the next sector
+        const uint32_t word = first >> 1;
+        const uint32_t over = ((word & 7u) + static_cast<uint32_t>(r)) & 8u;
+        const uint32_t base = word * 4u + static_cast<uint32_t>(r) * 4u + over * ((kSymSectorStride * 2u - 32u) / 8u);
         const int jb        = 2 * r - static_cast<int>(first & 1u);
         JG_GLOBAL const uint8_t* stream = reinterpret_cast<JG_GLOBAL const uint8_t*>(J.sym);
 #pragma unroll
         for (int k = 0; k < kPairs; ++k)
-            out[k] = jb + 16 * k < static_cast<int>(cnt) ? *reinterpret_cast<JG_GLOBAL const uint32_t*>(stream + base + k * (kSymSectorStride * 2u)) : 0u;
+            out[k] = (JG_IDCT_UNCOND || jb + 16 * k < static_cast<int>(cnt)) ? *reinterpret_cast<JG_GLOBAL const uint32_t*>(stream + (base + k * (kSymSectorStride * 2u))) : 0u;
     };
-    prefetch(toff[0], tcnt[0] & 0x7Fu, nx);
+#pragma unroll
+    for (int d = 0; d < kDepth; ++d) prefetch(toff[d], tcnt[d] & 0x7Fu, pre[d]);
 
 #pragma unroll
     for (int it = 0; it < kIdctIters; ++it) {
         uint32_t ex[kPairs];
 #pragma unroll
-        for (int k = 0; k < kPairs; ++k) ex[k] = nx[k];
-        if (it + 1 < kIdctIters) prefetch(toff[it + 1], tcnt[it + 1] & 0x7Fu, nx); // in flight while this one computes
+        for (int k = 0; k < kPairs; ++k) ex[k] = pre[it][k];
+        if (it + kDepth < kIdctIters) prefetch(toff[it + kDepth], tcnt[it + kDepth] & 0x7Fu, pre[it + kDepth]); // in flight while this one computes
         // The 8 lanes of a data unit sit in one wave and LDS executes a wave's instructions in order,
         // so the phases below need no workgroup barrier among themselves; only the pixel re-mapping
         // at the end crosses waves (one barrier per iteration, buffers alternate).
-        *reinterpret_cast<uint4*>(blk + r * 8) = make_uint4(0, 0, 0, 0);
+        *reinterpret_cast<u32x4*>(blk + r * 8) = zero4;
 
-        const uint32_t qtab = (s_geo[it * kIdctDuPerBlock + dl].vis >> 8) & 3u;
+        const uint32_t qoff = s_geo[it * kIdctDuPerBlock + dl].vis & 0x180u;
         // place one coefficient, not yet dequantised: zig-zag index, value (its low 16 bits count)
         const auto put = [&](uint32_t zz, uint32_t value) { *reinterpret_cast<int16_t*>(blk_bytes + s_slot[zz]) = static_cast<int16_t>(value); };
         const uint32_t cnt = tcnt[it] & 0x7Fu;
-        const uint32_t odd = toff[it] & 1u;
+        const bool odd     = (toff[it] & 1u) != 0;
         // Entry j of the unit (jg_defs.h): j == 0 is the DC value; an AC entry holds value << 6 | index; an entry
         // with index 0 behind one is the ESCAPE that carries the value's high bits. The unit's record says whether it
-        // holds one (no photograph does): the wave asks once.
-        if (__builtin_expect(__ballot((tcnt[it] & kUnitHasEscape) != 0) == 0, 1)) {
-            const int jb = 2 * r - static_cast<int>(odd);
+        // holds one (no photograph does).
+        if (__builtin_expect(plain || __ballot((tcnt[it] & kUnitHasEscape) != 0) == 0, 1)) {
             // the look-ups first, all of them (an index of a word that was not loaded is 0): one LDS latency, not one per entry
             uint32_t slot[kPairs][2];
 #pragma unroll
@@ -2087,19 +2122,26 @@ __global__ __launch_bounds__(256) void idct_kernel(JS js)
                 slot[k][0] = s_slot[ex[k] & 63u];
                 slot[k][1] = s_slot[(ex[k] >> 16) & 63u];
             }
-            if (r == 0) blk[0] = static_cast<int16_t>(ex[0] >> (odd * 16u)); // DC: lane 0, the half the unit starts in
+            if (r == 0) blk[0] = static_cast<int16_t>(ex[0] >> ((toff[it] << 4) & 31u)); // DC: lane 0, the half the unit starts in
+            // The lane's words hold the entries jb + c, c = 16 k + h, jb = 2 r - odd; an AC entry of the unit is one
+            // with 1 <= jb + c < cnt: c < left, and for lane 0 not the DC or the entry in front of it.
+            const int left = static_cast<int>(cnt) + static_cast<int>(toff[it] & 1u) - 2 * r;
 #pragma unroll
             for (int k = 0; k < kPairs; ++k) {
 #pragma unroll
                 for (int h = 0; h < 2; ++h) {
-                    // 1 <= j < cnt
-                    if (static_cast<uint32_t>(jb + 16 * k + h - 1) < cnt - 1u)
+                    bool mine = 16 * k + h < left;
+                    if (k == 0 && h == 0) mine = mine && r != 0;
+                    if (k == 0 && h == 1) mine = mine && !(r == 0 && odd);
+                    if (mine)
                         *reinterpret_cast<int16_t*>(blk_bytes + slot[k][h]) = static_cast<int16_t>(static_cast<int32_t>(ex[k] << (16 - 16 * h)) >> 22);
                 }
             }
-            for (uint32_t i = 16u * kPairs - odd + static_cast<uint32_t>(r); i < cnt; i += 8) { // dense units only: entries behind the fetched words
-                const uint32_t e = entry_at(sym_advance(toff[it], i));
-                put(sym_entry_index(e), static_cast<uint32_t>(sym_entry_value(e)));
+            if (!plain) {
+                for (uint32_t i = 16u * kPairs - (toff[it] & 1u) + static_cast<uint32_t>(r); i < cnt; i += 8) { // dense units only: entries behind the fetched words
+                    const uint32_t e = entry_at(sym_advance(toff[it], i));
+                    put(sym_entry_index(e), static_cast<uint32_t>(sym_entry_value(e)));
+                }
             }
         } else {
             for (uint32_t i = r; i < cnt; i += 8) {
@@ -2115,7 +2157,7 @@ __global__ __launch_bounds__(256) void idct_kernel(JS js)
         int v[8];
         {
             uint4 col      = *reinterpret_cast<const uint4*>(blk + r * 8); // column r
-            const uint4 qc = *reinterpret_cast<const uint4*>(s_qcol + qtab * 64u + r * 8);
+            const uint4 qc = *reinterpret_cast<const uint4*>(qcol_mine + qoff);
             col.x = mul_lo_u16x2(col.x, qc.x), col.y = mul_lo_u16x2(col.y, qc.y), col.z = mul_lo_u16x2(col.z, qc.z), col.w = mul_lo_u16x2(col.w, qc.w);
             unpack8(col, v);
         }
@@ -2129,28 +2171,29 @@ __global__ __launch_bounds__(256) void idct_kernel(JS js)
         idct8<0x8000 + (128 << 16)>(v);
 
         uint2 o;
-        o.x = finish_pixels(v[0], v[1]) | finish_pixels(v[2], v[3]) << 16;
-        o.y = finish_pixels(v[4], v[5]) | finish_pixels(v[6], v[7]) << 16;
+        o.x = finish_pixels(v[0], v[1], v[2], v[3]);
+        o.y = finish_pixels(v[4], v[5], v[6], v[7]);
         // A lane holds row r of unit dl; storing that directly makes every wave store touch ~40 cache
         // lines (8 units x 8 rows). Re-map through LDS: lane -> (row t / 32, unit t % 32), so that
         // consecutive lanes write the neighbouring 8-byte segments of one image row.
         s_px[it & 1][dl][r] = o;
         __syncthreads();
-        // The next iteration's entries have had this iteration's time to arrive; asking for them HERE, in front of the
-        // pixel stores, keeps those stores out of the wait (one counter counts loads and stores, and behind the
-        // stores' branches the compiler can only wait for everything: every iteration then stood until its
-        // predecessor's pixels had reached L2).
+        // The next iteration's entries have had an iteration's time or more to arrive; asking for them HERE, in front
+        // of the pixel stores, keeps those stores out of the wait (one counter counts loads and stores, and behind the
+        // stores' branches the compiler can only wait for everything: with the wait at the first use every iteration
+        // stood until its predecessor's pixels had reached L2 and its own entries had arrived, fetched a placement
+        // phase earlier).
         if (it + 1 < kIdctIters) {
 #pragma unroll
-            for (int k = 0; k < kPairs; ++k) asm volatile("" : "+v"(nx[k]));
+            for (int k = 0; k < kPairs; ++k) asm volatile("" : "+v"(pre[it + 1][k]));
         }
         {
             const int r2      = t >> 5;
             const int j       = t & 31;
             const UnitGeo g   = s_geo[it * kIdctDuPerBlock + j]; // all zero behind the last unit: nothing visible
-            const int vx = g.vis & 15, vy = (g.vis >> 4) & 15;
-            if (r2 < vy && vx > 0) {
-                const uint2 w = s_px[it & 1][j][r2];
+            const int vx = (g.vis >> 12) & 15;
+            if (r2 < static_cast<int>(g.vis & 15u)) {
+                const uint2 w = px_mine[(it & 1) * (kIdctDuPerBlock * 9)];
                 JG_GLOBAL uint8_t* row = reinterpret_cast<JG_GLOBAL uint8_t*>(
                     ((static_cast<uint64_t>(g.addr_hi) << 32) | g.addr_lo) + static_cast<uint64_t>(static_cast<uint32_t>(r2)) * static_cast<uint64_t>(static_cast<uint32_t>(g.pitch))); // one v_mad_u64_u32
                 if (g.vis & kGeoWhole) {
