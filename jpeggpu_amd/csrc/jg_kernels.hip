@@ -1947,6 +1947,25 @@ __device__ __forceinline__ void unpack8(const uint4& raw, int (&v)[8])
 constexpr int kIdctIters    = 8;                            // groups of 32 data units per workgroup
 constexpr int kIdctDuPerWg  = kIdctDuPerBlock * kIdctIters; // 256
 
+/// Zig-zag index of the coefficient in `row`, `col` (T.81 figure A.6), worked out instead of looked up: a table in
+/// memory is one more load for the prologue to wait for. Diagonal d = row + col holds the indices from d (d + 1) / 2
+/// on, downwards for odd d; the lower right half mirrors the upper left.
+__host__ __device__ constexpr int zigzag_of(int row, int col)
+{
+    const bool low = row + col > 7;
+    const int r = low ? 7 - row : row, c = low ? 7 - col : col, d = r + c;
+    const int z = d * (d + 1) / 2 + ((d & 1) ? r : c);
+    return low ? 63 - z : z;
+}
+constexpr bool zigzag_of_matches_table()
+{
+    constexpr uint8_t nat[64] = JG_ORDER_NATURAL; // zig-zag index -> natural index
+    for (int z = 0; z < 64; ++z)
+        if (zigzag_of(nat[z] >> 3, nat[z] & 7) != z) return false;
+    return true;
+}
+static_assert(zigzag_of_matches_table(), "zigzag_of");
+
 /// Two 16-bit products at once (v_pk_mul_lo_u16): the low halves of coefficient * quantiser.
 __device__ __forceinline__ uint32_t mul_lo_u16x2(uint32_t a, uint32_t b)
 {
@@ -2001,48 +2020,50 @@ __global__ __launch_bounds__(256) void idct_kernel(JS js)
     const int r  = t & 7;  // column (pass 1) or row (pass 2) handled by this lane
     const int dl = t >> 3; // data unit inside the group
 
-    s_qcol[t] = J.qtables[(t & ~63) + (t & 7) * 8 + ((t >> 3) & 7)]; // [table][col][row] <- natural row * 8 + col
-    if (t < 64) {
-        // natural index = row * 8 + col -> transposed slot col * 8 + row
-        constexpr uint8_t nat[64] = JG_ORDER_NATURAL;
-        const int n               = nat[t];
-        s_slot[t]                 = static_cast<uint8_t>(((n & 7) * 8 + (n >> 3)) * 2);
-    }
-    {
-        const int du = du0 + t;
-        UnitGeo g{0u, 0u, 0, 0u};
-        if (du < num_du) {
-            const int rel = static_cast<int>(magic_quot(du, ip.du_per_mcu_mul, ip.du_per_mcu_shift));
-            const int k   = du - rel * ip.du_per_mcu;
-            const int sc  = ip.du_comp[k];
-            const int mcu = rel + ip.first_mcu;
-            const int my  = static_cast<int>(magic_quot(mcu, ip.mcus_x_mul, ip.mcus_x_shift));
-            const int mx  = mcu - my * ip.mcus_x;
-            const int x0  = (mx * ip.comp_h[sc] + ip.du_dx[k]) * 8;
-            const int y0  = (my * ip.comp_v[sc] + ip.du_dy[k]) * 8;
-            const int vx  = min(max(ip.size_x[sc] - x0, 0), 8), vy = min(max(ip.size_y[sc] - y0, 0), 8);
-            const uint64_t a = reinterpret_cast<uint64_t>(ip.plane[sc]) + static_cast<uint64_t>(y0) * static_cast<uint32_t>(ip.pitch[sc]) + static_cast<uint32_t>(x0);
-            const bool whole = vx == 8 && ((a | static_cast<uint32_t>(ip.pitch[sc])) & 7u) == 0;
-            g = UnitGeo{static_cast<uint32_t>(a), static_cast<uint32_t>(a >> 32), ip.pitch[sc],
-                        static_cast<uint32_t>(vx > 0 ? vy : 0) | static_cast<uint32_t>(ip.qidx[sc] & 3) << 7 | static_cast<uint32_t>(vx) << 12 | (whole ? kGeoWhole : 0u)};
-        }
-        s_geo[t] = g;
-    }
-    int16_t* blk = s_blk[dl];
-    uint8_t* const blk_bytes = reinterpret_cast<uint8_t*>(blk);
-    __syncthreads(); // s_qcol, s_slot, s_geo are loaded
+    // The records of the lane's units of all iterations, asked for before anything else and without a branch (a unit
+    // past the end reads the last record and counts no entries): eight loads in flight at once. Behind an `if` each,
+    // as up to round 4, the compiler waited for every one before it issued the next -- eight memory latencies in a
+    // row in front of the first iteration, in a workgroup that lives for eight iterations.
+    uint2_t rec[kIdctIters];
+#pragma unroll
+    for (int it = 0; it < kIdctIters; ++it) rec[it] = ld_global(J.du_tab + min(du0 + it * kIdctDuPerBlock + dl, num_du - 1));
+    // (and the lane's byte and word of the job's geometry tables, below)
+    const uint32_t unit_byte = reinterpret_cast<const uint8_t*>(ip.du_comp)[t & 31];
+    const uint32_t comp_word = reinterpret_cast<const uint32_t*>(ip.comp_h)[t & 31];
 
-    // table entries of all iterations (independent loads, one latency); a table entry that was never
-    // written (corrupt stream) must not lead out of the buffer
+    s_qcol[t] = J.qtables[(t & ~63) + (t & 7) * 8 + ((t >> 3) & 7)]; // [table][col][row] <- natural row * 8 + col
+    if (t < 64) s_slot[zigzag_of(t >> 3, t & 7)] = static_cast<uint8_t>(((t & 7) * 8 + (t >> 3)) * 2); // natural row * 8 + col -> transposed slot col * 8 + row
+    // Geometry, first half: which unit of which MCU, and the one load the rest depends on. Straight-line code (a unit
+    // past the end works on the last one and is marked invisible): the loads of this prologue are then the
+    // compiler's to count, and the first entries below travel while the geometry is worked out.
+    const int gdu  = min(du0 + t, num_du - 1);
+    const int grel = static_cast<int>(magic_quot(gdu, ip.du_per_mcu_mul, ip.du_per_mcu_shift));
+    const int gk   = gdu - grel * ip.du_per_mcu;
+    // What the unit's place depends on sits in two small tables of the job: the MCU's units (component, block column,
+    // block row: three arrays of 10 bytes) and the components (six arrays of 4 ints, then 4 plane pointers). Lane L of
+    // every half wave loads byte L of the first and word L of the second -- loads that depend on nothing -- and a unit
+    // then takes its values from the lanes that hold them (ds_bpermute: no memory behind it). Indexed loads, first
+    // by the unit's place in the MCU, then by its component, were two more memory latencies in a row.
+    static_assert(kMaxDuPerMcu == 10 && kMaxComp == 4 && sizeof(ip.plane[0]) == 8, "lane layout of the two tables");
+    static_assert(offsetof(IdctParams, du_dx) == offsetof(IdctParams, du_comp) + 10 && offsetof(IdctParams, du_dy) == offsetof(IdctParams, du_comp) + 20 &&
+                      offsetof(IdctParams, comp_h) >= offsetof(IdctParams, du_comp) + 32,
+                  "32 bytes from du_comp on");
+    static_assert(offsetof(IdctParams, comp_v) == offsetof(IdctParams, comp_h) + 16 && offsetof(IdctParams, size_x) == offsetof(IdctParams, comp_h) + 32 &&
+                      offsetof(IdctParams, size_y) == offsetof(IdctParams, comp_h) + 48 && offsetof(IdctParams, pitch) == offsetof(IdctParams, comp_h) + 64 &&
+                      offsetof(IdctParams, qidx) == offsetof(IdctParams, comp_h) + 80 && offsetof(IdctParams, plane) == offsetof(IdctParams, comp_h) + 96,
+                  "32 words from comp_h on");
+    const auto from_lane = [](int lane, uint32_t v) { return static_cast<uint32_t>(__builtin_amdgcn_ds_bpermute(lane * 4, static_cast<int>(v))); };
+    const int gmcu = grel + ip.first_mcu;
+    const int gmy  = static_cast<int>(magic_quot(gmcu, ip.mcus_x_mul, ip.mcus_x_shift));
+    const int gmx  = gmcu - gmy * ip.mcus_x;
+    // a table entry that was never written (corrupt stream) must not lead out of the buffer
     uint32_t toff[kIdctIters], tcnt[kIdctIters];
     const uint64_t limit = J.sym_entries - 10 * kSymSectorStride; // a 128-entry gather from here stays inside
 #pragma unroll
     for (int it = 0; it < kIdctIters; ++it) {
-        const int du = du0 + it * kIdctDuPerBlock + dl;
-        uint2_t e{0u, 0u};
-        if (du < num_du) e = ld_global(J.du_tab + du);
-        tcnt[it] = e.y & 0xFFu; // entries (at most 127) | kUnitHasEscape
-        toff[it] = static_cast<uint32_t>(e.x < limit ? e.x : limit);
+        const bool mine = du0 + it * kIdctDuPerBlock + dl < num_du;
+        tcnt[it] = mine ? rec[it].y & 0xFFu : 0u; // entries (at most 127) | kUnitHasEscape
+        toff[it] = static_cast<uint32_t>(rec[it].x < limit ? rec[it].x : limit);
     }
     // Nothing but the fetched words to place in any of this wave's units (no unit above 31 entries, none with an
     // escape: the record's flag sits above the count)? Asked once per wave, not once per iteration.
@@ -2092,8 +2113,28 @@ __global__ __launch_bounds__(256) void idct_kernel(JS js)
         for (int k = 0; k < kPairs; ++k)
             out[k] = (JG_IDCT_UNCOND || jb + 16 * k < static_cast<int>(cnt)) ? *reinterpret_cast<JG_GLOBAL const uint32_t*>(stream + (base + k * (kSymSectorStride * 2u))) : 0u;
     };
+
+    {
+        // (the first entries: asked for behind the geometry's loads, so that waiting for those does not wait for these)
 #pragma unroll
-    for (int d = 0; d < kDepth; ++d) prefetch(toff[d], tcnt[d] & 0x7Fu, pre[d]);
+        for (int d = 0; d < kDepth; ++d) prefetch(toff[d], tcnt[d] & 0x7Fu, pre[d]);
+        const int sc = static_cast<int>(from_lane(gk, unit_byte));
+        const int dx = static_cast<int>(from_lane(10 + gk, unit_byte)), dy = static_cast<int>(from_lane(20 + gk, unit_byte));
+        const int comp_h = static_cast<int>(from_lane(sc, comp_word)), comp_v = static_cast<int>(from_lane(4 + sc, comp_word));
+        const int size_x = static_cast<int>(from_lane(8 + sc, comp_word)), size_y = static_cast<int>(from_lane(12 + sc, comp_word));
+        const int pitch = static_cast<int>(from_lane(16 + sc, comp_word)), qidx = static_cast<int>(from_lane(20 + sc, comp_word));
+        const uint64_t plane = static_cast<uint64_t>(from_lane(24 + 2 * sc, comp_word)) | static_cast<uint64_t>(from_lane(25 + 2 * sc, comp_word)) << 32;
+        const int x0  = (gmx * comp_h + dx) * 8;
+        const int y0  = (gmy * comp_v + dy) * 8;
+        const int vx  = min(max(size_x - x0, 0), 8), vy = min(max(size_y - y0, 0), 8);
+        const uint64_t a = plane + static_cast<uint64_t>(y0) * static_cast<uint32_t>(pitch) + static_cast<uint32_t>(x0);
+        const bool whole = vx == 8 && ((a | static_cast<uint32_t>(pitch)) & 7u) == 0;
+        const uint32_t vis = static_cast<uint32_t>(vx > 0 ? vy : 0) | static_cast<uint32_t>(qidx & 3) << 7 | static_cast<uint32_t>(vx) << 12 | (whole ? kGeoWhole : 0u);
+        s_geo[t] = UnitGeo{static_cast<uint32_t>(a), static_cast<uint32_t>(a >> 32), pitch, du0 + t < num_du ? vis : 0u};
+    }
+    int16_t* blk = s_blk[dl];
+    uint8_t* const blk_bytes = reinterpret_cast<uint8_t*>(blk);
+    __syncthreads(); // s_qcol, s_slot, s_geo are loaded
 
 #pragma unroll
     for (int it = 0; it < kIdctIters; ++it) {
