@@ -562,14 +562,23 @@ __device__ __forceinline__ void load_tables(uint8_t* s_tab, JG_GLOBAL const uint
     uint4* d       = reinterpret_cast<uint4*>(s_tab);
     JG_GLOBAL const uint4* s = reinterpret_cast<JG_GLOBAL const uint4*>(g_tab);
     const uint32_t base = lds_address(s_tab), ring = sp.cursor_off / 16;
-    for (uint32_t i = threadIdx.x; i < sp.tab_bytes / 16; i += blockDim.x) {
-        uint4 v = ld_global(s + i);
-        if (i >= ring) {
-            v.x += base * 0x00010001u; // LDS addresses stay below 64 KiB: static_asserts at the carves, launch_huff at run time
-            v.z += base;
-            v.w += base;
+    // Four loads of a lane in flight at a time, no branch (a piece past the end is the last one again): one
+    // at a time, every 4 KB of the pack was a memory latency of its own in front of the workgroup's first symbol --
+    // nine in a row for a 36 KB sync pack.
+    const uint32_t n16 = sp.tab_bytes / 16, step = blockDim.x;
+    for (uint32_t i0 = threadIdx.x; i0 < n16; i0 += 4 * step) {
+        uint4 v[4];
+#pragma unroll
+        for (uint32_t k = 0; k < 4; ++k) v[k] = ld_global(s + min(i0 + k * step, n16 - 1));
+#pragma unroll
+        for (uint32_t k = 0; k < 4; ++k) {
+            const uint32_t i   = min(i0 + k * step, n16 - 1); // (the last piece written again with the same content)
+            const uint32_t add = i >= ring ? base : 0u;
+            v[k].x += add * 0x00010001u; // LDS addresses stay below 64 KiB: static_asserts at the carves, launch_huff at run time
+            v[k].z += add;
+            v[k].w += add;
+            d[i] = v[k];
         }
-        d[i] = v;
     }
     sp.cursor_off += base;
 }
@@ -855,14 +864,19 @@ __global__ __launch_bounds__(T) void huff_sync_intra_batch(JS js)
     const int img_first = first_sub - OV;                    // subsequence of lane 0
     const int img_end   = min(T, sp.num_subseq - img_first); // lanes below this have a subsequence
 
-    JG_STAMP(0);
-    load_tables(s_tab, J.tables_sync, sp);
-    __syncthreads();
-    JG_STAMP(1);
-
     constexpr int kBits = W * 32;
     const int sub       = img_first + t;
     const bool active   = sub >= 0 && t < img_end;
+    // (the lane's segment: its index asked for before the table pack is copied, the record right behind it -- two memory
+    // latencies that used to follow the copy)
+    const int lane_seg = J.seg_idx[active ? sub : first_sub];
+
+    JG_STAMP(0);
+    load_tables(s_tab, J.tables_sync, sp);
+    const Segment lane_segment = ld_global(J.segments + lane_seg);
+    __syncthreads();
+    JG_STAMP(1);
+
     // Multi-hypothesis speculation (jg_defs.h): the table this kernel starts from was written by huff_mh_resolve -- for
     // every subsequence the candidate state the chain of links passes through -- instead of being speculated here. The
     // flows below then are the reference's, from that table; an entry the chain hopped over (not `known`) starts no
@@ -878,7 +892,7 @@ __global__ __launch_bounds__(T) void huff_sync_intra_batch(JS js)
     int rel = 0;
     bool known = true;
     if (active) {
-        seg = ld_global(J.segments + J.seg_idx[sub]);
+        seg = lane_segment;
         rel = sub - seg.subseq_offset;
         if (mh) {
             st.p         = J.mh_p[sub];
@@ -1753,11 +1767,24 @@ __global__ __launch_bounds__(T) void huff_write(JS js)
     const int first_sub = blockIdx.x * SEQ;
     const int nsub      = min(SEQ, sp.num_subseq - first_sub);
 
+    // What the lane needs of its own subsequence and of the one in front, asked for before anything else and without
+    // a branch (a lane without a subsequence reads the last one's): these loads travel while the table pack is copied.
+    // Where each sat in front of its first use -- behind the scans' barriers, one after the other -- the workgroup
+    // waited out seven memory latencies in a row before its first symbol.
+    const int sub_c        = first_sub + min(t, nsub - 1);
+    const int lane_seg     = J.seg_idx[sub_c];
+    const int first_seg    = J.seg_idx[first_sub];
+    const uint32_t lane_n  = static_cast<uint32_t>(J.st_n[sub_c]);
+    const uint32_t lane_01 = J.st_dc01[sub_c], lane_23 = J.st_dc23[sub_c];
+    const int prev_p       = J.st_p[max(sub_c - 1, 0)];
+    const int prev_cz      = J.st_cz[max(sub_c - 1, 0)];
+
     load_tables(s_tab, J.tables, sp);
+    const Segment lane_segment = ld_global(J.segments + lane_seg);
 
     // carry-in of the segment that is open at the sequence's first subsequence
     {
-        const Segment seg0 = ld_global(J.segments + J.seg_idx[first_sub]);
+        const Segment seg0 = ld_global(J.segments + first_seg);
         const int a        = seg0.subseq_offset / SEQ; // sequence holding the segment's start
         uint32_t cn = 0, c01 = 0, c23 = 0;
         if (seg0.subseq_offset < first_sub) {
@@ -1784,8 +1811,8 @@ __global__ __launch_bounds__(T) void huff_write(JS js)
     Segment seg{0, 0};
     bool carried = false; // segment started before this sequence
     if (active) {
-        seg_i   = J.seg_idx[sub];
-        seg     = ld_global(J.segments + seg_i);
+        seg_i   = lane_seg;
+        seg     = lane_segment;
         rel     = sub - seg.subseq_offset;
         carried = seg.subseq_offset < first_sub;
         ts      = carried ? 0 : seg.subseq_offset - first_sub;
@@ -1798,12 +1825,12 @@ __global__ __launch_bounds__(T) void huff_write(JS js)
     int nprefix  = 0, nnext = 0; // coefficient slots of the segment in front of this lane's subsequence / of the next one's
     uint32_t pred01 = 0, pred23 = 0; // DC predictors at the lane's first symbol: sums over the segment so far
     {
-        block_excl_scan_256<false>(active ? static_cast<uint32_t>(J.st_n[sub]) : 0u, s_scan, s_wave);
+        block_excl_scan_256<false>(active ? lane_n : 0u, s_scan, s_wave);
         nprefix = static_cast<int>(s_scan[t] - s_scan[ts] + (carried ? s_carry[0] : 0u));
         nnext   = static_cast<int>(s_scan[t + 1] - s_scan[ts] + (carried ? s_carry[0] : 0u));
-        block_excl_scan_256<true>(active ? J.st_dc01[sub] : 0u, s_scan, s_wave);
+        block_excl_scan_256<true>(active ? lane_01 : 0u, s_scan, s_wave);
         const uint32_t p01 = pk_add(pk_sub(s_scan[t], s_scan[ts]), carried ? s_carry[1] : 0u);
-        block_excl_scan_256<true>(active ? J.st_dc23[sub] : 0u, s_scan, s_wave);
+        block_excl_scan_256<true>(active ? lane_23 : 0u, s_scan, s_wave);
         const uint32_t p23 = pk_add(pk_sub(s_scan[t], s_scan[ts]), carried ? s_carry[2] : 0u);
         pred01 = p01;
         pred23 = p23;
@@ -1834,8 +1861,8 @@ __global__ __launch_bounds__(T) void huff_write(JS js)
     st.dc01 = pred01;
     st.dc23 = pred23;
     if (rel > 0) {
-        st.p         = J.st_p[sub - 1];
-        const int cz = J.st_cz[sub - 1];
+        st.p         = prev_p;
+        const int cz = prev_cz;
         st.c         = cz & 0xFF;
         st.z         = cz >> 8;
     }
