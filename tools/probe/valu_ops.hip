@@ -61,7 +61,14 @@
     X(50, "v_bitop3_b32 %0, %0, %2, %2 bitop3:0x96") \
     X(51, "v_cvt_f32_u32 %0, %0") \
     X(52, "v_mul_hi_u32 %0, %0, %2") \
-    X(53, "v_readfirstlane_b32 s20, %0")
+    X(53, "v_readfirstlane_b32 s20, %0") \
+    X(54, "v_mad_i32_i24 %0, %0, %2, %2") \
+    X(55, "v_mul_i32_i24 %0, 0x5a82, %0") \
+    X(56, "v_mul_i32_i24_sdwa %0, sext(%0), %2 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:WORD_0 src1_sel:DWORD") \
+    X(57, "v_add_u32_sdwa %0, sext(%0), sext(%2) dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:WORD_1 src1_sel:WORD_0") \
+    X(58, "v_add_u32 %0, 0x8000, %0") \
+    X(59, "v_bfe_i32 %0, %0, 0, 16") \
+    X(60, "v_and_b32 %0, -4, %0")
 
 template <int OP>
 __global__ __launch_bounds__(256) void spin(uint32_t* out, int iters)
