@@ -217,6 +217,12 @@ JG_HD inline int sym_entry_value(uint32_t e, uint32_t escape) { return static_ca
 /// Bit of a data-unit record's count that says "this unit holds an escape" (a count is at most 127).
 constexpr uint32_t kUnitHasEscape = 0x80u;
 
+#if defined(__HIP_DEVICE_COMPILE__)
+#define JG_WAVE_ANY(x) (__builtin_amdgcn_ballot_w64(x) != 0ull)
+#else
+#define JG_WAVE_ANY(x) (x) // a host emulation runs one lane at a time
+#endif
+
 /// STATE-ONLY decode (speculative pass, flows) from `st` up to bit `end_bit` of the segment, committing the symbols
 /// that end at or before it. `st.n`, `st.dc01`, `st.dc23` accumulate (not with SpecSink). `tabs` is the scan's SYNC
 /// table pack (LDS on the device). The write pass has its own loop (decode_units, below).
@@ -294,12 +300,13 @@ JG_HD inline void decode_subsequence(
             const TabPtr tab   = JG_TAB_AT(tabs, is_dc ? (JG_CUR_TABS & 0xFFFFu) : (JG_CUR_TABS >> 16));
             const uint32_t idx = peek >> (is_dc ? 32 - kLutBitsDc : 32 - kLutBitsAc);
             const uint32_t e32 = ld_u32(tab + kSyncEntryBytes * idx);
-            e                  = e32 & 0xFFFFu;
-            if ((e & 31u) == 0) {
-                e = huff_second_level<kSyncEntryBytes>(tab, e, peek, is_dc);
-            } else {
-                const uint32_t m = e32 >> 16;
-                if (zm + static_cast<int>((m >> 5) & 15u) < 63) e = m;
+            // the choice between the halves with selects, the second level -- a code longer than the index bits, rare --
+            // behind ONE question to the whole wave: as `if long code ... else choose` every step paid two exec-mask
+            // hand-offs between the vector and the scalar unit whether any lane had a long code or not
+            const uint32_t one = e32 & 0xFFFFu, m = e32 >> 16;
+            e                  = zm + static_cast<int>((m >> 5) & 15u) < 63 ? m : one;
+            if (JG_WAVE_ANY((one & 31u) == 0)) {
+                if ((one & 31u) == 0) e = huff_second_level<kSyncEntryBytes>(tab, one, peek, is_dc);
             }
             total = e & 31;
             JG_COMMIT();
@@ -380,11 +387,6 @@ JG_HD inline int extend_bits(uint32_t bits, int s)
     return bits > (mask >> 1) ? static_cast<int>(bits) : static_cast<int>(bits - mask);
 }
 
-#if defined(__HIP_DEVICE_COMPILE__)
-#define JG_WAVE_ANY(x) (__builtin_amdgcn_ballot_w64(x) != 0ull)
-#else
-#define JG_WAVE_ANY(x) (x) // a host emulation runs one lane at a time
-#endif
 
 /// The symbol loop of the WRITE PASS: decode from `st` and hand every coefficient to `sink`, for the data units the
 /// lane OWNS: those whose DC symbol its subsequence commits. It runs past the end of the subsequence to finish the last
