@@ -1,6 +1,6 @@
 #!/usr/bin/env python3
 """One image decoded on its own, 50 times: the workload for a per-kernel trace of a lone decode
-  cd /tmp && rocprofv3 --kernel-trace --stats -d $OUT/lone_trace -o t --output-format csv -- python3 tools/probe/lone_trace.py [photo|cfg2]"""
+  cd /tmp && rocprofv3 --kernel-trace --stats -d $OUT/lone_trace -o t --output-format csv -- python3 tools/probe/lone_trace.py [photo|cfg2|cfg2_nodri|cfg5]"""
 import os
 import sys
 
@@ -11,7 +11,8 @@ from tools import jpegsynth  # noqa: E402
 
 root = os.path.join(os.path.dirname(os.path.abspath(__file__)), "..", "..")
 which = sys.argv[1] if len(sys.argv) > 1 else "cfg2"
-data = open(os.path.join(root, "tests", "golden", "IMG_6510.JPG"), "rb").read() if which == "photo" else jpegsynth.config(2, seed=0)
+data = {"photo": lambda: open(os.path.join(root, "tests", "golden", "IMG_6510.JPG"), "rb").read(), "cfg2": lambda: jpegsynth.config(2, seed=0),
+        "cfg2_nodri": lambda: jpegsynth.encode(4032, 3024, ((2, 2), (1, 1), (1, 1)), True, 0, quality=88, noise=9, seed=0), "cfg5": lambda: jpegsynth.config(5)}[which]()
 dec = jp.Decoder()
 info = dec.parse_header(data)
 n = dec.get_buffer_size()
