@@ -559,7 +559,9 @@ def roofline_report(args, slot, stage_us, images_per_launch, entries, value, wor
             "own_GBs": ab[k] * images_per_launch / (us * 1e-6) / 1e9 if us > 0 else None,
             "own_frac_of_hbm_peak": ab[k] * images_per_launch / (us * 1e-6) / 1e9 / HBM_PEAK_GBS if us > 0 else None,
             "traffic_bytes_per_launch": t * images_per_launch if t else None,
-            "valu_issue_util": valu * VALU_CYCLES / (SIMDS * SHADER_HZ * us * 1e-6) if valu and us > 0 else None,
+            # (4 cycles per instruction is the model's price; simple additions and shifts measure 2.1-2.6, so a kernel made of
+            # them can come out above 1: capped)
+            "valu_issue_util": min(1.0, valu * VALU_CYCLES / (SIMDS * SHADER_HZ * us * 1e-6)) if valu and us > 0 else None,
             # ratios of counters of the SAME unit (per wave-resident cycle), from the committed profile, not from this run
             "issue_counters": counter_ratios(c)}
     in_pass = [k for k in stages if k in PASS_STAGES]
