@@ -836,16 +836,27 @@ __global__ __launch_bounds__(T) void huff_sync_intra(JS js)
 /// four streams overlap ran 5 % slower with it (26.5 k against 27.9 k images/s, measured six times in-run against this
 /// one; neither its LDS footprint -- padded to this kernel's and beyond --, nor its code size, nor the job's layout, nor
 /// the boundary records explain it: DESIGN.md section 7), so batches keep this one.
+/// Sequences a workgroup of the batch kernel takes, each on T of its lanes, all behind ONE copy of the table pack: what
+/// a CU holds of this kernel is bound by LDS, most of it the pack, and the kernel's time by how many waves a SIMD has to
+/// choose from (5 -> 4 workgroups per CU cost 21 %, round 4): two sequences per pack are 8 waves per SIMD instead of 5.
+#ifndef JG_BATCH_SEQ_PER_WG
+#define JG_BATCH_SEQ_PER_WG 2
+#endif
+constexpr int kBatchSeqPerWg = JG_BATCH_SEQ_PER_WG;
 struct SeqLdsBatch {
     static constexpr uint32_t kState = 0;
-    static constexpr uint32_t kTabs  = (kState + 6 * (T + 1) * 4 + 64 + 15) / 16 * 16; // 5 state arrays / scan scratch
+    static constexpr uint32_t kOne   = (6 * (T + 1) * 4 + 64 + 15) / 16 * 16; // one sequence's 5 state arrays / scan scratch
+    static constexpr uint32_t kTabs  = kState + kBatchSeqPerWg * kOne;
     static_assert(kTabs % 16 == 0, "the table pack is read with 16-byte loads");
 };
+static_assert(kStaticLdsSlack + SeqLdsBatch::kTabs + kMaxTablePackSync <= 65536, "absolute table addresses are packed into 16 bits (load_tables)");
 template <int W, class JS>
-__global__ __launch_bounds__(T) void huff_sync_intra_batch(JS js)
+__global__ __launch_bounds__(T * kBatchSeqPerWg) void huff_sync_intra_batch(JS js)
 {
     extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
-    int* s_p         = reinterpret_cast<int*>(smem + SeqLdsBatch::kState);
+    const int which = threadIdx.x / T;                       // the workgroup's sequence this lane works for
+    const int seq   = blockIdx.x * kBatchSeqPerWg + which;
+    int* s_p         = reinterpret_cast<int*>(smem + SeqLdsBatch::kState + which * SeqLdsBatch::kOne);
     int* s_n         = s_p + T;
     int* s_cz        = s_n + T;
     uint32_t* s_dc01 = reinterpret_cast<uint32_t*>(s_cz + T);
@@ -854,13 +865,14 @@ __global__ __launch_bounds__(T) void huff_sync_intra_batch(JS js)
     uint8_t* s_tab   = smem + SeqLdsBatch::kTabs;
 
     const JobView J(js.get());
-    if (static_cast<int>(blockIdx.x) >= J.num_seq) return;
+    if (static_cast<int>(blockIdx.x) * kBatchSeqPerWg >= J.num_seq) return;
     ScanParams sp = J.sp;
     sp.use_sync_pack();
-    const int t         = threadIdx.x;
+    const int t         = threadIdx.x % T;
     s_pend[t]           = 0;
     const int SEQ = sp.seq_subseq, OV = T - SEQ;             // 240 + 16 for a lone decode, 255 + 1 in batches (jg_defs.h)
-    const int first_sub = blockIdx.x * SEQ;                  // first subsequence this workgroup owns
+    // (a sequence behind the scan's last one has no lane with a subsequence: its lanes only keep the barriers company)
+    const int first_sub = seq * SEQ;                         // first subsequence this sequence owns
     const int img_first = first_sub - OV;                    // subsequence of lane 0
     const int img_end   = min(T, sp.num_subseq - img_first); // lanes below this have a subsequence
 
@@ -869,7 +881,7 @@ __global__ __launch_bounds__(T) void huff_sync_intra_batch(JS js)
     const bool active   = sub >= 0 && t < img_end;
     // (the lane's segment: its index asked for before the table pack is copied, the record right behind it -- two memory
     // latencies that used to follow the copy)
-    const int lane_seg = J.seg_idx[active ? sub : first_sub];
+    const int lane_seg = J.seg_idx[active ? sub : 0];
 
     JG_STAMP(0);
     load_tables(s_tab, J.tables_sync, sp);
@@ -984,9 +996,9 @@ __global__ __launch_bounds__(T) void huff_sync_intra_batch(JS js)
         J.st_dc23[sub] = s_dc23[t];
     }
     // (this kernel says nothing about the boundary: huff_sync_tail then starts a flow at every one, as round 3 did)
-    if (t == OV - 1) {
-        J.bnd_p[blockIdx.x]  = -1;
-        J.bnd_cz[blockIdx.x] = -1;
+    if (t == OV - 1 && seq < J.num_seq) {
+        J.bnd_p[seq]  = -1;
+        J.bnd_cz[seq] = -1;
     }
 }
 
@@ -2376,7 +2388,7 @@ hipError_t launch_huff(Stage stage, const JS& js, const JobExtent& e, int grid_y
         } else {
             const size_t lds = SeqLdsBatch::kTabs + e.max_tab_bytes_sync;
             if ((err = allow_lds(huff_sync_intra_batch<W, JS>, lds)) != hipSuccess) return err;
-            huff_sync_intra_batch<W, JS><<<dim3(e.max_seq, grid_y), T, lds, stream>>>(js);
+            huff_sync_intra_batch<W, JS><<<dim3((e.max_seq + kBatchSeqPerWg - 1) / kBatchSeqPerWg, grid_y), T * kBatchSeqPerWg, lds, stream>>>(js);
         }
         break;
     case kStageSyncInter:
