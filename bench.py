@@ -89,6 +89,10 @@ def parse_args():
     ap.add_argument("--e2e-rounds", type=int, default=16,
                     help="rounds of the full-path measurement (parse + transfer + decode from pinned host memory); 0 = skip")
     ap.add_argument("--host-threads", type=int, default=6, help="threads of jpeggpu_ext_parse_headers in that measurement")
+    ap.add_argument("--curve-iters", type=int, default=30,
+                    help="N = 1: calls per point of `batch_curve` (one batched call of 1 .. 64 images, device time per image); 0 = skip")
+    ap.add_argument("--shard-iters", type=int, default=200,
+                    help="N = 1: iterations of `config3_rank_shard` (BASELINE configs[2]'s per-rank 8 images through the whole protocol); 0 = skip")
     return ap.parse_args()
 
 
@@ -111,8 +115,9 @@ class Slot:
 
     def __init__(self, torch, jp, data, device, subseq_bytes, planes_flat=None, planes_off=0, device_scan=False, batched=False):
         self.dec = jp.Decoder(subseq_bytes or None)
-        if batched and not subseq_bytes:
-            self.dec.set_batched(True)  # the library picks the subsequence size for images that share launches
+        if batched:
+            # how many images share a call: the library plans for that (subsequence size, speculation, sync kernel)
+            self.dec.set_batch_hint(int(batched))
         if device_scan:
             self.dec.set_device_scan(True)
         self.data = data
@@ -159,7 +164,7 @@ class BatchSet:
     def __init__(self, args, torch, jp, images, device, streams, batch):
         self.args, self.streams = args, streams
         nstreams = len(streams)
-        batched = args.mode == "batch"
+        batched = max(1, batch // nstreams) if args.mode == "batch" else 0  # images per jpeggpu_ext_decode_batch call
         probe = Slot(torch, jp, images[0], device, args.subseq_bytes, device_scan=bool(args.device_scan), batched=batched)
         self.per_image = probe.plane_bytes
         probe.dec.cleanup()
@@ -463,6 +468,115 @@ def latency_probe(args, torch, jp, data, device, stream, device_scan):
     return out
 
 
+def _percentile(xs, q):
+    xs = sorted(xs)
+    return xs[min(len(xs) - 1, int(q * len(xs)))]
+
+
+def batch_point(args, torch, jp, images, device, stream, nb, iters, subseq_bytes=0, sync_iters=0, hint=None, overlap=1, stages=False):
+    """Device time of ONE jpeggpu_ext_decode_batch call over `nb` images (inputs resident, one stream, nothing else on
+    the chip): HIP events on the launch stream around the call, median over `iters` calls. The decoders are told how many
+    images share a call (jpeggpu_ext_set_batched(decoder, nb)) and the library plans for that; `subseq_bytes`,
+    `sync_iters` override the plan (sweeps: tools/probe/batch_curve.py)."""
+    slots = []
+    for i in range(nb):
+        s = Slot(torch, jp, images[i % len(images)], device, subseq_bytes, batched=(nb if hint is None else hint))
+        s.transfer(stream.cuda_stream)
+        slots.append(s)
+    bt = jp.Batch(sum(s.layout.num_scans for s in slots))
+    scratch = torch.empty(bt.scratch_size, dtype=torch.uint8, device=device)
+    bt.set_items([(s.dec, s.ptrs, s.pitches, s.base, s.tmp_size) for s in slots])
+    if sync_iters > 0:
+        bt.set_sync_iterations(sync_iters)
+    bt.set_overlap(overlap)
+    for _ in range(3):
+        bt.decode(scratch.data_ptr(), stream.cuda_stream)
+    stream.synchronize()
+    us = []
+    for _ in range(iters):
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record(stream)
+        bt.decode(scratch.data_ptr(), stream.cuda_stream)
+        e1.record(stream)
+        stream.synchronize()
+        us.append(e0.elapsed_time(e1) * 1e3)
+    lay = slots[0].layout
+    out = {"images": nb, "device_us": statistics.median(us), "device_us_per_image": statistics.median(us) / nb,
+           "device_us_p99": _percentile(us, 0.99), "subsequence_bytes": lay.subsequence_bytes,
+           "subsequences_per_sequence": lay.subsequences_per_sequence, "hypotheses": lay.scans[0].hypotheses, "iters": iters}
+    if stages:
+        try:
+            bt.set_profiling(True)
+            for _ in range(5):
+                bt.decode(scratch.data_ptr(), stream.cuda_stream)
+                stream.synchronize()
+            out["stage_us"] = {k: v * 1e3 for k, v in bt.stage_ms().items()}
+        except jp.JpegGpuError:  # a call the library decodes image by image (lone plans): the decoders' own stage timing applies
+            out["stage_us"] = {}
+    bt.destroy()
+    for s in slots:
+        s.dec.cleanup()
+    return out
+
+
+def batch_curve(args, torch, jp, images, device, stream):
+    """`batch_curve`: device time per image of one batched call of 1 / 2 / 4 / 8 / 16 / 32 / 64 cfg-2 images with the plan
+    the library picks for that many (what a service that cannot wait for 64 images sees)."""
+    return [batch_point(args, torch, jp, images, device, stream, nb, args.curve_iters) for nb in (1, 2, 4, 8, 16, 32, 64)]
+
+
+def rank_shard(args, torch, jp, images, device, stream):
+    """BASELINE.json configs[2]'s PER-RANK unit of work on one GPU: the 8 images a rank of an 8-GPU node decodes (cfg 2,
+    seeds 0..7) through the whole boundary protocol -- jpeggpu_ext_parse_headers on a host thread pool, the two H2D copies
+    of every image, ONE jpeggpu_ext_decode_batch, stream sync -- from pinned host memory, wall clock, `--shard-iters`
+    iterations after 3 warm-ups; the device part of the same iterations from HIP events around the batched call."""
+    nb = 8
+    mine = [images[i % len(images)] for i in range(nb)]
+    slots = [Slot(torch, jp, d, device, args.subseq_bytes, batched=nb) for d in mine]
+    pinned = []
+    for d in mine:
+        t = torch.empty(len(d), dtype=torch.uint8).pin_memory()
+        t.numpy()[:] = memoryview(d)
+        pinned.append(t)
+    # d_tmp must hold whatever plan parse_header picks in the loop: it is the same plan as the probe's (same bytes, same hint)
+    bt = jp.Batch(sum(s.layout.num_scans for s in slots))
+    scratch = torch.empty(bt.scratch_size, dtype=torch.uint8, device=device)
+    bt.set_items([(s.dec, s.ptrs, s.pitches, s.base, s.tmp_size) for s in slots])
+    bt.set_overlap(2)  # one caller stream: two parts hide each other's synchronisation tail (jpeggpu_ext.h)
+    wall, dev, parse = [], [], []
+    for it in range(args.shard_iters + 3):
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        t0 = time.perf_counter()
+        jp.parse_headers([s.dec for s in slots], pinned, num_threads=min(nb, args.host_threads))
+        t1 = time.perf_counter()
+        for s in slots:
+            s.dec.transfer(s.base, s.tmp_size, stream.cuda_stream)
+        e0.record(stream)
+        bt.decode(scratch.data_ptr(), stream.cuda_stream)
+        e1.record(stream)
+        stream.synchronize()
+        t2 = time.perf_counter()
+        if it >= 3:
+            wall.append((t2 - t0) * 1e3)
+            parse.append((t1 - t0) * 1e3)
+            dev.append(e0.elapsed_time(e1))
+    ok = None
+    if not args.no_verify:
+        _, bad = verify(slots[:2], torch)
+        ok = not bad
+    lay = slots[0].layout
+    out = {"what": "BASELINE.json configs[2], one rank's share on one GPU: 8 x cfg 2 (seeds 0..7) per call; parse_headers (%d host "
+                   "threads) -> transfer -> decode_batch (2 overlapping parts) -> sync, pinned input" % min(nb, args.host_threads),
+           "images_per_call": nb, "iters": len(wall), "p50_ms": statistics.median(wall), "p99_ms": _percentile(wall, 0.99),
+           "device_p50_ms": statistics.median(dev), "device_p99_ms": _percentile(dev, 0.99), "host_parse_p50_ms": statistics.median(parse),
+           "images_per_s": nb * len(wall) / (sum(wall) * 1e-3), "device_images_per_s": nb / (statistics.median(dev) * 1e-3),
+           "subsequence_bytes": lay.subsequence_bytes, "verified": ok}
+    bt.destroy()
+    for s in slots:
+        s.dec.cleanup()
+    return out
+
+
 def verify(slots, torch):
     """Planes of one slot per distinct image against the CPU oracle, after the timed loop: the timed launches
     did the work the number claims."""
@@ -605,7 +719,11 @@ def gather_leg(args, torch, dist, jp, shard, bset, streams, device, rank, world,
     decode alone, gather alone, the pipeline."""
     per_rank = max(1, min(64 // world, args.batch))
     per_image = bset.per_image
-    mine = bset.slots[:per_rank]
+    # the rank's images parsed again for calls of `per_rank` images (jpeggpu_ext_set_batch_hint: the timed batch's
+    # decoders were planned for 64 per call)
+    mine = [Slot(torch, jp, bset.slots[i].data, device, args.subseq_bytes, batched=per_rank) for i in range(per_rank)]
+    for s in mine:
+        s.transfer(streams[0].cuda_stream)
     on_gpu = backend == "nccl"
     nbytes = per_rank * per_image
     bufs = [bset.planes_flat[:nbytes], torch.empty(nbytes, dtype=torch.uint8, device=device)]
@@ -678,12 +796,15 @@ def gather_leg(args, torch, dist, jp, shard, bset, streams, device, rank, world,
             ok = ok and all(checksum(gl[b][r]) == int(sums[r].item()) for r in range(world))
     for bt in bts:
         bt.destroy()
+    sb = mine[0].layout.subsequence_bytes
+    for s in mine:
+        s.dec.cleanup()
     return {"what": "BASELINE.json configs[2]: 64 x 12 MP 4:2:0 sharded over the ranks (image i -> rank i mod N), decoded, planes "
                     "gathered on rank 0; the gather of round k overlaps the decode of round k + 1 (two plane buffers, side stream)",
             "images_per_round": per_rank * world, "rounds": args.gather_rounds,
             "value": per_rank * world / (overlapped_ms * 1e-3), "unit": "images/s",
             "decode_ms": decode_ms, "gather_ms": gather_ms, "overlapped_ms": overlapped_ms, "ms_per_round": overlapped_ms,
-            "bytes_per_rank": nbytes, "backend": backend, "gathered_buffers_match_senders": ok}
+            "bytes_per_rank": nbytes, "backend": backend, "gathered_buffers_match_senders": ok, "subsequence_bytes": sb}
 
 
 def segment_shard_leg(args, torch, dist, jp, shard, streams, device, rank, world, backend, barrier, max_over_ranks):
@@ -694,7 +815,7 @@ def segment_shard_leg(args, torch, dist, jp, shard, streams, device, rank, world
 
     big = jpegsynth.encode(7216, 5408, ((2, 2), (1, 1), (1, 1)), True, (7216 + 15) // 16, quality=88, noise=9, seed=4242)
     dec = jp.Decoder()
-    dec.set_batched(True)
+    dec.set_batched(True)  # 256-byte subsequences: the share of a 39 MP image fills the chip
     dec.set_segment_shard(rank, world)
     info = dec.parse_header(big)
     n = dec.get_buffer_size()
@@ -915,6 +1036,42 @@ def main():
                 p["batch_verified"] = not bad
             pset.destroy()
         out["other_configs"] = others
+    if rank == 0 and world == 1 and args.mode == "batch":
+        # what callers that cannot wait for 64 images see, and BASELINE configs[2]'s per-rank unit of work on this one GPU
+        if args.curve_iters > 0:
+            out["batch_curve"] = batch_curve(args, torch, jp, images, device, streams[0])
+        if args.shard_iters > 0:
+            out["config3_rank_shard"] = rank_shard(args, torch, jp, images, device, streams[0])
+    if rank == 0:
+        # The driver's record keeps `value`, `config`, `roofline` and `cpu_baseline` whole and only names the other keys:
+        # the second half of BASELINE's metric (p50 latency), the PCIe-inclusive rate, the real image's fraction and the
+        # small-batch figures are therefore ALSO stored inside `roofline` (copies of the keys above, nothing new).
+        keep = {}
+        lat = out.get("latency_ms") or {}
+        if lat:
+            keep["latency_p50_ms"], keep["latency_p99_ms"] = lat["p50"], lat["p99"]
+            keep["latency_protocol"] = lat["protocol"]
+        if out.get("latency_ms_device_scan"):
+            keep["latency_p50_ms_device_scan"] = out["latency_ms_device_scan"]["p50"]
+        if out.get("value_full_path") is not None:
+            keep["value_full_path"] = out["value_full_path"]
+        ph = (out.get("other_configs") or {}).get("config1_photo_12MP_420_dri252") or {}
+        if ph.get("batch_roofline_frac") is not None:
+            keep["photo_frac"] = ph["batch_roofline_frac"]
+            keep["photo_images_per_s"] = ph.get("batch_images_per_s")
+            keep["photo_pass_us_serialized"] = {k: v for k, v in (ph.get("batch_stage_us_serialized") or {}).items() if k in PASS_STAGES}
+        if ph.get("p50_ms") is not None:
+            keep["photo_latency_p50_ms"] = ph["p50_ms"]
+        if out.get("batch_curve"):
+            keep["batch_curve"] = [{"images": p["images"], "device_us_per_image": p["device_us_per_image"], "subsequence_bytes": p["subsequence_bytes"]}
+                                   for p in out["batch_curve"]]
+        if out.get("config3_rank_shard"):
+            keep["config3_rank_shard"] = {k: out["config3_rank_shard"][k] for k in
+                                          ("images_per_call", "iters", "p50_ms", "p99_ms", "device_p50_ms", "device_p99_ms", "images_per_s", "subsequence_bytes")}
+        if out.get("roofline") is not None:
+            out["roofline"].update(keep)
+        else:
+            out["config"].update(keep)
     if rank == 0 and cpu is not None:
         out["cpu_baseline"] = cpu
     if world > 1:

@@ -38,6 +38,12 @@ extern "C" {
  * jpeggpu_ext_decode_batch accepts any mix of sizes (one group of launches per size). */
 enum jpeggpu_status jpeggpu_ext_set_subsequence_bytes(jpeggpu_decoder_t decoder, int subseq_bytes);
 enum jpeggpu_status jpeggpu_ext_set_batched(jpeggpu_decoder_t decoder, int batched);
+/* The plan knows the batch size: tell the decoder ABOUT how many images of this kind share one jpeggpu_ext_decode_batch
+ * call (0: decoded on its own, the default; jpeggpu_ext_set_batched(decoder, 1) is the hint 64, "the chip is full"). What
+ * is chosen at the next parse_header -- subsequence size, multi-hypothesis tables -- is then made for a launch of that
+ * size, and jpeggpu_ext_decode_batch picks its kernels from the subsequences a call REALLY holds. A wrong hint costs speed,
+ * never correctness: any decoder may be passed to either decode call. */
+enum jpeggpu_status jpeggpu_ext_set_batch_hint(jpeggpu_decoder_t decoder, int images_per_call);
 
 struct jpeggpu_ext_scan_layout {
     int num_components;        /* components in this scan */

@@ -110,6 +110,8 @@ def lib():
     L.jpeggpu_decoder_cleanup.argtypes = [dec]
     L.jpeggpu_ext_set_subsequence_bytes.argtypes = [dec, C.c_int]
     L.jpeggpu_ext_set_batched.argtypes = [dec, C.c_int]
+    if hasattr(L, "jpeggpu_ext_set_batch_hint"):  # (a library built before round 5, loaded through JPEGGPU_LIB for an A/B run, has none)
+        L.jpeggpu_ext_set_batch_hint.argtypes = [dec, C.c_int]
     L.jpeggpu_ext_get_layout.argtypes = [dec, C.POINTER(ExtLayout)]
     L.jpeggpu_ext_set_profiling.argtypes = [dec, C.c_int]
     L.jpeggpu_ext_get_stage_ms.argtypes = [dec, C.POINTER(C.c_float)]
@@ -175,6 +177,14 @@ class Decoder:
         """This decoder's images share their launches with others (jpeggpu_ext_decode_batch): the per-image choice
         of the subsequence size is made for throughput instead of for the latency of one image."""
         _check(lib().jpeggpu_ext_set_batched(self._h, int(on)), "jpeggpu_ext_set_batched")
+
+    def set_batch_hint(self, images_per_call: int):
+        """About how many images of this kind share one jpeggpu_ext_decode_batch call (0: decoded on its own). The plan
+        of the next parsed images -- subsequence size, multi-hypothesis speculation -- is made for a launch of that size."""
+        if hasattr(lib(), "jpeggpu_ext_set_batch_hint"):
+            _check(lib().jpeggpu_ext_set_batch_hint(self._h, int(images_per_call)), "jpeggpu_ext_set_batch_hint")
+        else:
+            self.set_batched(images_per_call > 0)
 
     def parse_header(self, data, size=None) -> ImgInfo:
         """`data`: bytes, a numpy uint8 array, or an integer host address (then `size` is required).

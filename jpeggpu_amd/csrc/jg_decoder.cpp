@@ -109,7 +109,11 @@ struct Decoder {
     // (jpeggpu_ext_set_batched; jpeggpu_ext_decode_batch accepts any mix of sizes) -- unless the caller fixed one
     // (jpeggpu_ext_set_subsequence_bytes, JPEGGPU_SUBSEQ_BYTES). `subseq_bytes` is the size of the last parsed image.
     int subseq_request  = 0;     // 0: choose per image; else 32 / 64 / 128 / 256
+    // About how many images of this kind share one jpeggpu_ext_decode_batch call (jpeggpu_ext_set_batch_hint; 0: decoded on
+    // its own, jpeggpu_ext_set_batched(1): kBatchHintFull). `batched`: the plan is a batch's (no multi-hypothesis tables).
+    int batch_hint      = 0;
     bool batched        = false;
+    int seq_subseq_used = 0;     // subsequences per sequence of the last decode call built from this parse (0: none yet)
     bool mh_enabled     = true;  // JPEGGPU_MULTI_HYPOTHESIS=0 at startup: plain speculation for lone decodes as well
     int subseq_bytes    = 64;
     bool parsed         = false;
@@ -382,8 +386,12 @@ jpeggpu_status do_transfer(Decoder& d, void* d_tmp, size_t tmp_size, hipStream_t
 }
 
 /// Validate the arguments of a decode and describe every scan of the image as a ScanJob.
+/// `lone`: jpeggpu_decoder_decode (multi-hypothesis tables where the plan has them). `keep_flows`: every flow stays in its
+/// sequence's workgroup (huff_sync_intra with re-packed flows; the tail kernel looks at sequence boundaries only) -- lone
+/// decodes and batches too small to fill the chip; else the sequence kernel runs `max_intra_iters` iterations and marks
+/// the rest for the tail kernel.
 jpeggpu_status build_jobs(
-    Decoder& d, const jpeggpu_img* img, void* d_tmp, size_t tmp_size, int max_intra_iters, bool lone, std::vector<jg::ScanJob>& jobs)
+    Decoder& d, const jpeggpu_img* img, void* d_tmp, size_t tmp_size, int max_intra_iters, bool lone, bool keep_flows, std::vector<jg::ScanJob>& jobs)
 {
     using namespace jg;
     if (!d.parsed) return JPEGGPU_INVALID_ARGUMENT;
@@ -410,12 +418,16 @@ jpeggpu_status build_jobs(
         sp.total_mcus       = sc.shard_mcus ? sc.shard_mcus : sc.mcus_x * sc.mcus_y; // of this decoder's share
         sp.subseq_words     = d.subseq_bytes / 4;
         sp.tab_bytes        = static_cast<uint32_t>(sc.table_pack.size());
-        sp.max_intra_iters  = max_intra_iters;
+        sp.max_intra_iters  = keep_flows ? kSeqLanes : max_intra_iters;
+        sp.tail_marks       = keep_flows ? 0 : 1;
         sp.cursor_off       = sc.cursor_off;
         sp.tab_bytes_sync   = static_cast<uint32_t>(sc.table_pack_sync.size());
         sp.cursor_off_sync  = sc.cursor_off_sync;
         sp.mh               = lone ? pl.mh : 0; // the multi-hypothesis kernels run in front of a lone decode's sequence kernel only
-        sp.seq_subseq       = lone ? kSeqSubseq : kSeqSubseqBatch; // a batch's sequences are longer: one overlap lane (jg_defs.h)
+        // a full batch's sequences are longer: one overlap lane (jg_defs.h); where every flow stays in the workgroup the 16
+        // overlap lanes are what keeps the sequence boundaries from starting tail flows
+        sp.seq_subseq       = keep_flows ? kSeqSubseq : kSeqSubseqBatch;
+        d.seq_subseq_used   = sp.seq_subseq;
         job.mh_p            = reinterpret_cast<int*>(base + pl.mh_p);
         job.mh_cz           = reinterpret_cast<int*>(base + pl.mh_cz);
         job.mh_link         = reinterpret_cast<uint32_t*>(base + pl.mh_link);
@@ -568,7 +580,7 @@ jpeggpu_status do_decode(Decoder& d, jpeggpu_img* img, void* d_tmp, size_t tmp_s
     using namespace jg;
     d.jobs.clear();
     // one image: latency matters, keep every flow inside the sequence's workgroup
-    const jpeggpu_status st = build_jobs(d, img, d_tmp, tmp_size, jg::kSeqLanes, true, d.jobs);
+    const jpeggpu_status st = build_jobs(d, img, d_tmp, tmp_size, jg::kSeqLanes, true, true, d.jobs);
     if (st != JPEGGPU_SUCCESS) return st;
     d.next_event_set();
     d.mark(-1, stream);
@@ -687,7 +699,7 @@ enum jpeggpu_status jpeggpu_decoder_parse_header(
     d.parsed   = false;
     jpeggpu_status st;
     try {
-        const int ask = d.subseq_request > 0 ? d.subseq_request : d.batched ? jg::kSubseqAutoBatched : jg::kSubseqAutoLone;
+        const int ask = d.subseq_request > 0 ? d.subseq_request : -d.batch_hint; // 0 / -N: chosen per image for N images per call
         st = d.reader.parse(data, size, ask, d.logger, d.device_scan != 0, d.shard_rank, d.shard_world);
         d.subseq_bytes = d.reader.subseq_bytes();
     } catch (const std::bad_alloc&) {
@@ -718,6 +730,7 @@ enum jpeggpu_status jpeggpu_decoder_parse_header(
     }
     d.make_plan();
     if (!d.fill_blob()) return JPEGGPU_OUT_OF_HOST_MEMORY;
+    d.seq_subseq_used = 0;
     d.parsed = true;
     return JPEGGPU_SUCCESS;
 }
@@ -765,7 +778,16 @@ enum jpeggpu_status jpeggpu_ext_set_subsequence_bytes(jpeggpu_decoder_t decoder,
 enum jpeggpu_status jpeggpu_ext_set_batched(jpeggpu_decoder_t decoder, int batched)
 {
     if (!decoder) return JPEGGPU_INVALID_ARGUMENT;
-    decoder->d.batched = batched != 0;
+    return jpeggpu_ext_set_batch_hint(decoder, batched != 0 ? jg::kBatchHintFull : 0);
+}
+
+enum jpeggpu_status jpeggpu_ext_set_batch_hint(jpeggpu_decoder_t decoder, int images_per_call)
+{
+    if (!decoder || images_per_call < 0) return JPEGGPU_INVALID_ARGUMENT;
+    decoder->d.batch_hint = images_per_call;
+    // up to kLonePlanImages images per call get the lone decode's plan (multi-hypothesis tables, 64-byte subsequences):
+    // jpeggpu_ext_decode_batch then decodes them one by one, as jpeggpu_decoder_decode would (jg::lone_plan)
+    decoder->d.batched = !jg::lone_plan(images_per_call);
     decoder->d.parsed  = false;
     return JPEGGPU_SUCCESS;
 }
@@ -839,7 +861,9 @@ enum jpeggpu_status jpeggpu_ext_get_layout(jpeggpu_decoder_t decoder, struct jpe
     const jg::Stream& s = d.reader.s;
     std::memset(out, 0, sizeof(*out));
     out->subsequence_bytes = d.subseq_bytes;
-    out->subsequences_per_sequence = d.batched ? jg::kSeqSubseqBatch : jg::kSeqSubseq; // of the call type the decoder was set up for
+    // of the last decode call built from this parse, whichever call it was (jpeggpu_decoder_decode and small batches: 240, a
+    // full batch: 255); before any: what a call of the kind the decoder was set up for would use
+    out->subsequences_per_sequence = d.seq_subseq_used ? d.seq_subseq_used : d.batched ? jg::kSeqSubseqBatch : jg::kSeqSubseq;
     out->num_scans         = s.num_scans;
     out->transferred_bytes = d.plan.bytes_len;
     out->blob_bytes        = d.plan.blob_size;
@@ -913,6 +937,9 @@ struct jpeggpu_batch {
     // kernel from 364 to 204 / 70 / 14 us per 64 images and the sequence kernel from 680 to 937 / 1109 / 1138 -- a
     // workgroup keeps its 22 KB of tables in LDS while one of its four waves works, and LDS is what bounds the kernel.
     int sync_iters              = 1;
+    bool sync_iters_set         = false; // jpeggpu_ext_batch_set_sync_iterations was called: the caller's cap, whatever the call's size
+    // Calls of fewer subsequences than this keep every flow in the sequence kernel (decode_batch_impl).
+    long long keep_flows_below  = jg::kKeepFlowsBelowSubseq;
     // A caller with ONE stream leaves the GPU idle while the latency-bound tail kernel runs (a fifth of a
     // batch's time). With overlap > 1 the jobs are split into that many parts, part 0 on the caller's
     // stream and the others on internal streams forked from and joined back into it with events.
@@ -945,6 +972,7 @@ enum jpeggpu_status jpeggpu_ext_batch_create(jpeggpu_batch_t* batch, int max_sca
     jpeggpu_batch* b = new (std::nothrow) jpeggpu_batch();
     if (!b) return JPEGGPU_OUT_OF_HOST_MEMORY;
     b->max_jobs = max_scans;
+    if (const char* e = std::getenv("JPEGGPU_EXP_KEEP_FLOWS_BELOW")) b->keep_flows_below = std::atoll(e); // experiments (tools/probe/batch_curve.py)
     for (int r = 0; r < jpeggpu_batch::kRing; ++r) {
         void* p = nullptr;
         if (hipHostMalloc(&p, jpeggpu_ext_batch_scratch_size(max_scans), hipHostMallocDefault) != hipSuccess ||
@@ -1020,6 +1048,34 @@ static enum jpeggpu_status decode_batch_impl(
     // parse_header unless the caller fixed it), and every size is a group of launches of its own.
     for (int i = 0; i < num_items; ++i)
         if (!items[i].decoder || !items[i].img) return JPEGGPU_INVALID_ARGUMENT;
+    // A call of one or two images planned as lone decodes (jpeggpu_ext_set_batch_hint): decoded one by one with the lone
+    // decode's kernels, multi-hypothesis speculation included -- the chip is empty either way.
+    {
+        bool all_lone = num_items <= jg::kLonePlanImages;
+        for (int i = 0; i < num_items && all_lone; ++i) all_lone = !items[i].decoder->d.batched;
+        if (all_lone) {
+            if (batch->profiling) return JPEGGPU_INVALID_ARGUMENT; // stage timing of such calls: jpeggpu_ext_set_profiling of the decoders
+            for (int i = 0; i < num_items; ++i) {
+                const jpeggpu_status st = do_decode(items[i].decoder->d, items[i].img, items[i].d_tmp, items[i].tmp_size, stream);
+                if (st != JPEGGPU_SUCCESS) return st;
+            }
+            return JPEGGPU_SUCCESS;
+        }
+    }
+    // Does the call fill the chip? A launch of fewer than kKeepFlowsBelowSubseq subsequences does not: its sequence kernel
+    // keeps every flow in the workgroup (the lone decode's kernel, one job per blockIdx.y) and the tail kernel has only
+    // the sequence boundaries to look at; a full batch runs one flow iteration there and leaves the rest to the tail kernel,
+    // whose latency other launches hide.
+    bool keep_flows = false;
+    {
+        long long total_subseq = 0;
+        for (int i = 0; i < num_items; ++i) {
+            const jg::Stream& s = items[i].decoder->d.reader.s;
+            if (!items[i].decoder->d.parsed) return JPEGGPU_INVALID_ARGUMENT;
+            for (int k = 0; k < s.num_scans; ++k) total_subseq += s.scans[k].num_subseq;
+        }
+        keep_flows = batch->sync_iters_set ? false : total_subseq < batch->keep_flows_below;
+    }
     std::vector<int>& order = batch->order;
     order.resize(static_cast<size_t>(num_items));
     for (int i = 0; i < num_items; ++i) order[static_cast<size_t>(i)] = i;
@@ -1034,7 +1090,7 @@ static enum jpeggpu_status decode_batch_impl(
             group_begin.push_back(static_cast<int>(batch->jobs.size()));
         }
         const size_t first_job = batch->jobs.size();
-        const jpeggpu_status st = build_jobs(it.decoder->d, it.img, it.d_tmp, it.tmp_size, batch->sync_iters, false, batch->jobs);
+        const jpeggpu_status st = build_jobs(it.decoder->d, it.img, it.d_tmp, it.tmp_size, batch->sync_iters, false, keep_flows, batch->jobs);
         if (st != JPEGGPU_SUCCESS) return st;
         if (const int dk = device_scan_index(it.decoder->d); dk >= 0) {
             // device-side front end (jpeggpu_ext_set_device_scan): the counts of this job are filled in on the device
@@ -1100,6 +1156,7 @@ static enum jpeggpu_status decode_batch_impl(
         for (int w = 0; w < gw; ++w) {
             Part p{a + static_cast<int>(static_cast<long long>(b - a) * w / gw), a + static_cast<int>(static_cast<long long>(b - a) * (w + 1) / gw), w, jg::JobExtent{}};
             for (int j = p.begin; j < p.end; ++j) jg::extend(p.extent, batch->jobs[static_cast<size_t>(j)]);
+            p.extent.repack_flows = keep_flows;
             if (p.end > p.begin) parts.push_back(p);
         }
     }
@@ -1130,7 +1187,8 @@ enum jpeggpu_status jpeggpu_ext_batch_set_overlap(jpeggpu_batch_t batch, int par
 enum jpeggpu_status jpeggpu_ext_batch_set_sync_iterations(jpeggpu_batch_t batch, int iterations)
 {
     if (!batch || iterations < 1) return JPEGGPU_INVALID_ARGUMENT; // the first flow iteration supplies n and the DC sums
-    batch->sync_iters = iterations;
+    batch->sync_iters     = iterations;
+    batch->sync_iters_set = true;
     return JPEGGPU_SUCCESS;
 }
 

@@ -40,6 +40,16 @@ constexpr int kSeqSubseqBatch  = kSeqLanes - kSeqOverlapBatch;
 #define JG_TAIL_PART 960
 #endif
 constexpr int kTailPartSubseq = JG_TAIL_PART;
+// A batched call of fewer subsequences than this does not fill the chip (256 CUs x 5 workgroups of 255 lanes hold
+// 326 000): what it waits for is the chain of dependent flow iterations, as a lone decode does, and its sequence kernel
+// keeps every flow in the workgroup (jg_decoder.cpp, decode_batch_impl; jg_kernels.hip, JobArrayLow). Measured per call of
+// cfg-2 images at 256 bytes (11 400 subsequences each; us, flows kept / one iteration + marks + tail kernel, round 5):
+// 2: 530 / 567, 4: 561 / 613, 8: 626 / 678, 16: 828 / 878, 24: 1194 / 1113, 32: 1502 / 1408, 64: 2833 / 2418; the
+// reference's photo 16: 1034 / 1121, 32: 1895 / 1668.
+#ifndef JG_KEEP_FLOWS_BELOW
+#define JG_KEEP_FLOWS_BELOW 220000
+#endif
+constexpr long long kKeepFlowsBelowSubseq = JG_KEEP_FLOWS_BELOW;
 constexpr int kDestuffWin   = 4096; // stuffed bytes handled by one destuff workgroup (256 lanes x 16 B)
 
 /// Zig-zag index -> raster index inside a data unit (T.81 figure A.6; reference src/defs.hpp:94-102).
@@ -270,6 +280,9 @@ struct ScanParams {
     uint32_t tab_bytes_sync, cursor_off_sync; // the same for the sync pack (state-only passes)
     int mh;               // hypotheses per subsequence of the multi-hypothesis speculation (below); 0: off
     int seq_subseq;       // subsequences a workgroup of the Huffman kernels owns: kSeqSubseq (lone decode) or kSeqSubseqBatch
+    int tail_marks;       // 1: the sequence kernel caps its flow iterations and leaves `pending` marks for huff_sync_tail (a
+                          //    full batch); 0: every flow stays in its sequence's workgroup and the tail kernel looks at the
+                          //    sequence boundaries only (a lone decode, a small batch). Set beside max_intra_iters (build_jobs).
     /// The state-only kernels call this on their copy of the parameters before loading the tables.
     JG_HD inline void use_sync_pack()
     {

@@ -146,6 +146,17 @@ struct JobArray {
     __device__ __forceinline__ const ScanJob& get() const { return jobs[blockIdx.y]; }
 };
 
+struct JobArrayLow {
+    // A batch that does not fill the chip (jpeggpu_ext_decode_batch with a handful of images): what such a call waits for is
+    // the chain of dependent flow iterations, as a lone decode does, and LDS is not what bounds the sequence kernel then: the
+    // lone decode's kernel (all flows kept in the workgroup, survivors re-packed), one job per blockIdx.y. Only
+    // huff_sync_intra is instantiated for it; every other stage of such a batch runs with JobArray.
+    static constexpr bool kSpeculateStateOnly = false;
+    static constexpr bool kRepackFlows = true;
+    const ScanJob* jobs;
+    __device__ __forceinline__ const ScanJob& get() const { return jobs[blockIdx.y]; }
+};
+
 struct JobSingle {
     // One job that lives in device memory, whatever blockIdx.y is: the lone decode of a device-scanned image (the
     // second dimension of the multi-hypothesis kernels' grid is the hypothesis).
@@ -720,6 +731,8 @@ __global__ __launch_bounds__(T) void huff_sync_intra(JS js)
             } else {
                 NoSink sums; // exact for a subsequence that opens a segment, replaced by a flow everywhere else
                 decode_subsequence(st, bw, fetch, (rel + 1) * kBits, s_tab, sp, sums);
+            }
+            if (!JS::kSpeculateStateOnly) {
                 s_n[t]    = st.n;
                 s_dc01[t] = st.dc01;
                 s_dc23[t] = st.dc23;
@@ -1393,7 +1406,8 @@ __global__ __launch_bounds__(TL) void huff_sync_tail(JS js)
     // leaves no marks: only the last subsequence of every sequence is looked at, one round of the loop instead of one per
     // TL subsequences: 48 000 subsequences of a 12 MP scan without restart markers are ONE part, and building its list took
     // 60 of the kernel's 70 us.)
-    const bool marks = sp.max_intra_iters < T;
+    // (ScanParams::tail_marks: set by build_jobs beside max_intra_iters -- up to round 4 this kernel inferred it from the cap)
+    const bool marks = sp.tail_marks != 0;
     const int SEQ    = sp.seq_subseq;
     const int step   = marks ? 1 : SEQ;
     int count = 0;
@@ -2385,6 +2399,9 @@ hipError_t launch_huff(Stage stage, const JS& js, const JobExtent& e, int grid_y
         if constexpr (JS::kRepackFlows) {
             if ((err = allow_lds(huff_sync_intra<W, JS>, seq_lds)) != hipSuccess) return err;
             huff_sync_intra<W, JS><<<dim3(e.max_seq, grid_y), T, seq_lds, stream>>>(js);
+        } else if (e.repack_flows) { // a batch too small to fill the chip: the lone decode's sequence kernel (JobArrayLow)
+            if ((err = allow_lds(huff_sync_intra<W, JobArrayLow>, seq_lds)) != hipSuccess) return err;
+            huff_sync_intra<W, JobArrayLow><<<dim3(e.max_seq, grid_y), T, seq_lds, stream>>>(JobArrayLow{js.jobs});
         } else {
             const size_t lds = SeqLdsBatch::kTabs + e.max_tab_bytes_sync;
             if ((err = allow_lds(huff_sync_intra_batch<W, JS>, lds)) != hipSuccess) return err;

@@ -33,6 +33,8 @@ struct JobExtent {
     int subseq_words    = 0; // identical for every job of a launch
     uint32_t max_tab_bytes = 0;      // largest write-pass table pack
     uint32_t max_tab_bytes_sync = 0; // largest sync pack
+    bool repack_flows   = false;     // batch launches: the lone decode's sequence kernel (every flow kept in its workgroup), for
+                                     // calls too small to fill the chip; the jobs then carry max_intra_iters = kSeqLanes, tail_marks = 0
 };
 void extend(JobExtent& e, const ScanJob& job);
 

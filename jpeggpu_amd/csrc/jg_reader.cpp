@@ -504,7 +504,7 @@ jpeggpu_status Reader::read_sos(const Logger& log)
     scan.begin            = static_cast<size_t>(cur_ - base_);
     if (s.num_scans == 0 && subseq_request_ <= 0) {
         // per-image choice (jg_reader.hpp): what is left of the file bounds the scan, DRI and the geometry give the segments
-        subseq_bytes_ = choose_subseq_bytes(subseq_request_ == kSubseqAutoBatched, static_cast<size_t>(end_ - cur_),
+        subseq_bytes_ = choose_subseq_bytes(-subseq_request_, static_cast<size_t>(end_ - cur_),
                                             static_cast<size_t>(ceil_div(total_mcus, scan.mcus_per_segment)));
         log.log("\tsubsequence size chosen for this image: %d bytes\n", subseq_bytes_);
     }

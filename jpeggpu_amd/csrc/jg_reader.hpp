@@ -94,9 +94,21 @@ struct Stream {
     size_t xfer_end   = 0;
 };
 
-constexpr int kSubseqAutoLone = 0, kSubseqAutoBatched = -1;
+/// Requests for a per-image choice (Reader::parse): 0 or -N, N = about how many images share the call (kBatchHintFull:
+/// "a batch", jpeggpu_ext_set_batched).
+constexpr int kBatchHintFull = 64;
+constexpr int kSubseqAutoLone = 0, kSubseqAutoBatched = -kBatchHintFull;
+/// Calls of so few images get the plan of a lone decode (multi-hypothesis tables, the lone decode's subsequence size) and
+/// jpeggpu_ext_decode_batch decodes them one by one: the chip is empty either way, and what such a call waits for is the
+/// chain of dependent passes the speculation shortens (jg_defs.h).
+#ifndef JG_LONE_PLAN_IMAGES
+#define JG_LONE_PLAN_IMAGES 1
+#endif
+constexpr int kLonePlanImages = JG_LONE_PLAN_IMAGES;
+inline bool lone_plan(int images_per_call) { return images_per_call <= kLonePlanImages; }
 
-/// Subsequence size for an image whose first scan has `scan_bytes_bound` bytes at most, in `segments` restart segments.
+/// Subsequence size for an image whose first scan has `scan_bytes_bound` bytes at most, in `segments` restart segments,
+/// decoded in calls of about `images_per_call` such images (0: on its own).
 ///   * One image at a time: what such a decode waits for is a handful of dependent passes over a subsequence (the
 ///     multi-hypothesis speculation and the one or two flow passes behind it, jg_defs.h), so shorter subsequences are
 ///     shorter passes -- as long as the extra lanes still fit the chip side by side and data units are not longer than
@@ -104,15 +116,23 @@ constexpr int kSubseqAutoLone = 0, kSubseqAutoBatched = -1;
 ///     0.47 at 64). Measured (tools/probe/latency_by_size.py, p50 at 32 / 64 / 128 bytes): 0.08 MP 0.18 / 0.22 / 0.27 ms,
 ///     2 MP 0.23 / 0.28 / 0.40, 12 MP 0.44 / 0.41 / 0.49: 32 bytes for scans below 1 MB that have restart segments,
 ///     64 otherwise (without restart segments there is no multi-hypothesis table, and 64 was best at every size).
-///   * Images that share launches: the chip is full anyway and every subsequence costs a fixed amount of state,
-///     table loads and scan work, so the longest size wins -- 256 bytes -- unless the restart segments are so short
-///     that padding each of them to whole subsequences would be a visible share of the decode (kept below 1/16: a
-///     segment is padded by half a subsequence on average), or the scan so small that it would not fill two sequences.
-inline int choose_subseq_bytes(bool batched, size_t scan_bytes_bound, size_t segments)
+///   * Images that share launches and fill the chip: every subsequence costs a fixed amount of state, table loads and
+///     scan work, so the longest size wins -- 256 bytes -- unless the restart segments are so short that padding each of
+///     them to whole subsequences would be a visible share of the decode (kept below 1/16: a segment is padded by half
+///     a subsequence on average), or the scan so small that it would not fill two sequences.
+///   * Calls that do NOT fill the chip (round 5; up to about a dozen 12 MP images): the write pass's workgroups live as
+///     long as ONE lane needs for its subsequence, whatever the chip holds, and the flow iterations are a chain of
+///     whole-subsequence decodes: 128 bytes. Device us per call of 2 / 4 / 8 / 16 cfg-2 images with every flow kept in the
+///     sequence kernel (tools/probe/batch_curve.py): 64 bytes 393 / 478 / 696 / 1163, 128 bytes 427 / 469 / 568 / 927,
+///     256 bytes 530 / 561 / 626 / 823; the reference's photo 2 / 8: 634 / 1060, 603 / 741, 712 / 834.
+constexpr size_t kSmallCallBytes = 36u << 20; // scan bytes of a call below which it counts as small
+inline int choose_subseq_bytes(int images_per_call, size_t scan_bytes_bound, size_t segments)
 {
     if (segments == 0) segments = 1;
     const size_t per_segment = scan_bytes_bound / segments;
+    const bool batched = !lone_plan(images_per_call);
     int b = batched ? 256 : 64;
+    if (batched && static_cast<size_t>(images_per_call) * scan_bytes_bound < kSmallCallBytes) b = 128;
     if (!batched && segments > 1 && scan_bytes_bound < (1u << 20)) b = 32;
     while (b > 32 && per_segment < static_cast<size_t>(8 * b)) b >>= 1;
     while (b > 64 && scan_bytes_bound < static_cast<size_t>(2 * kSeqSubseq) * static_cast<size_t>(b)) b >>= 1;

@@ -257,6 +257,72 @@ def test_batch_decode_equals_single(torch_cuda):
         dec.cleanup()
 
 
+@pytest.mark.parametrize("images", [1, 2, 4, 8, 16])
+def test_small_batches_with_the_plans_the_library_picks(torch_cuda, images, monkeypatch):
+    """jpeggpu_ext_set_batch_hint: calls of 1 / 2 / 4 / 8 / 16 images, every decoder told the call's size, decoded with
+    whatever the library then picks -- one image: the lone decode's plan (multi-hypothesis tables) and its kernels; a
+    handful: shorter subsequences and the sequence kernel that keeps every flow in its workgroup; and, forced here for
+    the same items, the full batch's one flow iteration + tail kernel -- planes against the oracle each time. The layout
+    says what the last call used (a decoder set up for one call type and passed to the other)."""
+    import jpeggpu_amd
+    from oracle import oracle
+    from tools import jpegsynth
+
+    torch = torch_cuda
+    m = cases.matrix()
+    # two mid-sized 4:2:0 files with restart rows (several sequences, flows that cross them) among small ones of every kind
+    mid = [jpegsynth.encode(1616, 1208, cases.S420, True, 101, quality=88, noise=9, seed=70 + k) for k in range(2)]
+    pool = mid + [m[k] for k in ("multi_seq_dri", "ni_420_dri", "four_comp_opt", "gray", "multi_seq_nodri", "cfg4_small", "dri_1", "ss_4x1")]
+    datas = [pool[i % len(pool)] for i in range(images)]
+    refs = [oracle.decode(d) for d in datas]
+    for mode in ("auto", "marks"):
+        if mode == "marks":
+            monkeypatch.setenv("JPEGGPU_EXP_KEEP_FLOWS_BELOW", "0")  # read at jpeggpu_ext_batch_create
+        keep, entries = [], []
+        for i, d in enumerate(datas):
+            dec = jpeggpu_amd.Decoder()
+            if i % 3 != 2:
+                dec.set_batch_hint(images)  # (every third decoder keeps the lone plan: any decoder may go into any call)
+            info = dec.parse_header(d)
+            n, tmp, base, planes = _alloc(torch, dec, info)
+            dec.transfer(base, n, 0)
+            keep.append((dec, tmp, planes))
+            entries.append((dec, [p.data_ptr() for p in planes], [p.stride(0) for p in planes], base, n))
+        lay0 = keep[0][0].layout()
+        if images == 1:
+            assert lay0.subsequence_bytes in (32, 64) and lay0.scans[0].hypotheses == 6, (lay0.subsequence_bytes, lay0.scans[0].hypotheses)
+        else:
+            assert lay0.subsequence_bytes == 128 and lay0.scans[0].hypotheses == 0, (lay0.subsequence_bytes, lay0.scans[0].hypotheses)
+            assert lay0.subsequences_per_sequence == 255  # before any call: what a full batch would use
+        batch = jpeggpu_amd.Batch(sum(k[0].layout().num_scans for k in keep))
+        scratch = torch.empty(batch.scratch_size, dtype=torch.uint8, device="cuda:0")
+        batch.set_items(entries)
+        for rep in range(2):
+            for _, _, planes in keep:
+                for p in planes:
+                    p.fill_(0xCD)
+            batch.decode(scratch.data_ptr(), 0)
+            torch.cuda.synchronize()
+            for i, (ref, (dec, _, planes)) in enumerate(zip(refs, keep)):
+                for c in range(ref.ncomp):
+                    assert np.array_equal(planes[c].cpu().numpy(), ref.planes[c]), (images, mode, i, c, rep)
+        # what the call used: a small call keeps its flows in the sequence kernel (240 + 16 lanes), a full one does not
+        used = [k[0].layout().subsequences_per_sequence for k in keep]
+        assert used == [240 if mode == "auto" or images == 1 else 255] * images, (mode, used)
+        if images >= 2:
+            # ... and the drop-in call on a decoder that was set up for batches reports its own geometry afterwards
+            dec, _, planes = keep[0]
+            ent = entries[0]
+            dec.decode(ent[1], ent[2], ent[3], ent[4], 0)
+            torch.cuda.synchronize()
+            assert dec.layout().subsequences_per_sequence == 240
+            for c in range(refs[0].ncomp):
+                assert np.array_equal(planes[c].cpu().numpy(), refs[0].planes[c])
+        batch.destroy()
+        for dec, _, _ in keep:
+            dec.cleanup()
+
+
 def test_corrupt_entropy_data_is_memory_safe(torch_cuda):
     """Random damage inside the entropy-coded segment (no new markers): the planes are garbage by
     definition, but every decode must complete, stay inside its buffers, and leave the decoder and the
