@@ -465,10 +465,47 @@ JG_HD inline void decode_units(
     w.seek(st.p);
     int flush_in = Sink::kFlushPeriod; // iterations to the sink's next flush point
     int flush_no = 0;                  // how many there have been
-    for (int it = 0; it < max_iters; ++it) {
-        if (iters_out) iters_out[0] = it + 1;
+    // The loop is UNROLLED over the DC period (round 5): one body = the DC slot and kWriteDcPeriod AC steps, then -- every
+    // kRareBodies-th body -- the rare slot, and -- every kFlushBodies-th -- the flush point. As a loop over single iterations
+    // every one of them paid three scalar tests with their branches (`it & 3`, `it & 7`, the flush counter: a third of the
+    // loop's scalar instructions, and scalar instructions are not free riders in a loop bound by instruction issue:
+    // DESIGN.md section 3); now a body pays two. The slots fall on the same iterations as before.
+    static_assert(kWriteRarePeriod % kWriteDcPeriod == 0 && Sink::kFlushPeriod % kWriteDcPeriod == 0, "slot periods are whole bodies");
+    constexpr int kRareBodies = kWriteRarePeriod / kWriteDcPeriod, kFlushBodies = Sink::kFlushPeriod / kWriteDcPeriod;
+    static_assert((kRareBodies & (kRareBodies - 1)) == 0, "a power of two");
+    flush_in = kFlushBodies; // bodies to the sink's next flush point
+    // what the rare slot needs of the AC step in front of it
+    uint32_t peek = 0, e0 = 0;
+    int len0 = 0, cat0 = 0, ready = 0;
+    uint32_t tab_off = 0;
+    // AC step, every lane
+    const auto ac_step = [&]() __attribute__((always_inline)) {
+        peek             = w.look();
+        tab_off          = actab;
+        const TabPtr tab = JG_TAB_AT(tabs, actab);
+        e0               = lut16_entry<kLutBitsAc>(tab, peek);
+        len0             = e0 & 31;
+        cat0             = (e0 >> 5) & 15;
+        // No step for a lane outside a unit (zm >= 63) or with a window that ran out (the DC symbol just emptied it, or
+        // its refill has to wait an iteration): `ready`. None here for a symbol that is `slow` -- an entry without a
+        // length, a category with an escape entry, a window about to leave its row: the lane waits for the rare slot.
+        // The sign of one OR says so.
+        ready            = (62 - zm) | w.left();
+        const int slow   = (len0 - 1) | (kEscapeFromCategory - 1 - cat0) | w.crossed();
+        const uint32_t e = (ready | slow) < 0 ? 0u : e0;
+        const int total  = e & 31;
+        if (iters_out && e != 0) ++iters_out[1];
+        w.skip(total);
+        const int s = (e >> 5) & 15;
+        zm += static_cast<int>(e >> 9); // index of the symbol's coefficient; 63 or more: the unit is complete
+        const int v = extend_bits(bits_field(peek, total, s), s);
+        sink.ac(s, zm, v);
+    };
+    int body = 0;
+    for (int it = 0; it < max_iters; it += kWriteDcPeriod, ++body) {
+        if (iters_out) iters_out[0] = it + kWriteDcPeriod;
         w.top(); // refill where the window ran out (at most 32 bits are consumed between two looks)
-        if ((it & (kWriteDcPeriod - 1)) == 0) { // DC slot: the same iterations for every lane of a wave
+        { // DC slot: the same iterations for every lane of a wave
             // (a lane whose window is about to leave its row first waits for the rare slot: the DC symbol may empty the
             // window, and the refill behind it would step out of the row)
             if (static_cast<uint32_t>(zm - 63) < static_cast<uint32_t>(kStopped - 63) && (w.left() | w.crossed()) >= 0) {
@@ -477,14 +514,14 @@ JG_HD inline void decode_units(
                     zm = kStopped; // the next unit is the next lane's, or lies past the segment
                 } else {
                     const Cursor cur    = JG_LOAD_CURSOR(unit_entry);
-                    const uint32_t peek = w.look();
+                    const uint32_t dpeek = w.look();
                     const TabPtr tab    = JG_TAB_AT(tabs, JG_CUR_TABS & 0xFFFFu);
-                    uint32_t e          = lut16_entry<kLutBitsDc>(tab, peek);
-                    if ((e & 31u) == 0) e = huff_second_level(tab, e, peek, true);
+                    uint32_t e          = lut16_entry<kLutBitsDc>(tab, dpeek);
+                    if ((e & 31u) == 0) e = huff_second_level(tab, e, dpeek, true);
                     const int total = e & 31;
                     w.skip(total); // the window may run out: the lane then sits the AC step of this iteration out
                     const int s      = (e >> 5) & 15;
-                    const int v      = extend_bits(bits_field(peek, total, s), s);
+                    const int v      = extend_bits(bits_field(dpeek, total, s), s);
                     const int csh    = JG_CUR_META & 63;
                     const uint64_t d = static_cast<uint64_t>(static_cast<uint32_t>(v) & 0xFFFFu) << csh;
                     dc01             = pk_add_u16(dc01, static_cast<uint32_t>(d));
@@ -500,27 +537,15 @@ JG_HD inline void decode_units(
             }
             if (!JG_WAVE_ANY(zm != kStopped)) break;
         }
-        // AC step, every lane
-        const uint32_t peek = w.look();
-        const TabPtr tab    = JG_TAB_AT(tabs, actab);
-        const uint32_t e0   = lut16_entry<kLutBitsAc>(tab, peek);
-        const int len0      = e0 & 31;
-        const int cat0      = (e0 >> 5) & 15;
-        // No step for a lane outside a unit (zm >= 63) or with a window that ran out (the DC symbol just emptied it, or
-        // its refill has to wait an iteration): `ready`. None here for a symbol that is `slow` -- an entry without a
-        // length, a category with an escape entry, a window about to leave its row: the lane waits for the rare slot.
-        // The sign of one OR says so.
-        const int ready  = (62 - zm) | w.left();
-        const int slow   = (len0 - 1) | (kEscapeFromCategory - 1 - cat0) | w.crossed();
-        const uint32_t e = (ready | slow) < 0 ? 0u : e0;
-        const int total  = e & 31;
-        if (iters_out && e != 0) ++iters_out[1];
-        w.skip(total);
-        const int s = (e >> 5) & 15;
-        zm += static_cast<int>(e >> 9); // index of the symbol's coefficient; 63 or more: the unit is complete
-        const int v = extend_bits(bits_field(peek, total, s), s);
-        sink.ac(s, zm, v);
-        if ((it & (kWriteRarePeriod - 1)) == kWriteRarePeriod - 1) { // rare slot: the same iterations for every lane of a wave
+        ac_step();
+#if defined(__HIP_DEVICE_COMPILE__)
+#pragma unroll
+#endif
+        for (int k = 1; k < kWriteDcPeriod; ++k) {
+            w.top();
+            ac_step();
+        }
+        if ((body & (kRareBodies - 1)) == kRareBodies - 1) { // rare slot: the same iterations for every lane of a wave
             // (zm and the window of a lane that waited are what they were: the null entry changed nothing)
             const bool symbol = ready >= 0 && ((len0 - 1) | (kEscapeFromCategory - 1 - cat0)) < 0;
             if (JG_WAVE_ANY(symbol || w.crossed() < 0)) {
@@ -530,6 +555,7 @@ JG_HD inline void decode_units(
                 }
                 if (w.crossed() < 0) w.cross(); // the symbol in the window, if it was only this, goes with the next iteration
                 if (symbol) {
+                    const TabPtr tab  = JG_TAB_AT(tabs, tab_off);
                     const uint32_t e2 = len0 == 0 ? huff_second_level(tab, e0, peek, false) : e0;
                     const int total2  = e2 & 31;
                     if (iters_out) ++iters_out[1];
@@ -543,7 +569,7 @@ JG_HD inline void decode_units(
             }
         }
         if (--flush_in == 0) { // the same iteration for every lane of the wave
-            flush_in = Sink::kFlushPeriod;
+            flush_in = kFlushBodies;
             sink.flush_point(flush_no++);
         }
     }

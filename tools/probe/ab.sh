@@ -5,5 +5,5 @@
 # bench.py picks the library from JPEGGPU_LIB. Remove jpeggpu_amd/lib/exp_*.so afterwards.
 libs=${@:-exp_base libjpeggpu}
 for rep in 1 2; do for lib in $libs; do
-JPEGGPU_LIB=$PWD/jpeggpu_amd/lib/$lib.so timeout -k 10 200 python bench.py --steps 4 --warmup 1 --no-cpu --e2e-rounds 0 --latency-iters 30 --unique 4 --no-verify --other-configs 0 $BENCH_ARGS > gpurun_out/b_x.log 2>&1 && python tools/probe/show.py $lib gpurun_out/b_x.log
+JPEGGPU_LIB=$PWD/jpeggpu_amd/lib/$lib.so timeout -k 10 200 python bench.py --steps 4 --warmup 1 --no-cpu --e2e-rounds 0 --latency-iters 30 --unique 4 --no-verify --other-configs 3 --photo-steps 2 --curve-iters 0 --shard-iters 0 $BENCH_ARGS > gpurun_out/b_x.log 2>&1 && python tools/probe/show.py $lib gpurun_out/b_x.log
 done; done
