@@ -70,8 +70,12 @@ constexpr int kDestuffWin   = 4096; // stuffed bytes handled by one destuff work
 ///   lut16 entry, indexed by the LB most significant bits of the 32-bit window:
 ///     bits  0..4  total symbol length = code length + magnitude bits, 1..31 (0 = code longer than LB bits)
 ///     bits  5..8  magnitude category s
-///     bits  9..15 zig-zag advance: run + 1 (1..16), or 64 for end-of-block (AC symbol with s == 0 and
-///                 run != 15): any advance that reaches index 64 closes the data unit; 1 in a DC table
+///     bits  9..14 zig-zag advance: run + 1 (1..16), or 63 for end-of-block (AC symbol with s == 0 and
+///                 run != 15): an advance that reaches index 63 or beyond closes the data unit; 1 in a DC table
+///     bit   15    only in the first level of an AC table of the WRITE pack (kEntrySlow): the lane cannot take this
+///                 entry in an ordinary step of the write pass's loop -- it has no length (second level / long code) or its
+///                 category takes an escape entry -- and waits for the rare slot; read as a signed 16-bit value the entry
+///                 is then negative, which is all the loop's step asks (jg_huff_core.h, decode_units)
 ///   an entry with bits 0..4 == 0 and a non-zero rest is indirect: (entry >> 5) - 1 is the index of a
 ///     second-level table sub16[k][32], indexed by the next 5 window bits, holding entries of the same
 ///     format (0 there, or a first-level 0, = take the long-code path below). The host allocates a
@@ -108,7 +112,7 @@ constexpr int kAcTableSize = (2 << kLutBitsAc) + kHuffAuxSize; // 4384, plus sec
 ///     bits 0..4   total length of ALL the symbols it stands for (every code with its magnitude bits lies inside
 ///                 the LB index bits)
 ///     bits 5..8   zig-zag advance of all but the last of them (at most 15)
-///     bits 9..15  zig-zag advance of all of them (an end-of-block, which can only be the last, counts 64)
+///     bits 9..15  zig-zag advance of all of them (an end-of-block, which can only be the last, counts 63)
 /// -- as many AC symbols as fit, decoded with this same table, which is right as long as the data unit does not end
 /// in front of the last of them: the symbol loop takes the high half unless index + advance of the earlier symbols
 /// reaches 64 (jg_huff_core.h). Where no second symbol fits the high half repeats the low one (its bits 5..8 are
@@ -129,6 +133,8 @@ constexpr uint32_t kMaxTablePackSync =
     kMaxComp * (kDcTableSizeSync + kMaxSubTables * kSubTableSize) + kMaxComp * (kAcTableSizeSync + kMaxSubTables * kSubTableSize) + kMaxDuPerMcu * 16;
 static_assert(kMaxTablePack < 65536 && kMaxTablePackSync < 65536, "table offsets are 16-bit");
 
+constexpr uint32_t kEobAdvance = 63u;   // advance field of an end-of-block
+constexpr uint32_t kEntrySlow  = 0x8000u;
 JG_HD inline uint32_t huff_entry(int codelen, uint32_t sym, bool is_dc)
 {
     // DC: sym is the category (hardened to 4 bits; valid baseline streams use 0..11).
@@ -136,7 +142,7 @@ JG_HD inline uint32_t huff_entry(int codelen, uint32_t sym, bool is_dc)
     const uint32_t s   = sym & 15u;
     const uint32_t r   = is_dc ? 0u : (sym >> 4);
     const bool eob = !is_dc && s == 0 && r != 15;
-    return (static_cast<uint32_t>(codelen) + s) | (s << 5) | ((eob ? 64u : r + 1u) << 9);
+    return (static_cast<uint32_t>(codelen) + s) | (s << 5) | ((eob ? kEobAdvance : r + 1u) << 9);
 }
 
 /// Layout of the destuffed buffer: TILES of 32 (or 16) subsequences, word-major inside a tile. The lanes

@@ -380,6 +380,49 @@ JG_HD inline uint32_t lut16_entry(TabPtr tab, uint32_t peek)
 #endif
 }
 
+/// First-level AC entry of the WRITE pack as a SIGNED 16-bit value: negative where the entry carries kEntrySlow (jg_defs.h).
+JG_HD inline int lut16_entry_signed(TabPtr tab, uint32_t peek)
+{
+#if defined(__HIP_DEVICE_COMPILE__) && defined(JG_TABS_IN_LDS)
+    uint32_t a;
+    asm("v_lshrrev_b32 %0, %1, %2\n\tv_lshl_add_u32 %0, %0, 1, %3"
+        : "=&v"(a)
+        : "n"(32 - kLutBitsAc), "v"(peek), "v"(static_cast<uint32_t>(reinterpret_cast<uintptr_t>(tab))));
+    return *reinterpret_cast<JG_TAB_AS const int16_t*>(static_cast<uintptr_t>(a)); // ds_read_i16
+#else
+    return *reinterpret_cast<JG_TAB_AS const int16_t*>(tab + 2 * (peek >> (32 - kLutBitsAc)));
+#endif
+}
+
+/// `e`, or 0 where `x` is negative: as a shift and a bit-field insert on the device (the compiler turns the C form back into
+/// compare + select, which costs the wave a wait state between the two on gfx950 and the vcc register).
+JG_HD inline uint32_t zero_if_negative(uint32_t e, int x)
+{
+#if defined(__HIP_DEVICE_COMPILE__)
+    uint32_t r;
+    asm("v_ashrrev_i32 %0, 31, %1\n\tv_bfi_b32 %0, %0, 0, %2" : "=&v"(r) : "v"(x), "v"(e));
+    return r;
+#else
+    return x < 0 ? 0u : e;
+#endif
+}
+
+/// EXTEND of the `s` bits that end `total` bits into the window (s == 0 gives 0). On the device: the field as a SIGNED
+/// bit-field t (negative where the magnitude's first bit is set: t = bits - 2^s), then t - ((2^s - 1) ^ (t >> 31)): bits
+/// for a set first bit, bits - (2^s - 1) for a clear one -- no compare, no select (a select behind a compare costs the
+/// wave a wait state on gfx950).
+JG_HD inline int extend_field(uint32_t peek, int total, int s)
+{
+#if defined(__HIP_DEVICE_COMPILE__)
+    const int t = __builtin_amdgcn_sbfe(static_cast<int>(peek), static_cast<uint32_t>(32 - total), static_cast<uint32_t>(s));
+    return t - static_cast<int>(bit_mask(s) ^ static_cast<uint32_t>(t >> 31));
+#else
+    const uint32_t bits = bits_field(peek, total, s);
+    const uint32_t mask = bit_mask(s);
+    return bits > (mask >> 1) ? static_cast<int>(bits) : static_cast<int>(bits - mask);
+#endif
+}
+
 /// T.81 F.2.2.1 EXTEND as extend_magnitude above, around bit_mask.
 JG_HD inline int extend_bits(uint32_t bits, int s)
 {
@@ -475,31 +518,27 @@ JG_HD inline void decode_units(
     static_assert((kRareBodies & (kRareBodies - 1)) == 0, "a power of two");
     flush_in = kFlushBodies; // bodies to the sink's next flush point
     // what the rare slot needs of the AC step in front of it
-    uint32_t peek = 0, e0 = 0;
-    int len0 = 0, cat0 = 0, ready = 0;
+    uint32_t peek = 0;
+    int e0 = 0, ready = 0; // the step's entry, signed (kEntrySlow is the sign); >= 0: the lane stands inside a unit with bits in its window
     uint32_t tab_off = 0;
     // AC step, every lane
     const auto ac_step = [&]() __attribute__((always_inline)) {
         peek             = w.look();
         tab_off          = actab;
         const TabPtr tab = JG_TAB_AT(tabs, actab);
-        e0               = lut16_entry<kLutBitsAc>(tab, peek);
-        len0             = e0 & 31;
-        cat0             = (e0 >> 5) & 15;
+        e0               = lut16_entry_signed(tab, peek);
         // No step for a lane outside a unit (zm >= 63) or with a window that ran out (the DC symbol just emptied it, or
-        // its refill has to wait an iteration): `ready`. None here for a symbol that is `slow` -- an entry without a
-        // length, a category with an escape entry, a window about to leave its row: the lane waits for the rare slot.
-        // The sign of one OR says so.
+        // its refill has to wait an iteration): `ready`. None here for an entry marked slow -- no length, or a category
+        // with an escape entry -- or with a window about to leave its row: the lane waits for the rare slot. The sign
+        // of one OR says so, and the entry is nulled by that sign (no compare, no select).
         ready            = (62 - zm) | w.left();
-        const int slow   = (len0 - 1) | (kEscapeFromCategory - 1 - cat0) | w.crossed();
-        const uint32_t e = (ready | slow) < 0 ? 0u : e0;
+        const uint32_t e = zero_if_negative(static_cast<uint32_t>(e0), ready | e0 | w.crossed());
         const int total  = e & 31;
         if (iters_out && e != 0) ++iters_out[1];
         w.skip(total);
         const int s = (e >> 5) & 15;
         zm += static_cast<int>(e >> 9); // index of the symbol's coefficient; 63 or more: the unit is complete
-        const int v = extend_bits(bits_field(peek, total, s), s);
-        sink.ac(s, zm, v);
+        sink.ac(s, zm, extend_field(peek, total, s));
     };
     int body = 0;
     for (int it = 0; it < max_iters; it += kWriteDcPeriod, ++body) {
@@ -547,7 +586,7 @@ JG_HD inline void decode_units(
         }
         if ((body & (kRareBodies - 1)) == kRareBodies - 1) { // rare slot: the same iterations for every lane of a wave
             // (zm and the window of a lane that waited are what they were: the null entry changed nothing)
-            const bool symbol = ready >= 0 && ((len0 - 1) | (kEscapeFromCategory - 1 - cat0)) < 0;
+            const bool symbol = ready >= 0 && e0 < 0;
             if (JG_WAVE_ANY(symbol || w.crossed() < 0)) {
                 if (iters_out) {
                     ++iters_out[2];
@@ -556,7 +595,8 @@ JG_HD inline void decode_units(
                 if (w.crossed() < 0) w.cross(); // the symbol in the window, if it was only this, goes with the next iteration
                 if (symbol) {
                     const TabPtr tab  = JG_TAB_AT(tabs, tab_off);
-                    const uint32_t e2 = len0 == 0 ? huff_second_level(tab, e0, peek, false) : e0;
+                    const uint32_t e1 = static_cast<uint32_t>(e0) & (kEntrySlow - 1u); // the entry without its mark
+                    const uint32_t e2 = (e1 & 31u) == 0 ? huff_second_level(tab, e1, peek, false) : e1;
                     const int total2  = e2 & 31;
                     if (iters_out) ++iters_out[1];
                     w.skip(total2);

@@ -180,7 +180,7 @@ void widen_huff_table(const std::vector<uint8_t>& t, bool is_dc, std::vector<uin
                 total_adv += adv;
                 bits += len;
                 ++count;
-                if (adv == 64u) break; // end of block: whatever follows belongs to the next data unit
+                if (adv == kEobAdvance) break; // end of block: whatever follows belongs to the next data unit
             }
             if (count >= 2) multi = bits | pre << 5 | total_adv << 9;
         }
@@ -452,7 +452,7 @@ jpeggpu_status Reader::read_sos(const Logger& log)
     // pack the tables in force for this scan, once in each form (jg_defs.h); components that select the same
     // table share it; the cursor ring sits behind the tables: one entry per data unit of the MCU
     const auto build_pack = [&](const std::vector<uint8_t> (&dc_tabs)[4], const std::vector<uint8_t> (&ac_tabs)[4],
-                                std::vector<uint8_t>& pack, uint32_t& cursor_off, uint32_t limit) -> bool {
+                                std::vector<uint8_t>& pack, uint32_t& cursor_off, uint32_t limit, bool write_pack) -> bool {
         uint32_t dc_off[kMaxComp], ac_off[kMaxComp];
         pack.clear();
         for (int a = 0; a < ns; ++a) {
@@ -473,6 +473,13 @@ jpeggpu_status Reader::read_sos(const Logger& log)
             } else {
                 ac_off[a] = static_cast<uint32_t>(pack.size());
                 pack.insert(pack.end(), ac_tabs[sc.ac_id].begin(), ac_tabs[sc.ac_id].end());
+                if (write_pack) {
+                    // first-level AC entries the write pass's ordinary step cannot take carry kEntrySlow (jg_defs.h): no
+                    // length (second level or long code), or a category with an escape entry
+                    uint16_t* lut = reinterpret_cast<uint16_t*>(pack.data() + ac_off[a]);
+                    for (uint32_t i = 0; i < (1u << kLutBitsAc); ++i)
+                        if ((lut[i] & 31u) == 0 || ((lut[i] >> 5) & 15u) >= static_cast<uint32_t>(kEscapeFromCategory)) lut[i] |= static_cast<uint16_t>(kEntrySlow);
+                }
             }
         }
         // 16-bit offsets in the ring, 16-bit LDS addresses on the device: cannot trip while the static_assert on
@@ -495,8 +502,8 @@ jpeggpu_status Reader::read_sos(const Logger& log)
         pack.insert(pack.end(), rb, rb + ring.size() * sizeof(CursorEntry));
         return true;
     };
-    if (!build_pack(dc_tab_, ac_tab_, scan.table_pack, scan.cursor_off, kMaxTablePack) ||
-        !build_pack(dc_tab_sync_, ac_tab_sync_, scan.table_pack_sync, scan.cursor_off_sync, kMaxTablePackSync))
+    if (!build_pack(dc_tab_, ac_tab_, scan.table_pack, scan.cursor_off, kMaxTablePack, true) ||
+        !build_pack(dc_tab_sync_, ac_tab_sync_, scan.table_pack_sync, scan.cursor_off_sync, kMaxTablePackSync, false))
         return JPEGGPU_INTERNAL_ERROR;
     const int total_mcus  = scan.mcus_x * scan.mcus_y;
     scan.mcus_per_segment = s.restart_interval ? s.restart_interval : total_mcus;

@@ -186,7 +186,7 @@ int emu_symbol_steps(const uint8_t* bits, const uint8_t* vals, int count, int is
         const int total = e & 31, s = (e >> 5) & 15, adv = static_cast<int>(e >> 9);
         length[i] = total;
         symbol[i] = s ? extend_bits(bits_field(peek, total, s), s) : 0;
-        run[i]    = dc ? 0 : s ? adv - 1 : adv == 64 ? 63 - z[i] : adv - 1; // an end of block advances to index 64 (jg_defs.h)
+        run[i]    = dc ? 0 : s ? adv - 1 : adv == static_cast<int>(kEobAdvance) ? 63 - z[i] : adv - 1; // an end of block's advance (jg_defs.h)
     }
     return 0;
 }
