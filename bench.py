@@ -1009,6 +1009,11 @@ def main():
             others[name] = {"file_bytes": len(blob), "p50_ms": r["p50"], "p99_ms": r["p99"], "p50_host_parse_ms": r["p50_host_parse"],
                             "max_ms": r["max"], "slowest_ms": r["slowest"], "iters": r["iters"], "subsequence_bytes": r["subsequence_bytes"],
                             "stage_us_device": r["stage_us_device"]}
+            if name.startswith("cfg2_geometry"):
+                # no restart markers: with the device scan the block list of the multi-hypothesis walk is the device's too (round 5)
+                r = latency_probe(args, torch, jp, blob, device, streams[0], device_scan=True)
+                others[name]["with_device_scan_enabled"] = {"p50_ms": r["p50"], "p99_ms": r["p99"], "p50_host_parse_ms": r["p50_host_parse"],
+                                                            "stage_us_device": r["stage_us_device"]}
             if name.startswith("config4"):
                 # three scans: jpeggpu_ext_set_device_scan hands the LAST scan of such a file to the device only if it is the
                 # bulk of the bytes; here it is a fifth, so the host walks all three (with the last one on the device, measured

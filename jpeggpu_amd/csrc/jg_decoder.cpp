@@ -78,6 +78,8 @@ struct ScanPlan {
     size_t mh_p = 0, mh_cz = 0, mh_link = 0, mh_pool = 0, mh_known = 0; // multi-hypothesis speculation (jg_defs.h), if mh > 1
     size_t blob_mh_blocks = 0, mh_blk_exit = 0, mh_blk_entry = 0;        // its block-wise chain walk, if mh_blocks is not empty
     std::vector<jg::MhBlock> mh_blocks;
+    int mh_blocks_device = 0;           // device-scanned scan without restart markers: capacity of the list jg_front.hip builds
+    size_t d_mh_blocks = 0;             //   ... and where it sits in d_tmp
     int mh = 0, max_seg_subseq = 0;
     int num_seq = 0;
     // device-side front end (jg_front.hip): tables built on the device, scratch, the job and the status word
@@ -188,13 +190,24 @@ void Decoder::make_plan()
         if (!batched && sc.du_per_mcu >= 2 && sc.du_per_mcu <= kMhMaxHyp && mh_enabled && run >= 2) {
             int longest = sc.device_walk ? kMhMaxSegSubseq : 0; // the device finds the segments: it falls back where one is longer
             for (const Segment& g : sc.segments) longest = std::max(longest, g.subseq_count);
-            if (sc.device_walk && s.restart_interval == 0) longest = kMhMaxSegSubseq + 1; // one segment of unknown length, tables on the device: no
+            // a device-scanned scan without restart markers is ONE segment whose length the host can only bound: the
+            // device builds the block list from what it finds (jg_front.hip, front_plan), sized here from the bound
+            const bool device_blocks = sc.device_walk && s.restart_interval == 0;
+            if (device_blocks) longest = std::max(sc.num_subseq, kMhMaxSegSubseq + 1);
             if (longest <= kMhMaxSegSubseq && run < 3 && sc.du_per_mcu < 4) longest = -1; // (runs of two: four units and more)
             if (longest > kMhMaxSegSubseq && run < 3) longest = -1;                       // (block-wise: runs of three and more)
+            sp.mh_blocks_device = 0;
             if (longest < 0) {
             } else if (longest <= kMhMaxSegSubseq) {
                 sp.mh             = sc.du_per_mcu;
                 sp.max_seg_subseq = longest;
+            } else if (device_blocks) {
+                const int nb = (sc.num_subseq + kMhMaxSegSubseq - 1) / kMhMaxSegSubseq;
+                if (nb <= kMhMaxBlocks) {
+                    sp.mh               = sc.du_per_mcu;
+                    sp.max_seg_subseq   = kMhMaxSegSubseq;
+                    sp.mh_blocks_device = nb;
+                }
             } else if (!sc.device_walk) {
                 for (const Segment& g : sc.segments) {
                     for (int r = 0; r < g.subseq_count; r += kMhMaxSegSubseq)
@@ -266,11 +279,16 @@ void Decoder::make_plan()
             o += align_up((1 + static_cast<size_t>(mh_pool_entries(static_cast<uint32_t>(S)))) * sizeof(uint2_t), 256);
             sp.mh_known = o;
             o += align_up(S, 256);
-            if (!sp.mh_blocks.empty()) {
+            const size_t nblocks = sp.mh_blocks_device ? static_cast<size_t>(sp.mh_blocks_device) : sp.mh_blocks.size();
+            if (nblocks) {
                 sp.mh_blk_exit = o;
-                o += align_up(sp.mh_blocks.size() * 64 * sizeof(uint16_t), 256);
+                o += align_up(nblocks * 64 * sizeof(uint16_t), 256);
                 sp.mh_blk_entry = o;
-                o += align_up(sp.mh_blocks.size() * sizeof(uint16_t), 256);
+                o += align_up(nblocks * sizeof(uint16_t), 256);
+            }
+            if (sp.mh_blocks_device) {
+                sp.d_mh_blocks = o;
+                o += align_up(nblocks * sizeof(MhBlock), 256);
             }
         }
         if (sc.device_walk) {
@@ -435,6 +453,10 @@ jpeggpu_status build_jobs(
         job.mh_known        = base + pl.mh_known;
         job.num_mh_blocks   = lone ? static_cast<int>(pl.mh_blocks.size()) : 0;
         job.mh_blocks       = job.num_mh_blocks ? reinterpret_cast<const MhBlock*>(blob + pl.blob_mh_blocks) : nullptr;
+        if (lone && pl.mh_blocks_device) { // the list the device builds (capacity here, the real count in its copy of the job)
+            job.num_mh_blocks = pl.mh_blocks_device;
+            job.mh_blocks     = reinterpret_cast<const MhBlock*>(base + pl.d_mh_blocks);
+        }
         job.mh_blk_exit     = reinterpret_cast<uint16_t*>(base + pl.mh_blk_exit);
         job.mh_blk_entry    = reinterpret_cast<uint16_t*>(base + pl.mh_blk_entry);
         IdctParams& ip = job.ip;
@@ -557,6 +579,8 @@ jg::FrontParams front_params(const Decoder& d, void* d_tmp, jg::ScanJob* d_job, 
     P.tail_parts = reinterpret_cast<int*>(base + pl.d_parts);
     P.job        = d_job;
     P.status     = u32(pl.d_status);
+    P.mh_blocks     = pl.mh_blocks_device ? reinterpret_cast<MhBlock*>(base + pl.d_mh_blocks) : nullptr;
+    P.max_mh_blocks = static_cast<uint32_t>(pl.mh_blocks_device);
     return P;
 }
 
@@ -897,7 +921,7 @@ enum jpeggpu_status jpeggpu_ext_get_layout(jpeggpu_decoder_t decoder, struct jpe
         o.symbol_region_entries = static_cast<int>(jg::sym_region_entries(d.subseq_bytes));
         o.device_scan           = sc.device_walk ? 1 : 0;
         o.hypotheses            = pl.mh;
-        o.hypothesis_blocks     = static_cast<int>(pl.mh_blocks.size());
+        o.hypothesis_blocks     = pl.mh_blocks_device ? pl.mh_blocks_device : static_cast<int>(pl.mh_blocks.size());
         if (sc.device_walk) {
             o.num_segments      = sc.expect_segments;
             o.num_chunks        = sc.max_chunks;

@@ -293,6 +293,7 @@ __global__ __launch_bounds__(PL) void front_plan(FS src)
             job->num_chunks        = 0;
             job->num_seq           = 0;
             job->num_tail_parts    = 0;
+            job->num_mh_blocks     = 0;
             job->sp.num_subseq     = 0;
             job->sp.num_segments   = 0;
             job->ip.num_du         = 0;
@@ -323,7 +324,7 @@ __global__ __launch_bounds__(PL) void front_plan(FS src)
     if (__syncthreads_or(too_big) || any_empty) {
         if (tid == 0) {
             JG_GLOBAL ScanJob* job = as_global(P.job);
-            job->num_chunks = job->num_seq = job->num_tail_parts = 0;
+            job->num_chunks = job->num_seq = job->num_tail_parts = job->num_mh_blocks = 0;
             job->sp.num_subseq = job->sp.num_segments = 0;
             job->ip.num_du = 0;
             stat[0] = any_empty ? 2 : 4; // JPEGGPU_INVALID_JPEG / JPEGGPU_NOT_SUPPORTED
@@ -383,10 +384,30 @@ __global__ __launch_bounds__(PL) void front_plan(FS src)
     }
     if (nparts >= P.max_parts) nparts = P.max_parts - 1;
     __syncthreads();
+    // blocks of the multi-hypothesis chain walk (a scan without restart markers: ONE segment of S subsequences, which the
+    // host could only bound): block b = subsequences [b * kMhMaxSegSubseq, ...), the first one opens the segment
+    uint32_t mh_nb = 0;
+    if (P.mh_blocks != nullptr && E == 1) {
+        mh_nb = (S + kMhMaxSegSubseq - 1) / kMhMaxSegSubseq;
+        if (mh_nb > P.max_mh_blocks) mh_nb = 0; // (cannot happen while S <= max_subseq: the plan sized the list from that bound)
+        for (uint32_t b = tid; b < mh_nb; b += PL) {
+            MhBlock blk;
+            blk.first   = static_cast<int>(b * kMhMaxSegSubseq);
+            blk.count   = static_cast<int>(S - b * kMhMaxSegSubseq < static_cast<uint32_t>(kMhMaxSegSubseq) ? S - b * kMhMaxSegSubseq : kMhMaxSegSubseq);
+            blk.seg_end = static_cast<int>(S);
+            blk.opens   = b == 0 ? 1 : 0;
+            typedef uint32_t V4 __attribute__((ext_vector_type(4)));
+            *reinterpret_cast<JG_GLOBAL V4*>(as_global(P.mh_blocks) + b) = __builtin_bit_cast(V4, blk);
+        }
+    }
     if (tid == 0) {
         parts[nparts]          = static_cast<int>(S);
         JG_GLOBAL ScanJob* job = as_global(P.job);
         const bool fits        = S <= P.max_subseq && C <= P.max_chunks;
+        if (P.mh_blocks != nullptr) {
+            job->num_mh_blocks = fits ? static_cast<int>(mh_nb) : 0;
+            if (!fits || mh_nb == 0) job->sp.mh = 0; // no list: the sequence kernel speculates plainly
+        }
         job->num_chunks        = fits ? static_cast<int>(C) : 0;
         const uint32_t seq     = static_cast<uint32_t>(job->sp.seq_subseq); // per job: a lone decode's sequences or a batch's (jg_defs.h)
         job->num_seq           = fits ? static_cast<int>((S + seq - 1) / seq) : 0;

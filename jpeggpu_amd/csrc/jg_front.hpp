@@ -31,6 +31,8 @@ struct FrontParams {
     Segment* segments;         // [expect_segments]          out
     DestuffChunk* chunks;      // [max_chunks]               out
     int* tail_parts;           // [max_parts]                out
+    MhBlock* mh_blocks;        // [max_mh_blocks] out, or null: blocks of the multi-hypothesis chain walk of a scan WITHOUT restart
+    uint32_t max_mh_blocks;    //   markers (one segment: blocks of kMhMaxSegSubseq subsequences, jg_defs.h)
     ScanJob* job;              // the scan's job in device memory: counts are filled in
     uint32_t* status;          // [8]: jpeggpu_status, subsequences, segments, chunks, tail parts, -, first FF FF 00, terminator ordinal
 };

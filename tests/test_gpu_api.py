@@ -749,6 +749,16 @@ def test_block_wise_multi_hypothesis_walk_without_restart_markers(torch_cuda, mo
             assert sc.hypothesis_blocks >= (sc.num_subsequences + 1023) // 1024 > 1, (name, sb, sc.hypothesis_blocks)
             for c in range(ref.ncomp):
                 assert np.array_equal(planes[c].cpu().numpy(), ref.planes[c]), (name, sb, c)
+        if name.endswith("nodri"):
+            # the same with the device-side marker scan (round 5): the scan is one segment whose length only the device
+            # knows -- it builds the block list itself (jg_front.hip, front_plan), the host sizes it from the header's bound
+            for sb in (0, 32):
+                planes, _, _tmp, _base, lay = jpeggpu_amd.decode_to_planes(data, subseq_bytes=sb, return_tmp=True, device_scan=True)
+                sc = lay.scans[0]
+                assert sc.device_scan == 1 and sc.hypotheses == 6, (name, sb, sc.hypotheses)
+                assert sc.hypothesis_blocks >= (sc.num_subsequences + 1023) // 1024 > 1, (name, sb, sc.hypothesis_blocks)
+                for c in range(ref.ncomp):
+                    assert np.array_equal(planes[c].cpu().numpy(), ref.planes[c]), (name, sb, c, "device scan")
     # BASELINE configs[4] -- runs of two data units with the same tables, no restart markers -- synchronises faster without
     # (measured, jg_decoder.cpp make_plan): the library does not apply the speculation there
     planes, _, _tmp, _base, lay = jpeggpu_amd.decode_to_planes(jpegsynth.config(5, small=True), return_tmp=True)

@@ -243,8 +243,9 @@ def test_subsequence_size_is_chosen_per_image(L, photo_bytes, monkeypatch):
 def test_multi_hypothesis_applies_to_lone_decodes_of_interleaved_restart_scans(L, photo_bytes, monkeypatch):
     """jpeggpu_ext_scan_layout.hypotheses (jg_defs.h, multi-hypothesis speculation): one candidate per data unit of the
     MCU for an image decoded on its own (device-scanned or not; a scan without restart markers, or with segments of more
-    than 1024 subsequences, walks its chain block-wise: hypothesis_blocks); not for batches, single-unit MCUs,
-    device-scanned images without restart markers, or when the environment switches it off."""
+    than 1024 subsequences, walks its chain block-wise: hypothesis_blocks -- for a device-scanned scan without restart
+    markers from a list the device builds, sized from the header's bound); not for batches, single-unit MCUs, or when
+    the environment switches it off."""
     m = cases.matrix()
 
     def hyp(data, batched=False, device_scan=False):
@@ -267,7 +268,8 @@ def test_multi_hypothesis_applies_to_lone_decodes_of_interleaved_restart_scans(L
     assert hyp(m["gray"]) == [0]
     assert hyp(m["cfg5_small"]) == [6] and blocks == [0]       # no restart markers, one short segment: walked whole
     assert hyp(m["multi_seq_nodri"]) == [6] and subseq[0] > 2048 and blocks == [(subseq[0] + 1023) // 1024]  # one long segment
-    assert hyp(m["multi_seq_nodri"], device_scan=True) == [0]  # the device finds the segments: no block list
+    # the device finds the one segment's length: the block list is its work (round 5), its capacity comes from the bound
+    assert hyp(m["multi_seq_nodri"], device_scan=True) == [6] and blocks == [(subseq[0] + 1023) // 1024] and blocks[0] > 1
     assert hyp(m["ni_420_dri"]) == [0, 0, 0]          # one data unit per MCU in every scan
     assert hyp(m["dri_7"]) == [6]
     monkeypatch.setenv("JPEGGPU_MULTI_HYPOTHESIS", "0")
