@@ -1478,7 +1478,10 @@ __global__ __launch_bounds__(TL) void huff_sync_tail(JS js)
             // that makes this iteration's state stores visible to the next one)
             int rank;
             const int total = block_rank<TL>(flowing, s_wave, rank);
-            JG_TAIL_STAMP(2 + trips, static_cast<uint32_t>(wall_clock64()));
+            if (trips < 30) {
+                JG_TAIL_STAMP(2 + trips, static_cast<uint32_t>(wall_clock64()));
+                JG_TAIL_STAMP(32 + trips, static_cast<uint32_t>(__syncthreads_count(live))); // flows of the trip
+            }
             ++trips;
             if (total == 0) break;
             if (flowing) {

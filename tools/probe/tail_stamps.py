@@ -49,7 +49,7 @@ used = b[:, 63] != 0
 flows, trips = b[used, 63] & 0xFFFF, b[used, 63] >> 16
 b = b[used]
 t0 = b[:, 0].min()
-end = np.array([r[2 + min(int(t), 60) - 1] for r, t in zip(b, trips)])
+end = np.array([r[2 + min(int(t), 30) - 1] for r, t in zip(b, trips)])
 print("tail stage %.0f us (sync_intra %.0f, write %.0f) | %d parts sampled" % (us["sync_inter"], us["sync_intra"], us["write"], used.sum()))
 print("flows per part: median %d, max %d | loop trips per part: median %d, p90 %d, max %d" % (np.median(flows), flows.max(), np.median(trips), np.percentile(trips, 90), trips.max()))
 print("start spread %.1f us | list building: median %.1f us | part lifetime: median %.1f, p90 %.1f, max %.1f us | last end - first start %.1f us" % (
@@ -57,10 +57,18 @@ print("start spread %.1f us | list building: median %.1f us | part lifetime: med
     (end - b[:, 0]).max() / 100.0, (end.max() - t0) / 100.0))
 per = []
 for r, t in zip(b, trips):
-    k = min(int(t), 60)
+    k = min(int(t), 30)
     per.extend(((r[2:2 + k] - r[1:1 + k]) / 100.0).tolist())
 per = np.array(per)
 print("one trip of the flow loop: median %.1f us, p90 %.1f us, max %.1f us (%d trips)" % (np.median(per), np.percentile(per, 90), per.max(), per.size))
 worst = int(np.argmax(end - b[:, 0]))
-k = min(int(trips[worst]), 60)
-print("slowest part: %d flows, %d trips, trips (us):" % (flows[worst], trips[worst]), np.round((b[worst, 2:2 + k] - b[worst, 1:1 + k]) / 100.0, 1).tolist())
+k = min(int(trips[worst]), 30)
+print("slowest part: %d flows, %d trips, trips (us):" % (flows[worst], trips[worst]), np.round((b[worst, 2:2 + k] - b[worst, 1:1 + k]) / 100.0, 1).tolist(),
+      "flows per trip:", b[worst, 32:32 + k].tolist())
+# time per trip by the number of flows in it (a trip of at most one flow per wave is decoded by the wave: wave_decode_subsequence)
+by = {}
+for r, t in zip(b, trips):
+    k = min(int(t), 30)
+    for d, f in zip(((r[2:2 + k] - r[1:1 + k]) / 100.0).tolist(), r[32:32 + k].tolist()):
+        by.setdefault("1-4" if f <= 4 else "5-16" if f <= 16 else "17-64" if f <= 64 else ">64", []).append(d)
+print("trip time by flows in the trip:", {k2: (len(v), round(float(np.median(v)), 1)) for k2, v in sorted(by.items())})
