@@ -10,6 +10,16 @@ LIB_PATH = os.path.join(LIB_DIR, "libjpeggpu.so")
 SOURCES = ["jg_kernels.hip", "jg_front.hip", "jg_decoder.cpp", "jg_reader.cpp"]
 
 
+def _mode_path(lib_path):
+    return lib_path + ".mode"
+
+
+def _wanted_mode():
+    """What the environment asks of a build: the refill's wait (JPEGGPU_SAFE_REFILL) and whether the check of the generated code
+    runs (JPEGGPU_SKIP_BUILD_CHECK). Recorded beside the library so that changing either rebuilds it."""
+    return "safe_refill=%s skip_check=%s" % (os.environ.get("JPEGGPU_SAFE_REFILL") == "1", os.environ.get("JPEGGPU_SKIP_BUILD_CHECK") == "1")
+
+
 def _stale() -> bool:
     if not os.path.exists(LIB_PATH):
         return True
@@ -17,7 +27,13 @@ def _stale() -> bool:
     # every source and header under csrc/ (a header missing from a hand-kept list once left a stale library)
     deps = [os.path.join(CSRC, f) for f in os.listdir(CSRC) if f.endswith((".h", ".hpp", ".hip", ".cpp"))]
     deps += [os.path.join(ROOT, "include", "jpeggpu", h) for h in ("jpeggpu.h", "jpeggpu_ext.h")]
-    return any(os.path.getmtime(d) > t for d in deps)
+    if any(os.path.getmtime(d) > t for d in deps):
+        return True
+    try:  # built under other settings of the environment: a fast-refill library must not outlive a request for the safe one
+        with open(_mode_path(LIB_PATH)) as f:
+            return f.read().split("|")[0].strip() != _wanted_mode()
+    except OSError:
+        return os.environ.get("JPEGGPU_SAFE_REFILL") == "1" or os.environ.get("JPEGGPU_SKIP_BUILD_CHECK") == "1"
 
 
 def build(force: bool = False, verbose: bool = False, out: str = None, extra_flags=()) -> str:
@@ -55,7 +71,12 @@ def device_assembly(extra_flags=(), verbose=False):
         cmd = _base_cmd(extra_flags) + ["--offload-device-only", "-S", os.path.join(CSRC, "jg_kernels.hip"), "-o", asm]
         if verbose:
             print(" ".join(cmd))
-        subprocess.check_call(cmd, stderr=subprocess.DEVNULL)
+        r = subprocess.run(cmd, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True)
+        if r.returncode != 0:  # the compiler's own words, not a bare CalledProcessError
+            import sys
+
+            sys.stderr.write(r.stderr)
+            raise subprocess.CalledProcessError(r.returncode, cmd, r.stdout, r.stderr)
         return open(asm).read().split("\n")
 
 
@@ -150,6 +171,8 @@ def _compile(lib_path, verbose, extra_flags):
     if verbose:
         print(" ".join(cmd))
     subprocess.check_call(cmd)
+    with open(_mode_path(lib_path), "w") as f:  # what the library was built as: `_stale` compares it with the environment
+        f.write("%s | refill: %s\n" % (_wanted_mode(), "vmcnt(0), safe" if "-DJG_SAFE_REFILL" in extra_flags else "vmcnt(1), checked"))
     return lib_path
 
 

@@ -18,6 +18,7 @@
 
 #include <hip/hip_runtime.h>
 
+#include <cstdio>
 #include <cstdlib>
 #include <algorithm>
 #include <atomic>
@@ -694,7 +695,11 @@ enum jpeggpu_status jpeggpu_decoder_startup(jpeggpu_decoder_t* decoder)
         // asynchronous and a refused scan shows as untouched planes. (Round 3 made "1" the asynchronous mode; a caller who
         // had set it for round 2's checked mode lost the error reporting without notice: ADVICE r3.)
         const int v = std::atoi(e);
+        const bool off = std::strcmp(e, "0") == 0 || std::strcmp(e, "off") == 0 || e[0] == 0;
         (*decoder)->d.device_scan = std::strcmp(e, "async") == 0 ? 1 : (v == 1 || v == 2 || std::strcmp(e, "checked") == 0) ? 2 : 0;
+        // a value nobody recognises must not silently mean "off" (ADVICE r4); the mode in force is logged at parse_header
+        if ((*decoder)->d.device_scan == 0 && !off)
+            std::fprintf(stderr, "jpeggpu: JPEGGPU_DEVICE_SCAN=\"%s\" is not one of 0, off, 1, 2, checked, async: the device scan stays off\n", e);
     }
     return JPEGGPU_SUCCESS;
 }
@@ -731,6 +736,9 @@ enum jpeggpu_status jpeggpu_decoder_parse_header(
     }
     if (st != JPEGGPU_SUCCESS) return st;
     const jg::Stream& s = d.reader.s;
+    if (d.device_scan)
+        d.logger.log("device-side marker scan: %s (jpeggpu_ext_set_device_scan / JPEGGPU_DEVICE_SCAN)\n",
+                     d.device_scan == 2 ? "checked -- jpeggpu_decoder_decode waits for the stream and returns the device's status" : "asynchronous");
     std::memset(img_info, 0, sizeof(*img_info));
     img_info->num_components = s.num_comp;
     for (int c = 0; c < s.num_comp; ++c) {
