@@ -673,9 +673,11 @@ def roofline_report(args, slot, stage_us, images_per_launch, entries, value, wor
             "own_GBs": ab[k] * images_per_launch / (us * 1e-6) / 1e9 if us > 0 else None,
             "own_frac_of_hbm_peak": ab[k] * images_per_launch / (us * 1e-6) / 1e9 / HBM_PEAK_GBS if us > 0 else None,
             "traffic_bytes_per_launch": t * images_per_launch if t else None,
-            # (4 cycles per instruction is the model's price; simple additions and shifts measure 2.1-2.6, so a kernel made of
-            # them can come out above 1: capped)
-            "valu_issue_util": min(1.0, valu * VALU_CYCLES / (SIMDS * SHADER_HZ * us * 1e-6)) if valu and us > 0 else None,
+            # RAW value of the 4-cycle model (SQ_INSTS_VALU x 4 cycles over the SIMD-cycles of this duration): simple additions
+            # and shifts issue in 2.1-2.6 cycles (profiles/r04_valu_issue_cost_by_instruction.txt), so the model overestimates
+            # and a kernel made of them can come out above 1; `issue_counters` below need no model
+            "valu_issue_util": valu * VALU_CYCLES / (SIMDS * SHADER_HZ * us * 1e-6) if valu and us > 0 else None,
+            "valu_issue_util_note": "4-cycle model, overestimates simple two-operand instructions (measured 2.1-2.6 cycles); not capped",
             # ratios of counters of the SAME unit (per wave-resident cycle), from the committed profile, not from this run
             "issue_counters": counter_ratios(c)}
     in_pass = [k for k in stages if k in PASS_STAGES]
@@ -687,7 +689,11 @@ def roofline_report(args, slot, stage_us, images_per_launch, entries, value, wor
     if t_pass_us > 0:
         achieved = bytes_per_launch / (t_pass_us * 1e-6) / 1e9
         roofline = {
-            "bound": "hbm", "limiter": "valu-issue",
+            "bound": "hbm",
+            # by the counter ratios, not by the model: a wave of the pass has an instruction in issue or execution in about 0.3 of
+            # its resident cycles and waits for an instruction's operands in 0.2 (issue_counters); vector instructions are 70 % of
+            # what it issues
+            "limiter": "instruction issue (vector 70 %, scalar 26 %, LDS / memory 4 % of the instructions; profiles/pmc_counters.json)",
             "kernel": "destuff+Huffman pass: " + " + ".join(KERNEL_NAMES[k] for k in in_pass),
             "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
             "traffic": sum(pass_traffic) if all(pass_traffic) else None,
@@ -707,6 +713,16 @@ def roofline_report(args, slot, stage_us, images_per_launch, entries, value, wor
                     "(valu_issue_util: SQ_INSTS_VALU of profiles/pmc_counters.json x 4 cycles / (1024 SIMDs x 2.4 GHz x this time))",
             "measured": "HIP events on the launch stream, %d serialized launches of %d images, one stream"
                         % (args.roofline_launches, images_per_launch)}
+    if roofline is not None:
+        # the counter-derived figures belong to the committed profile's run: say how its durations compare with this run's
+        prof_us = [traffic.get(KERNEL_NAMES[k].split("+")[0], {}).get("profile_avg_us") for k in in_pass]
+        if all(prof_us):
+            ratio = t_pass_us / sum(prof_us)
+            roofline["profile_pass_us"] = sum(prof_us)
+            roofline["run_over_profile_duration"] = ratio
+            if abs(ratio - 1.0) > 0.03:
+                roofline["traffic_source"] += ("; NOTE: this run's pass took %.0f us, the profile's %.0f us (%+.1f %%): traffic, valu_issue_util and "
+                                               "issue_counters are the profile's and are NOT rescaled" % (t_pass_us, sum(prof_us), 100.0 * (ratio - 1.0)))
     e2e = {"bytes_per_image": ab["b_e2e"], "throughput_GBs": ab["b_e2e"] * value / world / 1e9,
            "frac_of_hbm_peak": ab["b_e2e"] * value / world / 1e9 / HBM_PEAK_GBS}
     return roofline, kernels, e2e, ab

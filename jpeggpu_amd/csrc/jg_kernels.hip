@@ -749,6 +749,8 @@ __global__ __launch_bounds__(T) void huff_sync_intra(JS js)
     // speculative pass (and with the multi-hypothesis table) it also does so if j opens a restart segment -- from the
     // segment's start state, which is known, not guessed -- so that every subsequence gets its n and DC sums from a
     // decode that started in a real state; otherwise the speculative pass of such a j was already exact.
+    // (huff_sync_tail relies on this: whichever way, a segment's first subsequence ends up decoded from the segment's start
+    // state -- here by the flow of the lane in front of it, else by its own speculative pass, which started there)
     const bool covers_starts = JS::kSpeculateStateOnly || mh;
     bool flowing = covers_starts ? t + 1 < img_end && img_first + t + 1 >= 0 : active;
     int lim      = 0; // flows stay below this lane index: end of the segment or of the image
@@ -1407,6 +1409,12 @@ __global__ __launch_bounds__(TL) void huff_sync_tail(JS js)
     // TL subsequences: 48 000 subsequences of a 12 MP scan without restart markers are ONE part, and building its list took
     // 60 of the kernel's 70 us.)
     // (ScanParams::tail_marks: set by build_jobs beside max_intra_iters -- up to round 4 this kernel inferred it from the cap)
+    // CONTRACT with the sequence kernels (huff_sync_intra / huff_sync_intra_batch), which nothing else states:
+    //   * tail_marks == 0: every flow was followed to its end inside its sequence's workgroup; only a flow that would cross
+    //     into the next sequence is left, and bnd_p / bnd_cz say what that sequence's workgroup assumed in its place;
+    //   * tail_marks != 0: `pending[i]` is set for every entry i a flow was cut short at;
+    //   * either way a subsequence that OPENS a segment was decoded from the segment's start state (the flow pass's
+    //     `covers_starts`, or an exact speculative pass): no flow below ever enters a segment from the one in front of it.
     const bool marks = sp.tail_marks != 0;
     const int SEQ    = sp.seq_subseq;
     const int step   = marks ? 1 : SEQ;

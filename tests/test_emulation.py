@@ -8,7 +8,7 @@ from tests import cases
 from tests.emu import emu
 
 
-@pytest.mark.parametrize("subseq_bytes,max_intra_iters", [(128, 256), (64, 256), (32, 256), (256, 1), (128, 3), (32, 1), (64, 2)])
+@pytest.mark.parametrize("subseq_bytes,max_intra_iters", [(128, 256), (64, 256), (32, 256), (256, 1), (128, 3), (32, 1), (64, 2), (64, 255)])
 def test_emulated_pipeline_equals_sequential_decode(subseq_bytes, max_intra_iters):
     """max_intra_iters < 256 cuts the lock-step loop of the sequence kernel short and hands the
     unfinished flows to the tail pass (1: only the first flow iteration runs in the sequence kernel)."""

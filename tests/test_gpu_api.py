@@ -234,9 +234,12 @@ def test_batch_decode_equals_single(torch_cuda):
     batch = jpeggpu_amd.Batch(total_scans)
     scratch = torch.empty(batch.scratch_size, dtype=torch.uint8, device="cuda:0")
     batch.set_items(entries)
-    for rep, iters in enumerate([3, 1, 2, 256]):  # cap of the sequence kernel's lock-step loop (>= 1)
+    # cap of the sequence kernel's lock-step loop (>= 1); 255 / 256: one below and at the lane count -- a caller's cap always
+    # leaves marks for the tail kernel (ScanParams::tail_marks), however high it is (the kernel used to infer
+    # "no marks" from the cap)
+    for rep, iters in enumerate([3, 1, 2, 256, 255]):
         batch.set_sync_iterations(iters)
-        batch.set_overlap(1 + rep)  # 1..4 concurrent parts on internal streams
+        batch.set_overlap(1 + rep % 4)  # 1..4 concurrent parts on internal streams
         for _, _, planes in keep:
             for p in planes:
                 p.fill_(0xCD)

@@ -84,6 +84,14 @@ def main():
         print("%-18s fetch %10.0f KiB  write %10.0f KiB  -> %7.2f MB/image   VALU %.2f M/image" % (
             name, fetch, write, per / 1e6, v.get("SQ_INSTS_VALU", 0.0) / IMAGES_PER_LAUNCH / 1e6))
     print("total %.1f MB/image" % (total / 1e6))
+    # the serialized run's own kernel durations (rocprofv3 --kernel-trace --stats of the same command): bench.py compares its
+    # in-run durations with these and says so when they differ (the counter-derived figures are THIS profile's, not the run's)
+    stats = os.path.join(prof, "%s_kernel_stats_serialized.csv" % rnd)
+    if os.path.exists(stats):
+        for r in csv.DictReader(open(stats)):
+            m = re.search(KERNELS, r["Name"])
+            if m and "JobArray" in r["Name"] and m.group(1) in traffic:
+                traffic[m.group(1)]["profile_avg_us"] = float(r["AverageNs"]) / 1e3
     json.dump(traffic, open(os.path.join(prof, "pmc_traffic.json"), "w"), indent=1)
     json.dump(traffic, open(os.path.join(prof, "%s_pmc_traffic_batch64.json" % rnd), "w"), indent=1)
     json.dump({k: v for k, v in sorted(merged.items())}, open(os.path.join(prof, "%s_pmc_counters_batch64.json" % rnd), "w"), indent=1)
