@@ -12,13 +12,13 @@ set -e
 rnd=$1
 root=${GRAFT_REPO_ROOT:-$(pwd)}
 out=$root/gpurun_out
-ser="--steps 1 --warmup 1 --batch 64 --rounds 2 --streams 1 --unique 4 --no-cpu --no-verify --latency-iters 0 --other-configs 0 --e2e-rounds 0 --roofline-launches 8"
+ser="--steps 1 --warmup 1 --batch 64 --rounds 2 --streams 1 --unique 4 --no-cpu --no-verify --latency-iters 0 --other-configs 0 --e2e-rounds 0 --curve-iters 0 --shard-iters 0 --roofline-launches 8"
 cd /tmp && export TMPDIR=/tmp
 timeout -k 10 500 python3 "$root/bench.py" > "$out/${rnd}_bench_default.json" 2> "$out/${rnd}_bench_default.err"
 echo "bench done"
 rm -rf "$out/${rnd}_stats_default" "$out/${rnd}_stats_serialized"
 timeout -k 10 300 rocprofv3 --kernel-trace --stats -d "$out/${rnd}_stats_default" -o bench --output-format csv -- \
-    python3 "$root/bench.py" --steps 5 --warmup 2 --no-cpu --e2e-rounds 0 --other-configs 0 > "$out/${rnd}_stats_default.json" 2> "$out/${rnd}_stats_default.err"
+    python3 "$root/bench.py" --steps 5 --warmup 2 --no-cpu --e2e-rounds 0 --other-configs 0 --curve-iters 0 --shard-iters 0 > "$out/${rnd}_stats_default.json" 2> "$out/${rnd}_stats_default.err"
 echo "stats default done"
 timeout -k 10 300 rocprofv3 --kernel-trace --stats -d "$out/${rnd}_stats_serialized" -o bench --output-format csv -- \
     python3 "$root/bench.py" $ser > "$out/${rnd}_stats_serialized.json" 2> "$out/${rnd}_stats_serialized.err"
