@@ -42,7 +42,10 @@ def main():
                                     fill_bytes=int(rng.choice([0, 0, 0, 1, 3])), seed=int(rng.integers(1 << 30)),
                                     qmax=int(rng.choice([0, 0, 255, 65535])))
             ref = oracle.decode(data)
-            dec = jp.Decoder(sb)
+            # half of the decoders get a fixed subsequence size, the others what the library picks for the images per call
+            # they are told to expect (jpeggpu_ext_set_batch_hint, round 5: 0 / 1 = the lone decode's plan)
+            dec = jp.Decoder(sb if rng.random() < 0.5 else None)
+            dec.set_batch_hint(int(rng.choice([0, 1, 2, 8, 20, 64])))
             dec.set_device_scan(bool(rng.integers(2)))  # batches mix host-walked and device-scanned images
             info = dec.parse_header(data)
             n = dec.get_buffer_size()
@@ -58,7 +61,8 @@ def main():
         batch = jp.Batch(total_scans)
         scratch = torch.empty(batch.scratch_size, dtype=torch.uint8, device="cuda:0")
         batch.set_items(items)
-        batch.set_sync_iterations(int(rng.choice([1, 1, 2, 5, 256])))
+        if rng.random() < 0.5:  # a caller's cap (marks + tail kernel); else the library's choice: these calls are small, so
+            batch.set_sync_iterations(int(rng.choice([1, 1, 2, 5, 255, 256])))  # every flow stays in the sequence kernel
         batch.set_overlap(int(rng.integers(1, 5)))
         batch.decode(scratch.data_ptr(), 0)
         torch.cuda.synchronize()
