@@ -971,6 +971,24 @@ def main():
             stage_us, images_per_launch = serialized_stage_us(args, bset)
             entries = slots[0].stream_entries(torch)
             roofline, kernels, e2e, ab = roofline_report(args, slots[0], stage_us, images_per_launch, entries, value, world)
+            # the same pass in ONE call over the rank's whole batch (256 images): what larger launches are worth -- the tail
+            # kernel's latency and the last, partly filled round of workgroups are spread over four times the images
+            # (`frac` stays the 64-image figure of every round so far: BASELINE configs[2] is a batch of 64)
+            if roofline is not None and len(slots) > images_per_launch:
+                bt = jp.Batch(sum(s.layout.num_scans for s in slots))
+                scratch = torch.empty(bt.scratch_size, dtype=torch.uint8, device=device)
+                bt.set_items([(s.dec, s.ptrs, s.pitches, s.base, s.tmp_size) for s in slots])
+                bt.set_profiling(True)
+                for _ in range(3):
+                    bt.decode(scratch.data_ptr(), streams[0].cuda_stream)
+                    streams[0].synchronize()
+                us_all = {k: v * 1e3 for k, v in bt.stage_ms().items()}
+                bt.destroy()
+                t_all = sum(v for k, v in us_all.items() if k in PASS_STAGES and (k != "front" or bool(slots[0].layout.scans[0].device_scan)))
+                roofline["by_images_per_launch"] = {
+                    str(images_per_launch): {"pass_us": roofline["avg_launch_us"], "frac": roofline["frac"]},
+                    str(len(slots)): {"pass_us": t_all, "frac": ab["b_dh"] * len(slots) / (t_all * 1e-6) / 1e9 / HBM_PEAK_GBS if t_all > 0 else None,
+                                      "stage_us": us_all}}
         photo = args.workload == "photo"
         out = {
             "metric": "images/s, 12 MP 4:2:0 baseline JPEG decode, inputs resident in HBM "

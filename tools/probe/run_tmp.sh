@@ -1,5 +1,5 @@
 mkdir -p gpurun_out
-echo "== keep flows, cfg2 256/128 at 16..64"; JPEGGPU_EXP_KEEP_FLOWS_BELOW=1000000000 timeout -k 10 300 python tools/probe/batch_curve.py --images 16,24,32,48,64 --sizes 128,256 2>&1 | grep -v amdgpu.ids
-echo "== marks, cfg2"; JPEGGPU_EXP_KEEP_FLOWS_BELOW=0 timeout -k 10 300 python tools/probe/batch_curve.py --images 16,24,32,48,64 --sizes 128,256 2>&1 | grep -v amdgpu.ids
-echo "== keep flows, photo"; JPEGGPU_EXP_KEEP_FLOWS_BELOW=1000000000 timeout -k 10 300 python tools/probe/batch_curve.py --workload photo --images 16,32,64 --sizes 128,256 2>&1 | grep -v amdgpu.ids
-echo "== marks, photo"; JPEGGPU_EXP_KEEP_FLOWS_BELOW=0 timeout -k 10 300 python tools/probe/batch_curve.py --workload photo --images 16,32,64 --sizes 128,256 2>&1 | grep -v amdgpu.ids
+C="--no-cpu --e2e-rounds 0 --latency-iters 0 --no-verify --other-configs 0 --curve-iters 0 --shard-iters 0"
+for args in "--steps 4 --warmup 1 --unique 4" "--steps 4 --warmup 1 --unique 16" "--steps 20 --warmup 5 --unique 4" "--steps 20 --warmup 5 --unique 16" "--steps 4 --warmup 1 --unique 4"; do
+  timeout -k 10 200 python bench.py $C $args > gpurun_out/b_x.log 2>&1 && python tools/probe/show.py "[$args]" gpurun_out/b_x.log | tail -1
+done
