@@ -685,6 +685,13 @@ def roofline_report(args, slot, stage_us, images_per_launch, entries, value, wor
     pass_traffic = [kernels[KERNEL_NAMES[k]]["traffic_bytes_per_launch"] for k in in_pass]
     pass_valu = [counters.get(KERNEL_NAMES[k].split("+")[0], {}).get("SQ_INSTS_VALU") for k in in_pass]
     bytes_per_launch = ab["b_dh"] * images_per_launch
+    # instruction mix of the pass from the committed counters (vector / scalar / LDS + memory)
+    mix = {k: sum(counters.get(KERNEL_NAMES[st].split("+")[0], {}).get(k, 0.0) for st in in_pass)
+           for k in ("SQ_INSTS_VALU", "SQ_INSTS_SALU", "SQ_INSTS_LDS", "SQ_INSTS_VMEM_RD", "SQ_INSTS_VMEM_WR")}
+    tot = sum(mix.values())
+    limiter = "instruction issue" if not tot else ("instruction issue (vector %.0f %%, scalar %.0f %%, LDS / memory %.0f %% of the pass's instructions; "
+                                                   "profiles/pmc_counters.json)" % (100 * mix["SQ_INSTS_VALU"] / tot, 100 * mix["SQ_INSTS_SALU"] / tot,
+                                                                                  100 * (tot - mix["SQ_INSTS_VALU"] - mix["SQ_INSTS_SALU"]) / tot))
     roofline = None
     if t_pass_us > 0:
         achieved = bytes_per_launch / (t_pass_us * 1e-6) / 1e9
@@ -693,7 +700,7 @@ def roofline_report(args, slot, stage_us, images_per_launch, entries, value, wor
             # by the counter ratios, not by the model: a wave of the pass has an instruction in issue or execution in about 0.3 of
             # its resident cycles and waits for an instruction's operands in 0.2 (issue_counters); vector instructions are 70 % of
             # what it issues
-            "limiter": "instruction issue (vector 70 %, scalar 26 %, LDS / memory 4 % of the instructions; profiles/pmc_counters.json)",
+            "limiter": limiter,
             "kernel": "destuff+Huffman pass: " + " + ".join(KERNEL_NAMES[k] for k in in_pass),
             "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
             "traffic": sum(pass_traffic) if all(pass_traffic) else None,
