@@ -169,7 +169,12 @@ enum jpeggpu_status jpeggpu_ext_get_stage_ms(jpeggpu_decoder_t decoder, float* m
  * subsequence sizes are launched as one group per size. `d_scratch` is caller-owned device memory of at least
  * jpeggpu_ext_batch_scratch_size(total number of scans) bytes (job descriptors and front-end parameters),
  * private to the stream. The batch handle owns page-locked host staging only: a ring of FOUR staging buffers for
- * the job descriptors. Like jpeggpu_decoder_decode the call only enqueues -- with one exception: the fifth call in
+ * the job descriptors. What a call launches follows from what it holds (round 5): a call of ONE image whose decoder was
+ * planned for lone decodes (the default, or jpeggpu_ext_set_batch_hint(decoder, 0 or 1)) is decoded as
+ * jpeggpu_decoder_decode would decode it -- multi-hypothesis speculation included, never blocking --; a call of fewer
+ * than 220 000 subsequences (about nineteen 12 MP images at 256 bytes) keeps every synchronisation flow in its sequence
+ * kernel, as a lone decode does; a larger one runs one flow iteration there and the rest in the tail kernel.
+ * Like jpeggpu_decoder_decode the call only enqueues -- with one exception: the fifth call in
  * a row on one handle waits (hipEventSynchronize) until the copy of the first one has executed, i.e. the host can
  * run at most four batch calls ahead of the device per handle. */
 struct jpeggpu_batch;

@@ -600,7 +600,9 @@ jpeggpu_status read_device_status(Decoder& d, const void* d_tmp, hipStream_t str
     return JPEGGPU_SUCCESS;
 }
 
-jpeggpu_status do_decode(Decoder& d, jpeggpu_img* img, void* d_tmp, size_t tmp_size, hipStream_t stream)
+/// `may_block`: the checked mode of the device scan may wait for the stream (jpeggpu_decoder_decode); an item of a batch is
+/// never waited for (jpeggpu_ext.h).
+jpeggpu_status do_decode(Decoder& d, jpeggpu_img* img, void* d_tmp, size_t tmp_size, hipStream_t stream, bool may_block = true)
 {
     using namespace jg;
     d.jobs.clear();
@@ -630,7 +632,7 @@ jpeggpu_status do_decode(Decoder& d, jpeggpu_img* img, void* d_tmp, size_t tmp_s
             JG_CHECK_HIP(launch_stage_device_job(static_cast<Stage>(stage), d_job, extent, stream));
             d.mark(stage, stream);
         }
-        if (d.device_scan == 2) {
+        if (d.device_scan == 2 && may_block) {
             // Checked mode (JPEGGPU_DEVICE_SCAN=1 / 2 / checked in the environment of a caller that knows only the drop-in API):
             // what the host walk would have reported from parse_header is known on the device only now. Wait for
             // it and return it, as such a caller cannot ask for it; nothing of the device-walked scan was written to the
@@ -1083,12 +1085,12 @@ static enum jpeggpu_status decode_batch_impl(
     // A call of one or two images planned as lone decodes (jpeggpu_ext_set_batch_hint): decoded one by one with the lone
     // decode's kernels, multi-hypothesis speculation included -- the chip is empty either way.
     {
-        bool all_lone = num_items <= jg::kLonePlanImages;
+        // (with the batch's stage timing on, the call takes the batch's kernels: its events sit between THOSE launches)
+        bool all_lone = num_items <= jg::kLonePlanImages && !batch->profiling;
         for (int i = 0; i < num_items && all_lone; ++i) all_lone = !items[i].decoder->d.batched;
         if (all_lone) {
-            if (batch->profiling) return JPEGGPU_INVALID_ARGUMENT; // stage timing of such calls: jpeggpu_ext_set_profiling of the decoders
             for (int i = 0; i < num_items; ++i) {
-                const jpeggpu_status st = do_decode(items[i].decoder->d, items[i].img, items[i].d_tmp, items[i].tmp_size, stream);
+                const jpeggpu_status st = do_decode(items[i].decoder->d, items[i].img, items[i].d_tmp, items[i].tmp_size, stream, false);
                 if (st != JPEGGPU_SUCCESS) return st;
             }
             return JPEGGPU_SUCCESS;

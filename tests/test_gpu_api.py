@@ -286,6 +286,8 @@ def test_small_batches_with_the_plans_the_library_picks(torch_cuda, images, monk
             dec = jpeggpu_amd.Decoder()
             if i % 3 != 2:
                 dec.set_batch_hint(images)  # (every third decoder keeps the lone plan: any decoder may go into any call)
+            if images == 1 and mode == "marks":
+                dec.set_device_scan(2)  # the checked mode blocks jpeggpu_decoder_decode only: an item of a batch is never waited for
             info = dec.parse_header(d)
             n, tmp, base, planes = _alloc(torch, dec, info)
             dec.transfer(base, n, 0)
@@ -307,6 +309,7 @@ def test_small_batches_with_the_plans_the_library_picks(torch_cuda, images, monk
             batch.decode(scratch.data_ptr(), 0)
             torch.cuda.synchronize()
             for i, (ref, (dec, _, planes)) in enumerate(zip(refs, keep)):
+                assert dec.device_status(entries[i][3], 0) == jpeggpu_amd.Status.SUCCESS
                 for c in range(ref.ncomp):
                     assert np.array_equal(planes[c].cpu().numpy(), ref.planes[c]), (images, mode, i, c, rep)
         # what the call used: a small call keeps its flows in the sequence kernel (240 + 16 lanes), a full one does not
