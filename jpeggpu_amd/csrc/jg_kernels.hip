@@ -1365,6 +1365,46 @@ __global__ __launch_bounds__(256) void huff_mh_resolve(JS js)
 #endif
 constexpr int kTailLanesSmall = JG_TAIL_LANES_SMALL, kTailLanesLarge = 1024, kTailLargeFrom = JG_TAIL_LARGE_FROM;
 
+/// tails[b] (huff_seq_tails below: the sums of n and of the DC differences over the subsequences of sequence b that belong
+/// to the segment still open at b's end) for the sequences whose LAST subsequence lies in [lo, hi): a part is a run of whole
+/// segments, so everything such a sequence sums lies inside the part, whose states are final when its workgroup is done.
+/// Folded into the tail kernel's workgroups (round 5): one launch and its gap fewer in every decode -- 8 of a lone 12 MP
+/// decode's 245 us. Only for the 256-lane kernel: a part of a scan without restart markers holds hundreds of sequences,
+/// which huff_seq_tails sums side by side.
+template <int TL>
+__device__ __forceinline__ void part_seq_tails(const JobView& J, int lo, int hi, uint32_t* s_red)
+{
+    static_assert(TL == T, "one sequence per round of the workgroup's lanes");
+    const int SEQ = J.sp.seq_subseq, S = J.sp.num_subseq, t = threadIdx.x;
+    for (int b = lo / SEQ; b * SEQ < S; ++b) {
+        const int first = b * SEQ, last = min(first + SEQ, S) - 1;
+        if (last < lo) continue; // (cannot happen: b starts at the sequence that holds lo)
+        if (last >= hi) break;   // the sequence ends in a later part
+        const int open_from = ld_global(J.segments + J.seg_idx[last]).subseq_offset;
+        const int sub       = first + t;
+        const bool take     = sub <= last && sub >= open_from;
+        uint32_t n = take ? static_cast<uint32_t>(J.st_n[sub]) : 0u, d01 = take ? J.st_dc01[sub] : 0u, d23 = take ? J.st_dc23[sub] : 0u;
+#pragma unroll
+        for (int d = 32; d > 0; d >>= 1) {
+            n += __shfl_down(n, d);
+            d01 = pk_add_u16(d01, __shfl_down(d01, d));
+            d23 = pk_add_u16(d23, __shfl_down(d23, d));
+        }
+        __syncthreads(); // (the previous round's sums have been read)
+        if (lane_id() == 0) {
+            s_red[(t >> 6) * 3 + 0] = n;
+            s_red[(t >> 6) * 3 + 1] = d01;
+            s_red[(t >> 6) * 3 + 2] = d23;
+        }
+        __syncthreads();
+        if (t == 0) {
+            J.tails_n[b]    = static_cast<int>(s_red[0] + s_red[3] + s_red[6] + s_red[9]);
+            J.tails_dc01[b] = pk_add_u16(pk_add_u16(s_red[1], s_red[4]), pk_add_u16(s_red[7], s_red[10]));
+            J.tails_dc23[b] = pk_add_u16(pk_add_u16(s_red[2], s_red[5]), pk_add_u16(s_red[8], s_red[11]));
+        }
+    }
+}
+
 /// Continues, from global state, every flow that huff_sync_intra could not finish: one flow per
 /// sequence boundary (carry the exit state of the last subsequence of sequence b-1 into sequence b,
 /// b+1, ... until it meets the stored state or the segment ends) and one per pending mark. A flow
@@ -1386,6 +1426,8 @@ __global__ __launch_bounds__(TL) void huff_sync_tail(JS js)
 {
     extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
     __shared__ int s_wave[TL / 64];
+    __shared__ uint32_t s_red[12];
+    constexpr bool kFusedTails = TL == T; // (the 1024-lane kernel of large parts leaves the sequence tails to huff_seq_tails)
     int* s_j       = reinterpret_cast<int*>(smem); // next subsequence of a surviving flow
     int* s_pz      = s_j + TL;                     // its bit position
     int* s_cz      = s_pz + TL;                    // its c | z << 8
@@ -1434,7 +1476,10 @@ __global__ __launch_bounds__(TL) void huff_sync_tail(JS js)
         if (f) J.flow_list[lo + count + rank] = sub;
         count += total;
     }
-    if (count == 0) return; // (uniform) most parts of a batch: nothing crosses a sequence boundary unconfirmed
+    if (count == 0) { // (uniform) most parts of a lone decode: nothing crosses a sequence boundary unconfirmed
+        if constexpr (kFusedTails) part_seq_tails<TL>(J, lo, hi, s_red);
+        return;
+    }
     load_tables(s_tab, J.tables_sync, sp);
     __syncthreads(); // list and tables visible to the whole workgroup
     JG_TAIL_STAMP(1, static_cast<uint32_t>(wall_clock64()));
@@ -1508,6 +1553,10 @@ __global__ __launch_bounds__(TL) void huff_sync_tail(JS js)
         __syncthreads();
     }
     JG_TAIL_STAMP(63, static_cast<uint32_t>(count) | static_cast<uint32_t>(trips) << 16);
+    if constexpr (kFusedTails) {
+        __syncthreads(); // every flow's stores are done and visible to the workgroup
+        part_seq_tails<TL>(J, lo, hi, s_red);
+    }
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -2456,7 +2505,9 @@ hipError_t launch_any(Stage stage, const JS& js, const JobExtent& e, int grid_y,
         destuff_kernel<JS><<<dim3((e.max_chunks + kDestuffChunksPerWg - 1) / kDestuffChunksPerWg, grid_y), 256, 0, stream>>>(js);
         return hipGetLastError();
     case kStageTails:
-        if (e.max_seq == 0) return hipSuccess;
+        // (folded into the tail kernel's 256-lane workgroups: part_seq_tails; parts of scans without restart markers run the
+        // 1024-lane kernel and keep this launch)
+        if (e.max_seq == 0 || (e.max_tail_parts > 0 && e.max_tail_part < kTailLargeFrom)) return hipSuccess;
         huff_seq_tails<JS><<<dim3(e.max_seq, grid_y), T, 0, stream>>>(js);
         return hipGetLastError();
     case kStageIdct:
