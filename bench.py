@@ -661,10 +661,20 @@ def roofline_report(args, slot, stage_us, images_per_launch, entries, value, wor
     stages = [k for k in stage_us if k != "front" or device_scan]  # without the device scan "front" is a 24-us descriptor copy, not a kernel
     traffic = committed_profile("pmc_traffic.json")
     counters = committed_profile("pmc_counters.json")
+    # huff_tail_write (round 5): the tail kernel's parts and the write pass's sequences as one launch, reported under "write";
+    # "sync_inter" and "tails" then hold only the gaps between their events (no kernel: not listed below, but counted in the pass)
+    fused = os.environ.get("JPEGGPU_FUSE_TAIL_WRITE", "1") != "0" and stage_us.get("sync_inter", 1e9) < 15.0
+    names = dict(KERNEL_NAMES)
+    if fused:
+        names["write"] = "huff_tail_write"
+        ab = dict(ab)
+        ab["write"] = ab["write"] + ab["sync_inter"]
     kernels = {}
     for k in stages:
+        if fused and k in ("sync_inter", "tails"):
+            continue
         us = stage_us[k]
-        name = KERNEL_NAMES[k]
+        name = names[k]
         t = traffic.get(name.split("+")[0], {}).get("per_image_bytes")
         valu = counters.get(name.split("+")[0], {}).get("SQ_INSTS_VALU")
         c = counters.get(name.split("+")[0], {})
@@ -680,13 +690,14 @@ def roofline_report(args, slot, stage_us, images_per_launch, entries, value, wor
             "valu_issue_util_note": "4-cycle model, overestimates simple two-operand instructions (measured 2.1-2.6 cycles); not capped",
             # ratios of counters of the SAME unit (per wave-resident cycle), from the committed profile, not from this run
             "issue_counters": counter_ratios(c)}
-    in_pass = [k for k in stages if k in PASS_STAGES]
-    t_pass_us = sum(stage_us[k] for k in in_pass)
-    pass_traffic = [kernels[KERNEL_NAMES[k]]["traffic_bytes_per_launch"] for k in in_pass]
-    pass_valu = [counters.get(KERNEL_NAMES[k].split("+")[0], {}).get("SQ_INSTS_VALU") for k in in_pass]
+    all_pass = [k for k in stages if k in PASS_STAGES]
+    in_pass = [k for k in all_pass if names[k] in kernels]  # the stages that launch a kernel
+    t_pass_us = sum(stage_us[k] for k in all_pass)
+    pass_traffic = [kernels[names[k]]["traffic_bytes_per_launch"] for k in in_pass]
+    pass_valu = [counters.get(names[k].split("+")[0], {}).get("SQ_INSTS_VALU") for k in in_pass]
     bytes_per_launch = ab["b_dh"] * images_per_launch
     # instruction mix of the pass from the committed counters (vector / scalar / LDS + memory)
-    mix = {k: sum(counters.get(KERNEL_NAMES[st].split("+")[0], {}).get(k, 0.0) for st in in_pass)
+    mix = {k: sum(counters.get(names[st].split("+")[0], {}).get(k, 0.0) for st in in_pass)
            for k in ("SQ_INSTS_VALU", "SQ_INSTS_SALU", "SQ_INSTS_LDS", "SQ_INSTS_VMEM_RD", "SQ_INSTS_VMEM_WR")}
     tot = sum(mix.values())
     limiter = "instruction issue" if not tot else ("instruction issue (vector %.0f %%, scalar %.0f %%, LDS / memory %.0f %% of the pass's instructions; "
@@ -701,14 +712,14 @@ def roofline_report(args, slot, stage_us, images_per_launch, entries, value, wor
             # its resident cycles and waits for an instruction's operands in 0.2 (issue_counters); vector instructions are 70 % of
             # what it issues
             "limiter": limiter,
-            "kernel": "destuff+Huffman pass: " + " + ".join(KERNEL_NAMES[k] for k in in_pass),
+            "kernel": "destuff+Huffman pass: " + " + ".join(names[k] for k in in_pass),
             "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
             "traffic": sum(pass_traffic) if all(pass_traffic) else None,
             "traffic_source": "profiles/pmc_traffic.json: rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes over serialized launches of "
                               "the same shape in ANOTHER process of the same tree (counters cannot be read from inside this one), "
                               "per-shape calibration of profiles/*_fetch_calibration.json; valu_issue_util and issue_counters come "
                               "from profiles/pmc_counters.json the same way -- only the durations are measured in this run",
-            "issue_counters": counter_ratios({k: sum(counters.get(KERNEL_NAMES[s].split("+")[0], {}).get(k, 0.0) for s in in_pass)
+            "issue_counters": counter_ratios({k: sum(counters.get(names[s].split("+")[0], {}).get(k, 0.0) for s in in_pass)
                                              for k in ("SQ_WAVE_CYCLES", "SQ_ACTIVE_INST_ANY", "SQ_WAIT_ANY", "SQ_WAIT_INST_ANY", "SQ_INSTS_VALU",
                                                        "SQ_INSTS_SALU", "SQ_INSTS_LDS", "SQ_BUSY_CYCLES")}),
             "algorithmic_bytes_per_launch": bytes_per_launch, "algorithmic_bytes_per_image": ab["b_dh"],
@@ -722,7 +733,7 @@ def roofline_report(args, slot, stage_us, images_per_launch, entries, value, wor
                         % (args.roofline_launches, images_per_launch)}
     if roofline is not None:
         # the counter-derived figures belong to the committed profile's run: say how its durations compare with this run's
-        prof_us = [traffic.get(KERNEL_NAMES[k].split("+")[0], {}).get("profile_avg_us") for k in in_pass]
+        prof_us = [traffic.get(names[k].split("+")[0], {}).get("profile_avg_us") for k in in_pass]
         if all(prof_us):
             ratio = t_pass_us / sum(prof_us)
             roofline["profile_pass_us"] = sum(prof_us)

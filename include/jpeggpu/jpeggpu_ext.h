@@ -207,6 +207,16 @@ enum jpeggpu_status jpeggpu_ext_batch_set_sync_iterations(jpeggpu_batch_t batch,
  * 2-3 parts). A caller that already keeps several streams busy gains nothing. Stage timing then reports
  * part 0. */
 enum jpeggpu_status jpeggpu_ext_batch_set_overlap(jpeggpu_batch_t batch, int parts);
+/* A call that fills the chip (what jpeggpu_ext_decode_batch launches is described above) runs the parts of the
+ * synchronisation's tail and the sequences of the write pass as ONE launch, huff_tail_write: the sequences of parts
+ * that are done are written while the slow parts still run (default on, or the environment's JPEGGPU_FUSE_TAIL_WRITE=0
+ * when the batch is created; off: the two kernels one after the other, as up to round 4). Stage timing then reports
+ * the launch under "write" and nothing under "sync_inter". Not taken with a caller's cap of the sequence kernel's
+ * iterations (jpeggpu_ext_batch_set_sync_iterations), nor by calls of more than 256 scans. */
+enum jpeggpu_status jpeggpu_ext_batch_set_fused_tail(jpeggpu_batch_t batch, int enable);
+/* Writers of huff_tail_write that gave up waiting for a sequence to become ready, since the library was loaded (their
+ * wait is bounded so that a defect cannot hang the GPU; 0 on every correct run: tests and the soak assert it). */
+enum jpeggpu_status jpeggpu_ext_fused_tail_timeouts(unsigned int* count);
 /* Stage timing of batched decodes; same contract as jpeggpu_ext_set_profiling / _get_stage_ms. */
 enum jpeggpu_status jpeggpu_ext_batch_set_profiling(jpeggpu_batch_t batch, int enable);
 enum jpeggpu_status jpeggpu_ext_batch_get_stage_ms(jpeggpu_batch_t batch, float* ms /* [JPEGGPU_EXT_NUM_STAGES] */);

@@ -11,6 +11,7 @@ from .api import (  # noqa: F401
     JpegGpuError,
     Status,
     decode_to_planes,
+    fused_tail_timeouts,
     lib,
     parse_headers,
     self_test,

@@ -123,6 +123,9 @@ def lib():
     L.jpeggpu_ext_batch_set_profiling.argtypes = [C.c_void_p, C.c_int]
     L.jpeggpu_ext_batch_set_sync_iterations.argtypes = [C.c_void_p, C.c_int]
     L.jpeggpu_ext_batch_set_overlap.argtypes = [C.c_void_p, C.c_int]
+    if hasattr(L, "jpeggpu_ext_batch_set_fused_tail"):  # (experimental builds of older trees, JPEGGPU_LIB, lack it)
+        L.jpeggpu_ext_batch_set_fused_tail.argtypes = [C.c_void_p, C.c_int]
+        L.jpeggpu_ext_fused_tail_timeouts.argtypes = [C.POINTER(C.c_uint)]
     L.jpeggpu_ext_batch_get_stage_ms.argtypes = [C.c_void_p, C.POINTER(C.c_float)]
     L.jpeggpu_ext_upsample_planes.argtypes = [
         C.POINTER(ImgInfo), C.POINTER(Img), C.POINTER(Img), C.c_int, C.c_int, C.c_void_p]
@@ -297,6 +300,9 @@ class Batch:
     def set_overlap(self, parts: int):
         _check(lib().jpeggpu_ext_batch_set_overlap(self._h, parts), "jpeggpu_ext_batch_set_overlap")
 
+    def set_fused_tail(self, enable: bool):
+        _check(lib().jpeggpu_ext_batch_set_fused_tail(self._h, 1 if enable else 0), "jpeggpu_ext_batch_set_fused_tail")
+
     def set_sync_iterations(self, n: int):
         _check(lib().jpeggpu_ext_batch_set_sync_iterations(self._h, n), "jpeggpu_ext_batch_set_sync_iterations")
 
@@ -318,6 +324,13 @@ class Batch:
             self.destroy()
         except Exception:
             pass
+
+
+def fused_tail_timeouts() -> int:
+    """Writers of the fused tail + write launch that gave up waiting, since the library was loaded (0 on a correct run)."""
+    n = C.c_uint(0)
+    _check(lib().jpeggpu_ext_fused_tail_timeouts(C.byref(n)), "jpeggpu_ext_fused_tail_timeouts")
+    return n.value
 
 
 def self_test(stream: int = 0) -> None:

@@ -56,7 +56,7 @@ def check_refill(extra_flags=(), verbose=False):
     """The write pass refills its bit window from inline assembly and waits for all but the most recent load
     (jg_kernels.hip, RowWindow: `s_waitcnt vmcnt(1)`). That is only right if the compiler never touches the register the
     loads target while one is in flight -- which it does not know. So the generated code is checked, for every
-    instantiation of huff_write: no scratch memory, no spilled registers, and between the loop's first refill block and
+    instantiation of huff_write and huff_tail_write: no scratch memory, no spilled registers, and between the loop's first refill block and
     the `s_waitcnt vmcnt(0)` of RowWindow::done() no instruction outside the hand-written assembly blocks names that
     register. Returns a list of problems (empty: fine)."""
     return check_refill_text(device_assembly(extra_flags, verbose))
@@ -86,13 +86,13 @@ def check_refill_text(text):
 
     problems, seen = [], 0
     for k, ln in enumerate(text):  # the code object's metadata: spill counts per kernel
-        if ".name:" in ln and "huff_write" in ln:
+        if ".name:" in ln and ("huff_write" in ln or "huff_tail_write" in ln):
             for x in text[k:k + 14]:
                 if ("spill_count" in x or ".private_segment_fixed_size" in x) and not x.strip().endswith(" 0"):
                     problems.append("%s: %s" % (ln.split(".name:")[1].strip(), x.strip()))
     i = 0
     while i < len(text):
-        m = re.match(r"^(_ZN2jg\S*huff_write\S*):", text[i])
+        m = re.match(r"^(_ZN2jg\S*huff_(?:tail_)?write\S*):", text[i])
         if not m:
             i += 1
             continue
@@ -133,12 +133,79 @@ def check_refill_text(text):
             problems.append("%s: the refill blocks load into %s" % (name, sorted(regs)))
             continue
         reg = int(regs.pop()[1:])
-        lo, hi = refills[0][0], max(b for _, b in dones)
+        # Where may a load into that register be in flight? On the paths from a refill block to the next refill or to done():
+        # the body as a graph of straight-line pieces (cut at labels, behind branches and around the assembly blocks), the
+        # pieces reachable FROM a refill block that also REACH a refill or a done() block. (By position in the text -- from
+        # the first refill to the last done() -- the check took in code the compiler had laid out in between without it
+        # lying on any such path: the other role of huff_tail_write.)
+        cuts = {0, len(body)}
+        for a, b in blocks:
+            cuts.add(a)
+            cuts.add(b + 1)
+        label_at = {}
+        for k, ln in enumerate(body):
+            mm = re.match(r"^(\.LBB\S+):", ln)
+            if mm:
+                cuts.add(k)
+                label_at[mm.group(1)] = k
+            op = ln.split(";")[0].split()
+            if op and ln.startswith("\t") and (op[0].startswith("s_cbranch") or op[0] in ("s_branch", "s_endpgm", "s_setpc_b64")):
+                cuts.add(k + 1)
+        starts = sorted(c for c in cuts if c < len(body))
+        node_of = {}
+        for n, st in enumerate(starts):
+            for k in range(st, starts[n + 1] if n + 1 < len(starts) else len(body)):
+                node_of[k] = n
+        succ = [set() for _ in starts]
+        for n, st in enumerate(starts):
+            en = starts[n + 1] if n + 1 < len(starts) else len(body)
+            last = None
+            for k in range(st, en):
+                op = body[k].split(";")[0].split()
+                if op and body[k].startswith("\t") and not op[0].startswith("."):
+                    last = op
+            falls = True
+            if last and (last[0].startswith("s_cbranch") or last[0] == "s_branch"):
+                tgt = last[1].rstrip(",") if len(last) > 1 else ""
+                if tgt in label_at:
+                    succ[n].add(node_of[label_at[tgt]])
+                else:
+                    problems.append("%s: branch to an unknown label: %s" % (name, " ".join(last)))
+                falls = last[0] != "s_branch"
+            elif last and last[0] in ("s_endpgm", "s_setpc_b64"):
+                falls = last[0] != "s_endpgm"
+                if last[0] == "s_setpc_b64":
+                    problems.append("%s: an indirect branch inside the kernel" % name)
+            if falls and n + 1 < len(starts):
+                succ[n].add(n + 1)
+        pred = [set() for _ in starts]
+        for n, ss in enumerate(succ):
+            for m in ss:
+                pred[m].add(n)
+
+        def closure(seeds, edges, stop=()):
+            seen_n, todo = set(), list(seeds)
+            while todo:
+                x = todo.pop()
+                for y in edges[x]:
+                    if y not in seen_n:
+                        seen_n.add(y)
+                        if y not in stop:
+                            todo.append(y)
+            return seen_n
+
+        refill_nodes = {node_of[a] for a, _ in refills}
+        done_nodes = {node_of[a] for a, _ in dones}
+        # (forwards no further than a done() block: behind it nothing is in flight -- the structured exit of one role of
+        # huff_tail_write leads, on paper, into the other's code)
+        zone = closure(refill_nodes, succ, done_nodes) & (closure(refill_nodes | done_nodes, pred) | refill_nodes | done_nodes)
         in_asm = [False] * len(body)
         for a, b in blocks:
             for k in range(a, b + 1):
                 in_asm[k] = True
-        for k in range(lo, hi + 1):
+        for k in range(len(body)):
+            if node_of[k] not in zone:
+                continue
             ln = body[k].split(";")[0]
             if in_asm[k] or not ln.startswith("\t") or ln.strip().startswith("."):
                 continue

@@ -74,7 +74,7 @@ struct ScanPlan {
     size_t blob_tables = 0, blob_tables_sync = 0, blob_segments = 0, blob_chunks = 0, blob_parts = 0;
     // offsets inside d_tmp
     size_t destuffed = 0, seg_idx = 0, st_p = 0, st_n = 0, st_cz = 0, st_dc01 = 0, st_dc23 = 0;
-    size_t tails_n = 0, tails_dc01 = 0, tails_dc23 = 0, pending = 0, flow_list = 0, bnd_p = 0, bnd_cz = 0;
+    size_t tails_n = 0, tails_dc01 = 0, tails_dc23 = 0, pending = 0, flow_list = 0, bnd_p = 0, bnd_cz = 0, fuse_ctl = 0;
     size_t sym = 0, du_tab = 0;
     size_t mh_p = 0, mh_cz = 0, mh_link = 0, mh_pool = 0, mh_known = 0; // multi-hypothesis speculation (jg_defs.h), if mh > 1
     size_t blob_mh_blocks = 0, mh_blk_exit = 0, mh_blk_entry = 0;        // its block-wise chain walk, if mh_blocks is not empty
@@ -268,6 +268,8 @@ void Decoder::make_plan()
         o += align_up(static_cast<size_t>(sp.num_seq) * 4, 256);
         sp.bnd_cz = o;
         o += align_up(static_cast<size_t>(sp.num_seq) * 4, 256);
+        sp.fuse_ctl = o; // control words of huff_tail_write
+        o += align_up(fuse_ctl_words(static_cast<size_t>(sp.num_seq)) * 4, 256);
         if (sp.mh > 1) { // multi-hypothesis speculation (decided with the blob, above)
             const size_t N = S * static_cast<size_t>(sp.mh);
             sp.mh_p        = o;
@@ -510,6 +512,7 @@ jpeggpu_status build_jobs(
         job.tail_parts = reinterpret_cast<const int*>(blob + pl.blob_parts);
         job.num_tail_parts = static_cast<int>(sc.tail_parts.size()) - 1;
         job.max_tail_part  = 0;
+        job.fuse_ctl       = reinterpret_cast<uint32_t*>(base + pl.fuse_ctl);
         for (size_t k = 0; k + 1 < sc.tail_parts.size(); ++k)
             job.max_tail_part = std::max(job.max_tail_part, sc.tail_parts[k + 1] - sc.tail_parts[k]);
         job.tails_n    = reinterpret_cast<int*>(base + pl.tails_n);
@@ -974,6 +977,8 @@ struct jpeggpu_batch {
     bool sync_iters_set         = false; // jpeggpu_ext_batch_set_sync_iterations was called: the caller's cap, whatever the call's size
     // Calls of fewer subsequences than this keep every flow in the sequence kernel (decode_batch_impl).
     long long keep_flows_below  = jg::kKeepFlowsBelowSubseq;
+    // Full batches: the tail kernel's parts and the write pass's sequences as one launch (jg_kernels.hip: huff_tail_write).
+    bool fuse_tail_write        = true;
     // A caller with ONE stream leaves the GPU idle while the latency-bound tail kernel runs (a fifth of a
     // batch's time). With overlap > 1 the jobs are split into that many parts, part 0 on the caller's
     // stream and the others on internal streams forked from and joined back into it with events.
@@ -1007,6 +1012,7 @@ enum jpeggpu_status jpeggpu_ext_batch_create(jpeggpu_batch_t* batch, int max_sca
     if (!b) return JPEGGPU_OUT_OF_HOST_MEMORY;
     b->max_jobs = max_scans;
     if (const char* e = std::getenv("JPEGGPU_EXP_KEEP_FLOWS_BELOW")) b->keep_flows_below = std::atoll(e); // experiments (tools/probe/batch_curve.py)
+    if (const char* e = std::getenv("JPEGGPU_FUSE_TAIL_WRITE")) b->fuse_tail_write = std::atoi(e) != 0;
     for (int r = 0; r < jpeggpu_batch::kRing; ++r) {
         void* p = nullptr;
         if (hipHostMalloc(&p, jpeggpu_ext_batch_scratch_size(max_scans), hipHostMallocDefault) != hipSuccess ||
@@ -1191,6 +1197,7 @@ static enum jpeggpu_status decode_batch_impl(
             Part p{a + static_cast<int>(static_cast<long long>(b - a) * w / gw), a + static_cast<int>(static_cast<long long>(b - a) * (w + 1) / gw), w, jg::JobExtent{}};
             for (int j = p.begin; j < p.end; ++j) jg::extend(p.extent, batch->jobs[static_cast<size_t>(j)]);
             p.extent.repack_flows = keep_flows;
+            p.extent.fuse_tail_write = batch->fuse_tail_write && !batch->sync_iters_set;
             if (p.end > p.begin) parts.push_back(p);
         }
     }
@@ -1216,6 +1223,19 @@ enum jpeggpu_status jpeggpu_ext_batch_set_overlap(jpeggpu_batch_t batch, int par
     if (!batch || parts < 1 || parts > jpeggpu_batch::kMaxOverlap) return JPEGGPU_INVALID_ARGUMENT;
     batch->overlap = parts;
     return JPEGGPU_SUCCESS;
+}
+
+enum jpeggpu_status jpeggpu_ext_batch_set_fused_tail(jpeggpu_batch_t batch, int enable)
+{
+    if (!batch) return JPEGGPU_INVALID_ARGUMENT;
+    batch->fuse_tail_write = enable != 0;
+    return JPEGGPU_SUCCESS;
+}
+
+enum jpeggpu_status jpeggpu_ext_fused_tail_timeouts(unsigned int* count)
+{
+    if (!count) return JPEGGPU_INVALID_ARGUMENT;
+    return jg::read_fuse_timeouts(count) == hipSuccess ? JPEGGPU_SUCCESS : JPEGGPU_INTERNAL_ERROR;
 }
 
 enum jpeggpu_status jpeggpu_ext_batch_set_sync_iterations(jpeggpu_batch_t batch, int iterations)

@@ -6,6 +6,7 @@
 #ifndef JG_DEFS_H_
 #define JG_DEFS_H_
 
+#include <stddef.h>
 #include <stdint.h>
 
 #if defined(__HIPCC__)
@@ -344,6 +345,9 @@ struct MhBlock {
 };
 constexpr uint32_t kMhNoLink   = 0;
 constexpr uint32_t kMhNoPool   = 0xFFFFFFu; // 24-bit pool index
+/// Words of ScanJob::fuse_ctl for a scan of `num_seq` sequences (jg_kernels.hip, fuse_init: 16 + 2 * 256 shared ones, then a
+/// counter and a queue entry per sequence).
+JG_HD constexpr size_t fuse_ctl_words(size_t num_seq) { return 16 + 2 * 256 + 2 * num_seq; }
 JG_HD inline uint32_t mh_pool_entries(uint32_t num_subseq) { return 2u * num_subseq + 64u; } // states; one counter in front
 
 struct CursorEntry {
@@ -413,6 +417,8 @@ struct ScanJob {
     const int* tail_parts;       // [num_tail_parts + 1] subsequence ranges of huff_sync_tail's workgroups
     int num_tail_parts;
     int max_tail_part;           // subsequences in the largest part
+    uint32_t* fuse_ctl;          // control words of huff_tail_write (jg_kernels.hip: the tail kernel and the write pass in ONE launch), set
+                                 //   up by the sequence kernel of the same call: kFuseCtlWords(sequences) of them
     int* tails_n;                // per-sequence aggregates used to place the write pass
     uint32_t* tails_dc01;
     uint32_t* tails_dc23;

@@ -21,6 +21,7 @@
 #include <hip/hip_runtime.h>
 
 #include <cstdlib>
+#include <type_traits>
 
 #include "jg_bytes.h"
 #include "jg_wave.h"
@@ -559,6 +560,35 @@ __device__ uint32_t g_probe_tail[128 * 64];
 #define JG_TAIL_STAMP(i, v) do { } while (0)
 #endif
 
+/// A pointer every lane of the wave holds the same value of, moved to scalar registers where the compiler cannot see that
+/// (huff_tail_write, whose job follows from a ticket): free where it can.
+template <class P>
+__device__ __forceinline__ P uniform_ptr(P p)
+{
+    const uint64_t v  = reinterpret_cast<uint64_t>(p);
+    const uint32_t lo = __builtin_amdgcn_readfirstlane(static_cast<uint32_t>(v)), hi = __builtin_amdgcn_readfirstlane(static_cast<uint32_t>(v >> 32));
+    return reinterpret_cast<P>(static_cast<uint64_t>(hi) << 32 | lo);
+}
+
+/// Loads and stores of the words workgroups of ONE launch hand to each other (huff_tail_write: the states and sequence
+/// tails its parts finish, which its sequences read): kCoherent makes them agent-scope relaxed atomics, which on gfx950 are
+/// plain loads and stores that go to the level of the memory hierarchy all eight XCDs share (sc1) -- every XCD has an L2 of
+/// its own. The alternative, ordinary accesses between a release fence in the writer and an acquire fence in the reader,
+/// costs a write-back of the XCD's whole L2 per writing wave and an invalidation of it per reading wave: measured, the
+/// fused launch took 1 085 us where the two kernels it replaces take 931.
+template <bool kCoherent, class T_>
+__device__ __forceinline__ void st_shared(JG_GLOBAL T_* p, T_ v)
+{
+    if constexpr (kCoherent) __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    else *p = v;
+}
+template <bool kCoherent, class T_>
+__device__ __forceinline__ T_ ld_shared(JG_GLOBAL const T_* p)
+{
+    if constexpr (kCoherent) return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    else return *p;
+}
+
 /// LDS address of a pointer into the workgroup's shared memory.
 __device__ __forceinline__ uint32_t lds_address(const void* p)
 {
@@ -865,6 +895,32 @@ struct SeqLdsBatch {
     static_assert(kTabs % 16 == 0, "the table pack is read with 16-byte loads");
 };
 static_assert(kStaticLdsSlack + SeqLdsBatch::kTabs + kMaxTablePackSync <= 65536, "absolute table addresses are packed into 16 bits (load_tables)");
+/// Control words of huff_tail_write (below), ScanJob::fuse_ctl of every job of the launch, set up by fuse_init from the
+/// sequence kernel of the same call:
+///   [0]                      the launch's ticket counter                              (the FIRST job's words are used)
+///   [kFuseJobs + 2 j + 0/1]  job j's ready queue: entries pushed / entries claimed     (the first job's, j < kFuseMaxJobs)
+///   [kFuseOwn + s]           parts of the tail pass that hold subsequences of sequence s and are not done yet
+///   [kFuseOwn + num_seq + i] the job's ready queue: i-th sequence whose parts are all done (kFuseEmpty: not there yet)
+constexpr int kFuseJobs = 16, kFuseMaxJobs = 256, kFuseOwn = kFuseJobs + 2 * kFuseMaxJobs;
+constexpr uint32_t kFuseEmpty = 0xFFFFFFFFu;
+static_assert(fuse_ctl_words(0) == static_cast<size_t>(kFuseOwn), "the plan carves what fuse_init lays out (jg_defs.h)");
+
+__device__ __forceinline__ void fuse_init(const ScanJob* jobs, int job, const JobView& J, int lanes)
+{
+    JG_GLOBAL uint32_t* own  = as_global(jobs[job].fuse_ctl);
+    JG_GLOBAL uint32_t* ctl0 = as_global(jobs[0].fuse_ctl);
+    const int t = threadIdx.x, SEQ = J.sp.seq_subseq, S = J.sp.num_subseq;
+    if (t < kFuseJobs) own[t] = 0u;
+    if (t < 2 && job < kFuseMaxJobs) ctl0[kFuseJobs + 2 * job + t] = 0u;
+    for (int q = t; q < J.num_seq; q += lanes) {
+        const int first = q * SEQ, last = min(first + SEQ, S) - 1;
+        uint32_t holders = 0;
+        for (int k = 0; k < J.num_tail_parts; ++k) holders += J.tail_parts[k] <= last && J.tail_parts[k + 1] > first ? 1u : 0u;
+        own[kFuseOwn + q]             = holders;
+        own[kFuseOwn + J.num_seq + q] = kFuseEmpty;
+    }
+}
+
 template <int W, class JS>
 __global__ __launch_bounds__(T * kBatchSeqPerWg) void huff_sync_intra_batch(JS js)
 {
@@ -880,6 +936,9 @@ __global__ __launch_bounds__(T * kBatchSeqPerWg) void huff_sync_intra_batch(JS j
     uint8_t* s_tab   = smem + SeqLdsBatch::kTabs;
 
     const JobView J(js.get());
+    if constexpr (std::is_same<JS, JobArray>::value) {
+        if (blockIdx.x == 0) fuse_init(js.jobs, static_cast<int>(blockIdx.y), J, T * kBatchSeqPerWg); // huff_tail_write of the same call
+    }
     if (static_cast<int>(blockIdx.x) * kBatchSeqPerWg >= J.num_seq) return;
     ScanParams sp = J.sp;
     sp.use_sync_pack();
@@ -1371,7 +1430,7 @@ constexpr int kTailLanesSmall = JG_TAIL_LANES_SMALL, kTailLanesLarge = 1024, kTa
 /// Folded into the tail kernel's workgroups (round 5): one launch and its gap fewer in every decode -- 8 of a lone 12 MP
 /// decode's 245 us. Only for the 256-lane kernel: a part of a scan without restart markers holds hundreds of sequences,
 /// which huff_seq_tails sums side by side.
-template <int TL>
+template <int TL, bool kCoherent = false>
 __device__ __forceinline__ void part_seq_tails(const JobView& J, int lo, int hi, uint32_t* s_red)
 {
     static_assert(TL == T, "one sequence per round of the workgroup's lanes");
@@ -1383,7 +1442,12 @@ __device__ __forceinline__ void part_seq_tails(const JobView& J, int lo, int hi,
         const int open_from = ld_global(J.segments + J.seg_idx[last]).subseq_offset;
         const int sub       = first + t;
         const bool take     = sub <= last && sub >= open_from;
-        uint32_t n = take ? static_cast<uint32_t>(J.st_n[sub]) : 0u, d01 = take ? J.st_dc01[sub] : 0u, d23 = take ? J.st_dc23[sub] : 0u;
+        uint32_t n = 0u, d01 = 0u, d23 = 0u;
+        if (take) {
+            n   = static_cast<uint32_t>(ld_shared<kCoherent>(J.st_n + sub));
+            d01 = ld_shared<kCoherent>(J.st_dc01 + sub);
+            d23 = ld_shared<kCoherent>(J.st_dc23 + sub);
+        }
 #pragma unroll
         for (int d = 32; d > 0; d >>= 1) {
             n += __shfl_down(n, d);
@@ -1398,9 +1462,9 @@ __device__ __forceinline__ void part_seq_tails(const JobView& J, int lo, int hi,
         }
         __syncthreads();
         if (t == 0) {
-            J.tails_n[b]    = static_cast<int>(s_red[0] + s_red[3] + s_red[6] + s_red[9]);
-            J.tails_dc01[b] = pk_add_u16(pk_add_u16(s_red[1], s_red[4]), pk_add_u16(s_red[7], s_red[10]));
-            J.tails_dc23[b] = pk_add_u16(pk_add_u16(s_red[2], s_red[5]), pk_add_u16(s_red[8], s_red[11]));
+            st_shared<kCoherent>(J.tails_n + b, static_cast<int>(s_red[0] + s_red[3] + s_red[6] + s_red[9]));
+            st_shared<kCoherent>(J.tails_dc01 + b, pk_add_u16(pk_add_u16(s_red[1], s_red[4]), pk_add_u16(s_red[7], s_red[10])));
+            st_shared<kCoherent>(J.tails_dc23 + b, pk_add_u16(pk_add_u16(s_red[2], s_red[5]), pk_add_u16(s_red[8], s_red[11])));
         }
     }
 }
@@ -1421,25 +1485,26 @@ __device__ __forceinline__ void part_seq_tails(const JobView& J, int lo, int hi,
 /// ahead; only the Huffman tables and the repacking buffer need LDS. With the overlap lanes of
 /// huff_sync_intra a boundary flow normally confirms the stored state in its first iteration; this
 /// kernel is what makes the result exact.
-template <int W, int TL, class JS>
-__global__ __launch_bounds__(TL) void huff_sync_tail(JS js)
+template <int W, int TL, bool kCoherent = false>
+__device__ __forceinline__ void tail_part(const JobView& J, int part, uint8_t* smem, int* s_wave, uint32_t* s_red)
 {
-    extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
-    __shared__ int s_wave[TL / 64];
-    __shared__ uint32_t s_red[12];
     constexpr bool kFusedTails = TL == T; // (the 1024-lane kernel of large parts leaves the sequence tails to huff_seq_tails)
     int* s_j       = reinterpret_cast<int*>(smem); // next subsequence of a surviving flow
     int* s_pz      = s_j + TL;                     // its bit position
     int* s_cz      = s_pz + TL;                    // its c | z << 8
     uint8_t* s_tab = reinterpret_cast<uint8_t*>(s_cz + TL);
 
-    const JobView J(js.get());
-    if (static_cast<int>(blockIdx.x) >= J.num_tail_parts) return;
+#if !defined(JG_NO_TAIL_PRIO)
+    // A part is a chain of dependent instructions of a few lanes: where its waves share a SIMD with the waves of throughput
+    // kernels (other streams' launches; the writers of huff_tail_write) they go first -- what they ask of the issue slots is
+    // next to nothing, and everything downstream waits for them.
+    __builtin_amdgcn_s_setprio(3);
+#endif
     ScanParams sp          = J.sp;
     sp.use_sync_pack();
     JG_GLOBAL const uint32_t* scan32 = reinterpret_cast<JG_GLOBAL const uint32_t*>(J.destuffed);
-    const int lo           = J.tail_parts[blockIdx.x];
-    const int hi           = J.tail_parts[blockIdx.x + 1];
+    const int lo           = J.tail_parts[part];
+    const int hi           = J.tail_parts[part + 1];
     const int tid          = threadIdx.x;
     JG_TAIL_STAMP(0, static_cast<uint32_t>(wall_clock64()));
 
@@ -1477,7 +1542,7 @@ __global__ __launch_bounds__(TL) void huff_sync_tail(JS js)
         count += total;
     }
     if (count == 0) { // (uniform) most parts of a lone decode: nothing crosses a sequence boundary unconfirmed
-        if constexpr (kFusedTails) part_seq_tails<TL>(J, lo, hi, s_red);
+        if constexpr (kFusedTails) part_seq_tails<TL, kCoherent>(J, lo, hi, s_red);
         return;
     }
     load_tables(s_tab, J.tables_sync, sp);
@@ -1519,11 +1584,11 @@ __global__ __launch_bounds__(TL) void huff_sync_tail(JS js)
                     p        = st.p;
                     cz       = st.c | (st.z << 8);
                     flowing  = !(p == J.st_p[j] && cz == J.st_cz[j]) && j + 1 < lim;
-                    J.st_p[j]    = p;
-                    J.st_n[j]    = st.n;
-                    J.st_cz[j]   = cz;
-                    J.st_dc01[j] = st.dc01;
-                    J.st_dc23[j] = st.dc23;
+                    st_shared<kCoherent>(J.st_p + j, p);
+                    st_shared<kCoherent>(J.st_n + j, st.n);
+                    st_shared<kCoherent>(J.st_cz + j, cz);
+                    st_shared<kCoherent>(J.st_dc01 + j, st.dc01);
+                    st_shared<kCoherent>(J.st_dc23 + j, st.dc23);
                     ++j;
                 }
             }
@@ -1555,8 +1620,19 @@ __global__ __launch_bounds__(TL) void huff_sync_tail(JS js)
     JG_TAIL_STAMP(63, static_cast<uint32_t>(count) | static_cast<uint32_t>(trips) << 16);
     if constexpr (kFusedTails) {
         __syncthreads(); // every flow's stores are done and visible to the workgroup
-        part_seq_tails<TL>(J, lo, hi, s_red);
+        part_seq_tails<TL, kCoherent>(J, lo, hi, s_red);
     }
+}
+
+template <int W, int TL, class JS>
+__global__ __launch_bounds__(TL) void huff_sync_tail(JS js)
+{
+    extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
+    __shared__ int s_wave[TL / 64];
+    __shared__ uint32_t s_red[12];
+    const JobView J(js.get());
+    if (static_cast<int>(blockIdx.x) >= J.num_tail_parts) return;
+    tail_part<W, TL>(J, static_cast<int>(blockIdx.x), smem, s_wave, s_red);
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -1835,22 +1911,19 @@ static_assert(kStaticLdsSlack + 3 * kTailLanesLarge * 4 + kMaxTablePackSync <= 6
 /// DC predictors. Lanes SEQ..T-1 have no subsequence here (the sequence is SEQ long); they only help
 /// with the scans. The bitstream is read straight from the destuffed buffer, one refill ahead (as in
 /// huff_sync_tail); LDS holds the ring and the tables: five workgroups per CU.
-template <int W, class JS>
-__global__ __launch_bounds__(T) void huff_write(JS js)
+template <int W, bool kCoherent = false>
+__device__ __forceinline__ void write_sequence(const JobView& J, int seq, uint8_t* smem)
 {
-    extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
     uint32_t* s_scan  = reinterpret_cast<uint32_t*>(smem + WriteLds::kScan); // T + 1
     uint32_t* s_wave  = s_scan + T + 1;                                       // 4
     uint32_t* s_carry = s_wave + 4;                                           // 3
     uint32_t* s_ring  = reinterpret_cast<uint32_t*>(smem + WriteLds::kRing);
     uint8_t* s_tab    = smem + WriteLds::kTabs;
 
-    const JobView J(js.get());
-    if (static_cast<int>(blockIdx.x) >= J.num_seq) return;
     ScanParams sp = J.sp;
     const int t         = threadIdx.x;
     const int SEQ       = sp.seq_subseq;
-    const int first_sub = blockIdx.x * SEQ;
+    const int first_sub = seq * SEQ;
     const int nsub      = min(SEQ, sp.num_subseq - first_sub);
 
     // What the lane needs of its own subsequence and of the one in front, asked for before anything else and without
@@ -1860,10 +1933,10 @@ __global__ __launch_bounds__(T) void huff_write(JS js)
     const int sub_c        = first_sub + min(t, nsub - 1);
     const int lane_seg     = J.seg_idx[sub_c];
     const int first_seg    = J.seg_idx[first_sub];
-    const uint32_t lane_n  = static_cast<uint32_t>(J.st_n[sub_c]);
-    const uint32_t lane_01 = J.st_dc01[sub_c], lane_23 = J.st_dc23[sub_c];
-    const int prev_p       = J.st_p[max(sub_c - 1, 0)];
-    const int prev_cz      = J.st_cz[max(sub_c - 1, 0)];
+    const uint32_t lane_n  = static_cast<uint32_t>(ld_shared<kCoherent>(J.st_n + sub_c));
+    const uint32_t lane_01 = ld_shared<kCoherent>(J.st_dc01 + sub_c), lane_23 = ld_shared<kCoherent>(J.st_dc23 + sub_c);
+    const int prev_p       = ld_shared<kCoherent>(J.st_p + max(sub_c - 1, 0));
+    const int prev_cz      = ld_shared<kCoherent>(J.st_cz + max(sub_c - 1, 0));
 
     load_tables(s_tab, J.tables, sp);
     const Segment lane_segment = ld_global(J.segments + lane_seg);
@@ -1874,10 +1947,10 @@ __global__ __launch_bounds__(T) void huff_write(JS js)
         const int a        = seg0.subseq_offset / SEQ; // sequence holding the segment's start
         uint32_t cn = 0, c01 = 0, c23 = 0;
         if (seg0.subseq_offset < first_sub) {
-            for (int b = a + t; b < static_cast<int>(blockIdx.x); b += T) {
-                cn += static_cast<uint32_t>(J.tails_n[b]);
-                c01 = pk_add(c01, J.tails_dc01[b]);
-                c23 = pk_add(c23, J.tails_dc23[b]);
+            for (int b = a + t; b < seq; b += T) {
+                cn += static_cast<uint32_t>(ld_shared<kCoherent>(J.tails_n + b));
+                c01 = pk_add(c01, ld_shared<kCoherent>(J.tails_dc01 + b));
+                c23 = pk_add(c23, ld_shared<kCoherent>(J.tails_dc23 + b));
             }
         }
         cn  = block_sum_256<false>(cn, s_wave);
@@ -1953,7 +2026,7 @@ __global__ __launch_bounds__(T) void huff_write(JS js)
         st.z         = cz >> 8;
     }
     sink.started = 0u; // until the lane's first DC symbol
-    RowWindow<W> words{GlobalFetch<W, true>{reinterpret_cast<JG_GLOBAL const uint32_t*>(J.destuffed), 0, 0}};
+    RowWindow<W> words{GlobalFetch<W, true>{uniform_ptr(reinterpret_cast<JG_GLOBAL const uint32_t*>(J.destuffed)), 0, 0}};
     words.g.set_row(sub, rel);
     // Iterations a valid stream can need for the bits of the subsequence and of the unit the lane runs on into (64 symbols of
     // at most 32 bits): the densest stream is two-bit data units (a one-bit DC code of category 0 and a one-bit end of
@@ -1978,6 +2051,143 @@ __global__ __launch_bounds__(T) void huff_write(JS js)
 #endif
     sink.finish();
 }
+
+template <int W, class JS>
+__global__ __launch_bounds__(T) void huff_write(JS js)
+{
+    extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
+    const JobView J(js.get());
+    if (static_cast<int>(blockIdx.x) >= J.num_seq) return;
+    write_sequence<W>(J, static_cast<int>(blockIdx.x), smem);
+}
+
+/// The tail kernel's parts AND the write pass's sequences of a batch as ONE launch (round 5). As two launches the chip
+/// waits for the slowest part's chain of dependent flow iterations -- 2-4 whole subsequences by a handful of lanes, 200-500
+/// us per 64 images during which 7 of 8 wave slots are empty -- before the first symbol is written. Here a workgroup takes
+/// a TICKET when it starts (one atomic counter per launch) and the ticket is its role: first every part of every job, then
+/// as many writers as there are sequences. A part that is done counts itself off every sequence it holds subsequences of
+/// (a part is a run of whole segments: the states a sequence reads, its predecessor's exit state and the sequence tails its
+/// look-back adds up -- part_seq_tails -- all lie in the parts that hold its subsequences) and pushes the sequences that
+/// reach zero onto its job's READY QUEUE; a writer claims the next entry of a queue that has one, whichever job's: the
+/// sequences of the parts that are done are written while the slow parts still run, and no writer sits on a wave slot
+/// waiting for ITS sequence while others are ready (with sequences bound to writers by ticket the launch took as long as
+/// the two kernels it replaces).
+/// No deadlock by construction: a writer holds a ticket behind every part's, so every part HAS STARTED (is resident or
+/// done) when a writer first waits, parts wait for nothing, and every sequence is pushed exactly once. Tickets rather
+/// than blockIdx: the order in which workgroups start is not specified. The wait is bounded all the same (a queue that
+/// never fills would hang the chip for every process on it): a writer that gives up leaves its sequence unwritten and
+/// says so in g_fuse_timeouts.
+/// What parts hand to writers goes through st_shared / ld_shared (every XCD has its own L2), the control words through
+/// agent-scope atomics; a part waits for its stores to be taken (s_waitcnt vmcnt(0)) before it counts itself off.
+__device__ unsigned int g_fuse_timeouts;
+constexpr uint32_t kFuseMaxPolls = 1u << 21; // ~2 s of polling
+
+/// `jobs[i]` as memory nothing writes while the kernel runs (the constant address space): behind the ticket's atomic the
+/// compiler no longer takes the job array for unchanged and would load every field of the job per lane, into vector
+/// registers -- the kernels keep a job's forty pointers and its parameters in scalar registers.
+__device__ __forceinline__ const ScanJob& constant_job(const ScanJob* jobs, uint32_t i)
+{
+    typedef const __attribute__((address_space(4))) ScanJob* ConstJob;
+    return *(const ScanJob*)(ConstJob)(jobs + i);
+}
+
+#define JG_FUSE_LOAD(p) __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)
+#define JG_FUSE_ADD(p, v) __hip_atomic_fetch_add(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)
+#define JG_FUSE_STORE(p, v) __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)
+
+template <int W>
+__global__ __launch_bounds__(T) void huff_tail_write(const ScanJob* jobs, int num_jobs, int max_parts, int max_seq)
+{
+    extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
+    __shared__ int s_wave[T / 64];
+    __shared__ uint32_t s_red[12];
+    __shared__ uint32_t s_role, s_claim[2];
+    JG_GLOBAL uint32_t* ctl0 = as_global(jobs[0].fuse_ctl);
+    if (threadIdx.x == 0) s_role = JG_FUSE_ADD(ctl0, 1u);
+    __syncthreads();
+    // (uniform, and known to be: the job's pointers then live in scalar registers as in every other kernel)
+    const uint32_t role = __builtin_amdgcn_readfirstlane(s_role), num_tail = static_cast<uint32_t>(num_jobs) * static_cast<uint32_t>(max_parts);
+    if (role < num_tail) {
+        const uint32_t j   = role / static_cast<uint32_t>(max_parts);
+        const ScanJob& job = constant_job(jobs, j);
+        const int part     = static_cast<int>(role % static_cast<uint32_t>(max_parts));
+        const JobView J(job);
+        if (part >= J.num_tail_parts) return;
+        tail_part<W, T, true>(J, part, smem, s_wave, s_red);
+        // this lane's stores (states, sequence tails: st_shared) have been taken by the memory every XCD reads; then the
+        // part counts itself off its sequences and queues the ones it was the last holder of
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();
+        JG_GLOBAL uint32_t* own = as_global(job.fuse_ctl);
+        const int SEQ = J.sp.seq_subseq, lo = J.tail_parts[part], hi = J.tail_parts[part + 1];
+        for (int q = lo / SEQ + static_cast<int>(threadIdx.x); q <= (hi - 1) / SEQ && q < J.num_seq; q += T) {
+            if (JG_FUSE_ADD(own + kFuseOwn + q, 0xFFFFFFFFu) == 1u) {
+                const uint32_t i = JG_FUSE_ADD(ctl0 + kFuseJobs + 2 * j, 1u);
+                if (i < static_cast<uint32_t>(J.num_seq)) JG_FUSE_STORE(own + kFuseOwn + J.num_seq + i, static_cast<uint32_t>(q));
+            }
+        }
+        return;
+    }
+    // a writer: one per sequence of every job (the static share only says whether there is one for this workgroup)
+    const uint32_t r = role - num_tail;
+    if (r >= static_cast<uint32_t>(num_jobs) * static_cast<uint32_t>(max_seq)) return;
+    const uint32_t home = r / static_cast<uint32_t>(max_seq);
+    if (static_cast<int>(r % static_cast<uint32_t>(max_seq)) >= constant_job(jobs, home).num_seq) return;
+    if (threadIdx.x < 64) { // the first wave looks for a queue with an entry nobody has claimed, 64 jobs at a time from its own on
+        uint32_t polls = 0, got_job = kFuseEmpty, got_i = 0;
+        while (got_job == kFuseEmpty) {
+            for (int base = 0; base < num_jobs && got_job == kFuseEmpty; base += 64) {
+                const int k      = base + static_cast<int>(threadIdx.x);
+                const uint32_t j = (home + static_cast<uint32_t>(k)) % static_cast<uint32_t>(num_jobs);
+                bool has         = false;
+                if (k < num_jobs) {
+                    const uint32_t pushed = JG_FUSE_LOAD(ctl0 + kFuseJobs + 2 * j), claimed = JG_FUSE_LOAD(ctl0 + kFuseJobs + 2 * j + 1);
+                    has                   = claimed < pushed;
+                }
+                const unsigned long long any = __builtin_amdgcn_ballot_w64(has);
+                if (any) {
+                    const int first = __builtin_ctzll(any);
+                    const uint32_t jj = static_cast<uint32_t>(__builtin_amdgcn_readlane(static_cast<int>(j), first));
+                    uint32_t i = 0;
+                    if (threadIdx.x == 0) i = JG_FUSE_ADD(ctl0 + kFuseJobs + 2 * jj + 1, 1u);
+                    i = static_cast<uint32_t>(__builtin_amdgcn_readfirstlane(static_cast<int>(i)));
+                    // (claimed beyond what is pushed yet: the entry will come; beyond the job's sequences: another writer was faster)
+                    if (i < static_cast<uint32_t>(constant_job(jobs, jj).num_seq)) {
+                        got_job = jj;
+                        got_i   = i;
+                    }
+                }
+            }
+            if (got_job == kFuseEmpty) {
+                if (++polls > kFuseMaxPolls) break;
+                __builtin_amdgcn_s_sleep(32);
+            }
+        }
+        uint32_t q = kFuseEmpty;
+        if (got_job != kFuseEmpty) {
+            const ScanJob& job = constant_job(jobs, got_job);
+            JG_GLOBAL uint32_t* entry = as_global(job.fuse_ctl) + kFuseOwn + job.num_seq + got_i;
+            while ((q = JG_FUSE_LOAD(entry)) == kFuseEmpty) {
+                if (++polls > kFuseMaxPolls) break;
+                __builtin_amdgcn_s_sleep(8);
+            }
+        }
+        if (threadIdx.x == 0) {
+            if (q == kFuseEmpty) atomicAdd(&g_fuse_timeouts, 1u);
+            s_claim[0] = got_job;
+            s_claim[1] = q;
+        }
+    }
+    __syncthreads(); // (what the parts stored is read with ld_shared below: no cache is asked to forget anything)
+    const uint32_t seq = __builtin_amdgcn_readfirstlane(s_claim[1]);
+    if (seq == kFuseEmpty) return;
+    const ScanJob& job = constant_job(jobs, __builtin_amdgcn_readfirstlane(s_claim[0]));
+    const JobView J(job);
+    write_sequence<W, true>(J, static_cast<int>(seq), smem);
+}
+#undef JG_FUSE_LOAD
+#undef JG_FUSE_ADD
+#undef JG_FUSE_STORE
 
 // ------------------------------------------------------------------------------------------------
 // dequantisation + inverse DCT
@@ -2447,6 +2657,13 @@ hipError_t allow_lds(K kernel, size_t bytes)
         reinterpret_cast<const void*>(kernel), hipFuncAttributeMaxDynamicSharedMemorySize, static_cast<int>(bytes));
 }
 
+/// Does a batch launch with these extents run huff_tail_write? Asked by the three stages it replaces or skips: only behind
+/// huff_sync_intra_batch (which clears its flags) and only where the tail kernel would run its 256-lane workgroups.
+inline bool fuses_tail_write(const JobExtent& e, int num_jobs)
+{
+    return e.fuse_tail_write && !e.repack_flows && e.max_tail_parts > 0 && e.max_tail_part < kTailLargeFrom && e.max_seq > 0 && num_jobs <= kFuseMaxJobs;
+}
+
 template <int W, class JS>
 hipError_t launch_huff(Stage stage, const JS& js, const JobExtent& e, int grid_y, hipStream_t stream)
 {
@@ -2469,7 +2686,7 @@ hipError_t launch_huff(Stage stage, const JS& js, const JobExtent& e, int grid_y
         }
         break;
     case kStageSyncInter:
-        if (e.max_tail_parts > 0)
+        if (e.max_tail_parts > 0 && !(std::is_same<JS, JobArray>::value && fuses_tail_write(e, grid_y)))
         {
             if (e.max_tail_part >= kTailLargeFrom) {
                 constexpr int TL = kTailLanesLarge;
@@ -2486,6 +2703,17 @@ hipError_t launch_huff(Stage stage, const JS& js, const JobExtent& e, int grid_y
         if (const char* x = std::getenv("JPEGGPU_EXP_EXTRA_LDS")) lds += static_cast<size_t>(std::atoi(x));
         if ((err = allow_lds(huff_write<W, JS>, lds)) != hipSuccess) return err;
 #endif
+        if constexpr (std::is_same<JS, JobArray>::value) {
+            if (fuses_tail_write(e, grid_y)) { // the parts of the tail kernel and the sequences of the write pass, by ticket
+                const size_t tail_lds = 3 * T * 4 + e.max_tab_bytes_sync;
+                lds                   = lds > tail_lds ? lds : tail_lds;
+                if ((err = allow_lds(huff_tail_write<W>, lds)) != hipSuccess) return err;
+                const long long wgs = static_cast<long long>(grid_y) * (static_cast<long long>(e.max_tail_parts) + e.max_seq);
+                if (wgs > 0x7FFFFFFFll) return hipErrorInvalidValue;
+                huff_tail_write<W><<<dim3(static_cast<unsigned>(wgs)), T, lds, stream>>>(js.jobs, grid_y, e.max_tail_parts, e.max_seq);
+                break;
+            }
+        }
         huff_write<W, JS><<<dim3(e.max_seq, grid_y), T, lds, stream>>>(js);
         break;
     }
@@ -2567,6 +2795,11 @@ extern "C" __attribute__((visibility("default"))) int jpeggpu_probe_read(void* d
     return 0;
 }
 #endif
+
+hipError_t read_fuse_timeouts(unsigned int* count)
+{
+    return hipMemcpyFromSymbol(count, HIP_SYMBOL(g_fuse_timeouts), sizeof(unsigned int));
+}
 
 bool subseq_bytes_supported(int b) { return b == 32 || b == 64 || b == 128 || b == 256; }
 

@@ -33,10 +33,14 @@ struct JobExtent {
     int subseq_words    = 0; // identical for every job of a launch
     uint32_t max_tab_bytes = 0;      // largest write-pass table pack
     uint32_t max_tab_bytes_sync = 0; // largest sync pack
+    bool fuse_tail_write = false;    // batch launches: the tail kernel's parts and the write pass's sequences as ONE launch
+                                     // (huff_tail_write), launched at kStageWrite; kStageSyncInter and kStageTails launch nothing
     bool repack_flows   = false;     // batch launches: the lone decode's sequence kernel (every flow kept in its workgroup), for
                                      // calls too small to fill the chip; the jobs then carry max_intra_iters = kSeqLanes, tail_marks = 0
 };
 void extend(JobExtent& e, const ScanJob& job);
+/// Writers of huff_tail_write that gave up waiting (0 on a correct run), since the library was loaded.
+hipError_t read_fuse_timeouts(unsigned int* count);
 
 /// One stage for ONE job passed by value as a kernel argument (the drop-in single-image API).
 hipError_t launch_stage(Stage stage, const ScanJob& job, hipStream_t stream);

@@ -278,15 +278,17 @@ def test_small_batches_with_the_plans_the_library_picks(torch_cuda, images, monk
     pool = mid + [m[k] for k in ("multi_seq_dri", "ni_420_dri", "four_comp_opt", "gray", "multi_seq_nodri", "cfg4_small", "dri_1", "ss_4x1")]
     datas = [pool[i % len(pool)] for i in range(images)]
     refs = [oracle.decode(d) for d in datas]
-    for mode in ("auto", "marks"):
-        if mode == "marks":
+    # "marks": the full batch's path -- since round 5 with the tail kernel's parts and the write pass's sequences in ONE launch
+    # (huff_tail_write: ready queues, tickets); "marks_two_launches": the same with the two kernels one after the other
+    for mode in ("auto", "marks", "marks_two_launches"):
+        if mode != "auto":
             monkeypatch.setenv("JPEGGPU_EXP_KEEP_FLOWS_BELOW", "0")  # read at jpeggpu_ext_batch_create
         keep, entries = [], []
         for i, d in enumerate(datas):
             dec = jpeggpu_amd.Decoder()
             if i % 3 != 2:
                 dec.set_batch_hint(images)  # (every third decoder keeps the lone plan: any decoder may go into any call)
-            if images == 1 and mode == "marks":
+            if images == 1 and mode != "auto":
                 dec.set_device_scan(2)  # the checked mode blocks jpeggpu_decoder_decode only: an item of a batch is never waited for
             info = dec.parse_header(d)
             n, tmp, base, planes = _alloc(torch, dec, info)
@@ -302,6 +304,8 @@ def test_small_batches_with_the_plans_the_library_picks(torch_cuda, images, monk
         batch = jpeggpu_amd.Batch(sum(k[0].layout().num_scans for k in keep))
         scratch = torch.empty(batch.scratch_size, dtype=torch.uint8, device="cuda:0")
         batch.set_items(entries)
+        if mode == "marks_two_launches":
+            batch.set_fused_tail(False)
         for rep in range(2):
             for _, _, planes in keep:
                 for p in planes:
@@ -315,6 +319,7 @@ def test_small_batches_with_the_plans_the_library_picks(torch_cuda, images, monk
         # what the call used: a small call keeps its flows in the sequence kernel (240 + 16 lanes), a full one does not
         used = [k[0].layout().subsequences_per_sequence for k in keep]
         assert used == [240 if mode == "auto" or images == 1 else 255] * images, (mode, used)
+        assert jpeggpu_amd.fused_tail_timeouts() == 0
         if images >= 2:
             # ... and the drop-in call on a decoder that was set up for batches reports its own geometry afterwards
             dec, _, planes = keep[0]

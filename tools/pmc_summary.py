@@ -8,7 +8,7 @@ import os
 import re
 import sys
 
-KERNELS = r"(destuff_kernel|huff_sync_intra|huff_sync_tail|huff_seq_tails|huff_write|idct_kernel)"
+KERNELS = r"(destuff_kernel|huff_sync_intra|huff_sync_tail|huff_seq_tails|huff_tail_write|huff_write|idct_kernel)"
 
 
 def main():

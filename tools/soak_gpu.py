@@ -58,10 +58,16 @@ def main():
             items.append((dec, [p.data_ptr() for p in planes], [p.stride(0) for p in planes], base, n))
             keep.append((dec, tmp, planes, data))
             refs.append(ref)
+        # a third of the calls as if they filled the chip (read when the batch is created): the full batch's kernels -- one flow
+        # iteration, marks, and the tail kernel's parts + the write pass's sequences as one launch (huff_tail_write)
+        full = rng.random() < 0.34
+        os.environ["JPEGGPU_EXP_KEEP_FLOWS_BELOW"] = "0" if full else str(220000)
         batch = jp.Batch(total_scans)
         scratch = torch.empty(batch.scratch_size, dtype=torch.uint8, device="cuda:0")
         batch.set_items(items)
-        if rng.random() < 0.5:  # a caller's cap (marks + tail kernel); else the library's choice: these calls are small, so
+        if full and rng.random() < 0.25:
+            batch.set_fused_tail(False)  # ... or as two launches
+        if not full and rng.random() < 0.5:  # a caller's cap (marks + tail kernel); else the library's choice: these calls are small, so
             batch.set_sync_iterations(int(rng.choice([1, 1, 2, 5, 255, 256])))  # every flow stays in the sequence kernel
         batch.set_overlap(int(rng.integers(1, 5)))
         batch.decode(scratch.data_ptr(), 0)
@@ -120,6 +126,7 @@ def main():
         images += len(keep)
         if rounds % 20 == 0:  # a run that stays silent for minutes is taken to be hung on the GPU pool
             print("  %d rounds, %d images, %.0f s" % (rounds, images, time.time() - t0), flush=True)
+    assert jp.fused_tail_timeouts() == 0, jp.fused_tail_timeouts()
     print("soak ok: %d rounds, %d images (%d of them also decoded as restart-segment shares), %.0f s" % (rounds, images, sharded, time.time() - t0))
 
 

@@ -20,11 +20,11 @@ import re
 import shutil
 import sys
 
-KERNELS = r"(destuff_kernel|huff_sync_intra|huff_sync_tail|huff_seq_tails|huff_write|idct_kernel)"
+KERNELS = r"(destuff_kernel|huff_sync_intra|huff_sync_tail|huff_seq_tails|huff_tail_write|huff_write|idct_kernel)"
 # the read / write shape of each kernel in tools/probe/fetch_probe.hip's terms
 READ_SHAPE = {"destuff_kernel": "rd_wide16", "huff_sync_intra": "rd_dword_rows", "huff_sync_tail": "rd_dword_rows",
-              "huff_seq_tails": "rd_dword_rows", "huff_write": "rd_dword_rows", "idct_kernel": "rd_u16_units"}
-WRITE_SHAPE = {"huff_write": "wr_sector32", "idct_kernel": "wr_row8"}
+              "huff_seq_tails": "rd_dword_rows", "huff_write": "rd_dword_rows", "huff_tail_write": "rd_dword_rows", "idct_kernel": "rd_u16_units"}
+WRITE_SHAPE = {"huff_write": "wr_sector32", "huff_tail_write": "wr_sector32", "idct_kernel": "wr_row8"}
 IMAGES_PER_LAUNCH = 64
 
 
