@@ -18,13 +18,13 @@ def main():
     acc = collections.defaultdict(lambda: collections.defaultdict(list))
     for r in csv.DictReader(open(cc[0])):
         m = re.search(KERNELS, r["Kernel_Name"])
-        if m and "JobArray" in r["Kernel_Name"]:
+        if m and ("JobArray" in r["Kernel_Name"] or m.group(1) == "huff_tail_write"):
             acc[m.group(1)][r["Counter_Name"]].append(float(r["Counter_Value"]))
     dur = collections.defaultdict(list)
     if kt:
         for r in csv.DictReader(open(kt[0])):
             m = re.search(KERNELS, r["Kernel_Name"])
-            if m and "JobArray" in r["Kernel_Name"]:
+            if m and ("JobArray" in r["Kernel_Name"] or m.group(1) == "huff_tail_write"):
                 dur[m.group(1)].append((int(r["End_Timestamp"]) - int(r["Start_Timestamp"])) / 1e3)
     for k in sorted(acc):
         parts = ["%s=%.4g" % (c, sum(v) / len(v)) for c, v in sorted(acc[k].items())]

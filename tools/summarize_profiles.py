@@ -33,7 +33,7 @@ def counters(d):
     for path in glob.glob(os.path.join(d, "**", "*counter_collection.csv"), recursive=True):
         for r in csv.DictReader(open(path)):
             m = re.search(KERNELS, r["Kernel_Name"])
-            if m and "JobArray" in r["Kernel_Name"]:
+            if m and ("JobArray" in r["Kernel_Name"] or m.group(1) == "huff_tail_write"):
                 acc[m.group(1)][r["Counter_Name"]].append(float(r["Counter_Value"]))
     return {k: {c: sum(v) / len(v) for c, v in cs.items()} for k, cs in acc.items()}
 
@@ -90,7 +90,7 @@ def main():
     if os.path.exists(stats):
         for r in csv.DictReader(open(stats)):
             m = re.search(KERNELS, r["Name"])
-            if m and "JobArray" in r["Name"] and m.group(1) in traffic:
+            if m and ("JobArray" in r["Name"] or m.group(1) == "huff_tail_write") and m.group(1) in traffic:
                 traffic[m.group(1)]["profile_avg_us"] = float(r["AverageNs"]) / 1e3
     json.dump(traffic, open(os.path.join(prof, "pmc_traffic.json"), "w"), indent=1)
     json.dump(traffic, open(os.path.join(prof, "%s_pmc_traffic_batch64.json" % rnd), "w"), indent=1)
