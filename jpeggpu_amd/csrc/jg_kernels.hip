@@ -2080,7 +2080,7 @@ __global__ __launch_bounds__(T) void huff_write(JS js)
 /// What parts hand to writers goes through st_shared / ld_shared (every XCD has its own L2), the control words through
 /// agent-scope atomics; a part waits for its stores to be taken (s_waitcnt vmcnt(0)) before it counts itself off.
 __device__ unsigned int g_fuse_timeouts;
-constexpr uint32_t kFuseMaxPolls = 1u << 21; // ~2 s of polling
+constexpr uint32_t kFuseMaxPolls = 1u << 23; // 10-25 s of polling: far beyond any part of a valid or a corrupt stream, even with the chip shared
 
 /// `jobs[i]` as memory nothing writes while the kernel runs (the constant address space): behind the ticket's atomic the
 /// compiler no longer takes the job array for unchanged and would load every field of the job per lane, into vector
