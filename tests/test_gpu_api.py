@@ -334,11 +334,13 @@ def test_small_batches_with_the_plans_the_library_picks(torch_cuda, images, monk
             dec.cleanup()
 
 
-def test_corrupt_entropy_data_is_memory_safe(torch_cuda):
+def test_corrupt_entropy_data_is_memory_safe(torch_cuda, monkeypatch):
     """Random damage inside the entropy-coded segment (no new markers): the planes are garbage by
     definition, but every decode must complete, stay inside its buffers, and leave the decoder and the
     device usable -- the guards that matter for serving untrusted files (quota, region capacity,
-    table clamps, bounded flows). Canary bytes around tmp and the planes must survive."""
+    table clamps, bounded flows). Canary bytes around tmp and the planes must survive. Every damaged file also goes
+    through the batched call, with the kernels of a small call and of one that fills the chip (round 5: the fused
+    launch, whose writers wait for parts -- which must finish whatever the bits say)."""
     import jpeggpu_amd
     from oracle import oracle
 
@@ -378,6 +380,30 @@ def test_corrupt_entropy_data_is_memory_safe(torch_cuda):
             for p in planes:
                 assert (p[0] == 0x5A).all() and (p[-1] == 0x5A).all(), (name, trial, "plane overrun")
             dec.cleanup()
+            # the same bytes as an item of a batched call
+            for below in ("220000", "0"):
+                monkeypatch.setenv("JPEGGPU_EXP_KEEP_FLOWS_BELOW", below)  # read at jpeggpu_ext_batch_create
+                dec = jpeggpu_amd.Decoder(int(rng.choice([32, 64, 128, 256])))
+                dec.set_batch_hint(64)
+                dec.set_device_scan(bool(trial & 2))
+                info = dec.parse_header(bytes(bad))
+                n = dec.get_buffer_size()
+                tmp = torch.full((n + 256 + 2 * guard,), 0x5A, dtype=torch.uint8, device="cuda:0")
+                base = (tmp.data_ptr() + guard + 255) // 256 * 256
+                planes = [torch.full((info.sizes_y[c] + 2, info.sizes_x[c]), 0x5A, dtype=torch.uint8, device="cuda:0") for c in range(info.num_components)]
+                dec.transfer(base, n, 0)
+                batch = jpeggpu_amd.Batch(dec.layout().num_scans)
+                scratch = torch.empty(batch.scratch_size, dtype=torch.uint8, device="cuda:0")
+                batch.set_items([(dec, [p[1:-1].data_ptr() for p in planes], [p.stride(0) for p in planes], base, n)])
+                batch.decode(scratch.data_ptr(), 0)
+                torch.cuda.synchronize()
+                off = base - tmp.data_ptr()
+                assert (tmp[:off] == 0x5A).all() and (tmp[off + n:] == 0x5A).all(), (name, trial, below, "tmp overrun (batch)")
+                for p in planes:
+                    assert (p[0] == 0x5A).all() and (p[-1] == 0x5A).all(), (name, trial, below, "plane overrun (batch)")
+                batch.destroy()
+                dec.cleanup()
+        assert jpeggpu_amd.fused_tail_timeouts() == 0
         # the device still decodes correctly afterwards
         planes, _ = jpeggpu_amd.decode_to_planes(good)
         for c in range(ref.ncomp):
@@ -566,10 +592,14 @@ def test_device_scan_agrees_with_host_walk_on_refusals(torch_cuda, monkeypatch):
             dec.cleanup()
 
 
-def test_batch_with_bad_device_scanned_items(torch_cuda):
+@pytest.mark.parametrize("full_batch_kernels", [False, True])
+def test_batch_with_bad_device_scanned_items(torch_cuda, monkeypatch, full_batch_kernels):
     """A batch in which some device-scanned items turn out to be unusable on the device (scan without terminating
     marker, restart markers that do not follow DRI): those report their status and leave their planes alone, the
-    other items of the same launches decode bit-exact."""
+    other items of the same launches decode bit-exact. Also through the kernels of a call that fills the chip (round 5:
+    huff_tail_write hands out its roles by the launch's extents; the refused jobs hold no part and no sequence)."""
+    if full_batch_kernels:
+        monkeypatch.setenv("JPEGGPU_EXP_KEEP_FLOWS_BELOW", "0")  # read at jpeggpu_ext_batch_create
     import jpeggpu_amd
     from jpeggpu_amd import Status
     from oracle import oracle
@@ -610,6 +640,7 @@ def test_batch_with_bad_device_scanned_items(torch_cuda):
                     assert np.array_equal(planes[c].cpu().numpy(), ref.planes[c]), (name, c, overlap)
             else:
                 assert all((p == 0xAB).all() for p in planes), name
+    assert jpeggpu_amd.fused_tail_timeouts() == 0
     batch.destroy()
     for dec, _, _ in keep:
         dec.cleanup()
