@@ -663,7 +663,9 @@ def roofline_report(args, slot, stage_us, images_per_launch, entries, value, wor
     counters = committed_profile("pmc_counters.json")
     # huff_tail_write (round 5): the tail kernel's parts and the write pass's sequences as one launch, reported under "write";
     # "sync_inter" and "tails" then hold only the gaps between their events (no kernel: not listed below, but counted in the pass)
-    fused = os.environ.get("JPEGGPU_FUSE_TAIL_WRITE", "1") != "0" and stage_us.get("sync_inter", 1e9) < 15.0
+    # (what the library does for a call of this size: fewer than 220 000 subsequences keep the two kernels -- jg_defs.h)
+    call_subseq = images_per_launch * sum(slot.layout.scans[k].num_subsequences for k in range(slot.layout.num_scans))
+    fused = os.environ.get("JPEGGPU_FUSE_TAIL_WRITE", "1") != "0" and call_subseq >= 220000 and stage_us.get("sync_inter", 1e9) < 15.0
     names = dict(KERNEL_NAMES)
     if fused:
         names["write"] = "huff_tail_write"
